@@ -1,0 +1,316 @@
+"""pyref.py - independent big-integer restatement of the reference's sumcheck hot path.
+
+TEST INFRASTRUCTURE ONLY (see oracle/sc_oracle.c header): imported by tests/, by
+oracle/gen_golden.py (which writes tests/golden/*.json) and by nothing in the product.
+
+Everything here works on *canonical* Python ints in [0, p) - no Montgomery form, no
+64-bit tricks - so it shares no arithmetic code with oracle/sc_oracle.c or with the HIP
+kernels; the three must agree value-for-value.  Each function cites the reference
+file:line it follows (paths relative to /root/reference).  The dense-MLE operations are
+those of the un-vendored crate ark-poly = "0.6" (`DenseMultilinearExtension`), restated
+from its published algorithm and anchored on the reference's call sites.
+"""
+
+GOLDILOCKS = 2**64 - 2**32 + 1
+MASK64 = 2**64 - 1
+
+SEED_A = 0xA5A5000000000001
+SEED_B = 0xB6B6000000000002
+SEED_R = 0xC7C7000000000003
+SEED_PT = 0xD8D8000000000004
+
+
+def splitmix64(x):
+    z = (x + 0x9E3779B97F4A7C15) & MASK64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+    return z ^ (z >> 31)
+
+
+def synth_table(seed, log_len, p, start=0):
+    """t[i] = splitmix64(seed + i) mod p."""
+    return [splitmix64((seed + start + i) & MASK64) % p for i in range(1 << log_len)]
+
+
+def synth_challenge(seed, j, p):
+    return splitmix64((seed + j) & MASK64) % p
+
+
+# ---- ark_poly::DenseMultilinearExtension (LE: variable 0 = index bit 0) -------------
+
+def mle_fix_variables(t, r, p):
+    """fix the first len(r) variables; call sites matrix-multiplication/src/lib.rs:83,86,104,105."""
+    poly = list(t)
+    nv = (len(poly) - 1).bit_length()
+    assert len(poly) == 1 << nv
+    for i, ri in enumerate(r, start=1):
+        for b in range(1 << (nv - i)):
+            left, right = poly[2 * b], poly[2 * b + 1]
+            poly[b] = (left + ri * (right - left)) % p
+    return poly[: 1 << (nv - len(r))]
+
+
+def mle_evaluate(t, point, p):
+    """matrix-multiplication/src/lib.rs:97-98."""
+    out = mle_fix_variables(t, point, p)
+    assert len(out) == 1
+    return out[0]
+
+
+def mle_relabel(t, a, b, k):
+    """swap variables [a,a+k) and [b,b+k); matrix-multiplication/src/lib.rs:82."""
+    mask = (1 << k) - 1
+    out = [0] * len(t)
+    for i, v in enumerate(t):
+        fa, fb = (i >> a) & mask, (i >> b) & mask
+        j = i & ~((mask << a) | (mask << b))
+        out[j | (fb << a) | (fa << b)] = v
+    return out
+
+
+# ---- matrix_multiplication::G -------------------------------------------------------
+
+def g_new(n, A_flat, B_flat, point, p):
+    """matrix-multiplication/src/lib.rs:77-92."""
+    f_a = mle_fix_variables(mle_relabel(list(A_flat), 0, n, n), point[:n], p)
+    f_b = mle_fix_variables(list(B_flat), point[n:], p)
+    assert len(f_a) == 1 << n and len(f_b) == 1 << n
+    return f_a, f_b
+
+
+def g_round_evals(a, b, p):
+    """the three running sums of G::to_univariate, matrix-multiplication/src/lib.rs:110-122."""
+    e = [0, 0, 0]
+    for i in range(len(a)):
+        if i & 1:
+            e[1] += a[i] * b[i]
+            e[2] += (2 * a[i] - a[i - 1]) * (2 * b[i] - b[i - 1])
+        else:
+            e[0] += a[i] * b[i]
+    return [x % p for x in e]
+
+
+def interpolate_quadratic(points, p):
+    """matrix-multiplication/src/lib.rs:17-60: dense (c0,c1,c2) through three points."""
+    c = [0, 0, 0]
+    for i in range(3):
+        (xi, yi), (xj, _), (xk, _) = points[i], points[(i + 1) % 3], points[(i + 2) % 3]
+        den_inv = pow((xi - xj) * (xi - xk) % p, p - 2, p)
+        c[0] += xj * xk * yi * den_inv
+        c[1] += (-xj - xk) * yi * den_inv
+        c[2] += yi * den_inv
+    return [x % p for x in c]
+
+
+def g_to_univariate(a, b, p):
+    """matrix-multiplication/src/lib.rs:110-131 -> dense coefficients."""
+    e = g_round_evals(a, b, p)
+    return interpolate_quadratic([(0, e[0]), (1 % p, e[1]), (2 % p, e[2])], p)
+
+
+def poly_eval(c, x, p):
+    acc = 0
+    for coef in reversed(c):
+        acc = (acc * x + coef) % p
+    return acc
+
+
+def g_to_evaluations(a, b, p):
+    """matrix-multiplication/src/lib.rs:137-146."""
+    return [(x * y) % p for x, y in zip(a, b)]
+
+
+def g_evaluate(a, b, point, p):
+    """matrix-multiplication/src/lib.rs:96-101."""
+    return mle_evaluate(a, point, p) * mle_evaluate(b, point, p) % p
+
+
+# ---- sum_check_protocol::{Prover, Verifier} -----------------------------------------
+
+class ProverRef:
+    """sum-check-protocol/src/lib.rs:73-117 specialised to the table-backed G."""
+
+    def __init__(self, a, b, p):
+        self.a, self.b, self.p = list(a), list(b), p
+        self.c_1 = sum(g_to_evaluations(a, b, p)) % p          # :89
+        self.num_vars = (len(a) - 1).bit_length()
+        self.r = []
+
+    def round(self, r_prev, j):                                # :105-112
+        if j != 0:
+            self.r.append(r_prev)
+            self.a = mle_fix_variables(self.a, [r_prev], self.p)
+            self.b = mle_fix_variables(self.b, [r_prev], self.p)
+        return g_to_univariate(self.a, self.b, self.p)
+
+
+class VerifierRef:
+    """sum-check-protocol/src/lib.rs:227-331.  round() returns ('jth', r) / ('final', bool)
+    or raises ValueError for ProverClaimMismatch."""
+
+    def __init__(self, n, oracle, p):
+        self.n, self.oracle, self.p = n, oracle, p
+        self.c_1 = 0
+        self.g_part, self.r = [], []
+
+    def set_c_1(self, c_1):
+        self.c_1 = c_1
+
+    def round(self, g_j, r_j):
+        p = self.p
+        if not self.r:                                         # :284-297
+            ev = (poly_eval(g_j, 0, p) + poly_eval(g_j, 1 % p, p)) % p
+            if self.c_1 != ev:
+                raise ValueError("prover claim mismatches evaluation start %d %d" % (self.c_1, ev))
+            self.g_part.append(g_j)
+            self.r.append(r_j)
+            return ("jth", r_j)
+        if len(self.r) == self.n - 1:                          # :298-310
+            self.r.append(r_j)
+            if self.oracle is None:
+                raise LookupError("verifier has no oracle access to the polynomial")
+            return ("final", poly_eval(g_j, r_j, p) == self.oracle(self.r))
+        prev = poly_eval(self.g_part[-1], self.r[-1], p)       # :313-328
+        ev = (poly_eval(g_j, 0, p) + poly_eval(g_j, 1 % p, p)) % p
+        if prev != ev:
+            raise ValueError("prover claim mismatches evaluation %d %d" % (prev, ev))
+        self.g_part.append(g_j)
+        self.r.append(r_j)
+        return ("jth", r_j)
+
+
+def transcript(a, b, challenges, p):
+    """Full interactive run as in matrix-multiplication/src/lib.rs:337-370 with the
+    verifier's draws scripted by `challenges` (challenges[j] drawn in round j).
+    n = 1 follows the reference literally: Verifier::round takes the 'first round' branch
+    (r is empty, :284) and never reaches FinalRound."""
+    n = (len(a) - 1).bit_length()
+    prover = ProverRef(a, b, p)
+    verifier = VerifierRef(n, lambda pt: g_evaluate(a, b, pt, p), p)
+    verifier.set_c_1(prover.c_1)
+    r_j = 1 % p
+    evals, coeffs, accepted = [], [], None
+    pa, pb = list(a), list(b)
+    for j in range(n):
+        if j:
+            pa = mle_fix_variables(pa, [r_j], p)
+            pb = mle_fix_variables(pb, [r_j], p)
+        evals.append(g_round_evals(pa, pb, p))
+        g_j = prover.round(r_j, j)
+        coeffs.append(g_j)
+        kind, val = verifier.round(g_j, challenges[j])
+        if kind == "jth":
+            r_j = val
+        else:
+            accepted = val
+    return {
+        "c_1": prover.c_1,
+        "evals": evals,
+        "coeffs": coeffs,
+        "final_eval": g_evaluate(a, b, challenges[:n], p),
+        "accepted": accepted,
+    }
+
+
+# ---- multilinear-extensions crate (BE: r[0] <-> index MSB) --------------------------
+
+def vsbw(evals, r, p):
+    """multilinear-extensions/src/lib.rs:6-24."""
+    table = [1 % p]
+    for r_j in r:
+        new = []
+        for e in table:
+            new.append(e * (1 - r_j) % p)
+            new.append(e * r_j % p)
+        table = new
+    return sum(w * v for w, v in zip(table, evals)) % p
+
+
+def cti(evals, r, p):
+    """multilinear-extensions/src/lib.rs:29-60."""
+    n = len(r)
+    res = 0
+    for i, ev in enumerate(evals):
+        w = [1 if i & (1 << j) else 0 for j in reversed(range(n))]
+        basis = 1
+        for x_i, w_i in zip(r, w):
+            basis = basis * (x_i * w_i + (1 - x_i) * (1 - w_i)) % p
+        res += ev * basis
+    return res % p
+
+
+def mle_fix_variables_be(t, r, p):
+    """stride-half pairing: fixes index bits nv-1, nv-2, ... (the crate's variable order)."""
+    poly = list(t)
+    for ri in r:
+        half = len(poly) // 2
+        poly = [(poly[b] + ri * (poly[b + half] - poly[b])) % p for b in range(half)]
+    return poly
+
+
+# ---- two-variables-per-pass identities (checker for the GPU schedule) ---------------
+
+def g_grid_sums(a, b, p):
+    """S[u][v] = sum over quads of a(u,v)*b(u,v), (u,v) in {0,1,2}^2 on index bits (0,1)."""
+    S = [[0] * 3 for _ in range(3)]
+    for q in range(len(a) // 4):
+        def ext(t):
+            g = [[t[4 * q + 2 * h], t[4 * q + 2 * h + 1],
+                  2 * t[4 * q + 2 * h + 1] - t[4 * q + 2 * h]] for h in range(2)]
+            return [[g[0][u], g[1][u], 2 * g[1][u] - g[0][u]] for u in range(3)]
+        ea, eb = ext(a), ext(b)
+        for u in range(3):
+            for v in range(3):
+                S[u][v] += ea[u][v] * eb[u][v]
+    return [[x % p for x in row] for row in S]
+
+
+# ---- other reference call sites that pin the LE index convention --------------------
+
+def poly_mul(a, b, p):
+    out = [0] * (len(a) + len(b) - 1)
+    for i, x in enumerate(a):
+        for j, y in enumerate(b):
+            out[i + j] = (out[i + j] + x * y) % p
+    return out
+
+
+def restrict_poly(b, c, evals, p):
+    """gkr-protocol/src/lib.rs:291-321 -> dense coefficients (trailing zeros trimmed)."""
+    k = [(ci - bi) % p for bi, ci in zip(b, c)]
+    nv = (len(evals) - 1).bit_length()
+    res = [0] * (nv + 1)
+    for i, ev in enumerate(evals):
+        poly = [ev % p]
+        for bit in range(nv):
+            lin = [b[bit] % p, k[bit]]
+            if i & (1 << bit) == 0:
+                lin = [(1 - lin[0]) % p, (-lin[1]) % p]
+            poly = poly_mul(poly, lin, p)
+        for d, x in enumerate(poly):
+            res[d] = (res[d] + x) % p
+    while len(res) > 1 and res[-1] == 0:
+        res.pop()
+    return res
+
+
+def triangle_c1(adj_flat, k, p):
+    """Prover::new on triangle_counting::G: sum of G::to_evaluations,
+    triangle-counting/src/lib.rs:138-172 with idx(i,j,k) = (i << k) | j."""
+    n = 1 << k
+    total = 0
+    for x in range(n):
+        for y in range(n):
+            for z in range(n):
+                total += adj_flat[(y << k) | x] * adj_flat[(z << k) | y] * adj_flat[(z << k) | x]
+    return total % p
+
+
+def matmul(A, B, p):
+    n = len(A)
+    return [[sum(A[i][k] * B[k][j] for k in range(n)) % p for j in range(n)] for i in range(n)]
+
+
+def bits_le(v, nbits):
+    """u32_to_boolean_vec, matrix-multiplication/src/lib.rs:305-313."""
+    return [(v >> i) & 1 for i in range(nbits)]

@@ -1,0 +1,185 @@
+"""Pins the CPU oracle (oracle/sc_oracle.c) against
+  (1) every known-answer vector the reference's own tests hold for this path
+      (tests/golden/reference_kats.json, transcribed with file:line sources),
+  (2) the independent big-integer restatement oracle/pyref.py,
+  (3) the committed transcripts of the synthetic instance.
+No GPU needed."""
+import json
+import os
+import random
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pyref  # noqa: E402
+from oracle import Oracle  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+GOLD = pyref.GOLDILOCKS
+
+
+def load(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+KATS = load("reference_kats.json")
+
+
+def test_kat_mle_f5_grid():
+    """multilinear-extensions/src/lib.rs:76-120"""
+    k = KATS["mle_f5_grid"]
+    o = Oracle(k["p"])
+    ev = o.to_mont(k["evals"])
+    for i in range(5):
+        for j in range(5):
+            r = o.to_mont([i, j])
+            assert o.from_mont1(o.cti(ev, r)) == k["expected_grid"][i][j]
+            assert o.from_mont1(o.vsbw(ev, r)) == k["expected_grid"][i][j]
+            # BE evaluate == LE evaluate at the reversed point
+            assert o.from_mont1(o.evaluate(ev, r[::-1].copy())) == k["expected_grid"][i][j]
+
+
+def test_kat_matmul_book():
+    """matrix-multiplication/src/lib.rs:203-303"""
+    k = KATS["matmul_book"]
+    o = Oracle(k["p"])
+    A = o.to_mont(sum(k["A"], []))
+    B = o.to_mont(sum(k["B"], []))
+    for i in range(2):
+        for j in range(2):
+            pt = o.to_mont(pyref.bits_le(i, 1) + pyref.bits_le(j, 1))
+            fa, fb = o.g_new(1, A, B, pt)
+            assert o.from_mont1(o.c1(fa, fb)) == k["C"][i][j]
+            ch = o.to_mont([3])
+            res = o.prove(fa, fb, ch)
+            assert res["status"] == 0 and o.from_mont1(res["c_1"]) == k["C"][i][j]
+
+
+def test_kat_matmul_randomized_identities():
+    """matrix-multiplication/src/lib.rs:316-374: c_1 == (A*B)[i][j], sum_z g(z) == c_1,
+    and the verifier accepts every round."""
+    k = KATS["matmul_randomized_f5"]
+    p = k["p"]
+    o = Oracle(p)
+    rng = random.Random(1)
+    for case in k["cases"]:
+        logn = case["logn"]
+        n = 1 << logn
+        A = o.to_mont(sum(case["A"], []))
+        B = o.to_mont(sum(case["B"], []))
+        for i in range(n):
+            for j in range(n):
+                pt = o.to_mont(pyref.bits_le(i, logn) + pyref.bits_le(j, logn))
+                fa, fb = o.g_new(logn, A, B, pt)
+                c1 = o.from_mont1(o.c1(fa, fb))
+                assert c1 == case["C"][i][j]
+                tot = sum(o.from_mont1(o.g_evaluate(fa, fb, o.to_mont(pyref.bits_le(z, logn))))
+                          for z in range(n)) % p
+                assert tot == c1
+                ch = o.to_mont([rng.randrange(p) for _ in range(logn)])
+                assert o.prove(fa, fb, ch)["status"] == 0
+
+
+def test_kat_restrict_poly_pins_le_order():
+    """gkr-protocol/src/lib.rs:507-548: [32,385,383] over F_389.  restrict_poly(t) at a
+    point t0 equals the LE evaluate at b + t0*(c-b); checked through the C oracle."""
+    k = KATS["restrict_poly_389"]
+    p = k["p"]
+    o = Oracle(p)
+    assert pyref.restrict_poly(k["b"], k["c"], k["evals"], p) == k["expected_coeffs"]
+    ev = o.to_mont(k["evals"])
+    for t0 in range(7):
+        pt = [(bi + t0 * (ci - bi)) % p for bi, ci in zip(k["b"], k["c"])]
+        expect = pyref.poly_eval(k["expected_coeffs"], t0, p)
+        assert o.from_mont1(o.evaluate(ev, o.to_mont(pt))) == expect
+    # the BE reading of the same table gives a different polynomial: the KAT does pin LE
+    assert any(
+        pyref.vsbw(k["evals"], [(bi + t0 * (ci - bi)) % p for bi, ci in zip(k["b"], k["c"])], p)
+        != pyref.poly_eval(k["expected_coeffs"], t0, p) for t0 in range(7))
+
+
+def test_kat_triangle_index_convention():
+    """triangle-counting/src/lib.rs:232-266, :296-300"""
+    k = KATS["triangle_simple_389"]
+    assert pyref.triangle_c1(sum(k["adjacency"], []), k["k"], k["p"]) == k["expected_c_1"]
+
+
+@pytest.mark.parametrize("entry", load("transcripts.json"),
+                         ids=lambda e: "p%d-n%d" % (e["p"] if e["p"] < 2**40 else 0, e["n"]))
+def test_transcripts_c_oracle_vs_fixture(entry):
+    p, n = entry["p"], entry["n"]
+    o = Oracle(p)
+    a = o.generate(entry["seed_a"], n)
+    b = o.generate(entry["seed_b"], n)
+    if "a" in entry:
+        assert o.from_mont(a) == entry["a"] and o.from_mont(b) == entry["b"]
+    ch = np.array([o.challenge(entry["seed_r"], j + 1) for j in range(n)], dtype=np.uint64)
+    assert o.from_mont(ch) == entry["challenges"]
+    res = o.prove(a, b, ch)
+    assert res["status"] == 0
+    assert o.from_mont1(res["c_1"]) == entry["c_1"]
+    assert [o.from_mont(row) for row in res["evals"]] == entry["evals"]
+    assert [o.from_mont(row) for row in res["coeffs"]] == entry["coeffs"]
+    assert o.from_mont1(res["final_eval"]) == entry["final_eval"]
+
+
+@pytest.mark.parametrize("entry", load("mle_vectors.json"),
+                         ids=lambda e: "p%d-n%d" % (e["p"] if e["p"] < 2**40 else 0, e["n"]))
+def test_mle_vectors(entry):
+    p, n = entry["p"], entry["n"]
+    o = Oracle(p)
+    t = o.generate(entry["seed"], n)
+    pt = o.to_mont(entry["point"])
+    assert o.from_mont1(o.evaluate(t, pt)) == entry["evaluate_le"]
+    assert o.from_mont1(o.vsbw(t, pt)) == entry["evaluate_be"]
+    if n <= 8:
+        assert o.from_mont1(o.cti(t, pt)) == entry["evaluate_be"]
+    k = entry["k"]
+    if entry["fix_le"] is not None:
+        assert o.from_mont(o.fix_variables(t, pt[:k], 0)) == entry["fix_le"]
+        assert o.from_mont(o.fix_variables(t, pt[:k], 1)) == entry["fix_be"]
+
+
+@pytest.mark.parametrize("p", [5, 389, 1572869, GOLD, 2**64 - 59])
+def test_c_oracle_vs_pyref_random(p):
+    rng = random.Random(p % 1000)
+    o = Oracle(p)
+    for n in (1, 2, 3, 4, 7):
+        a_c = [rng.randrange(p) for _ in range(1 << n)]
+        b_c = [rng.randrange(p) for _ in range(1 << n)]
+        ch_c = [rng.randrange(p) for _ in range(n)]
+        t = pyref.transcript(a_c, b_c, ch_c, p)
+        a, b, ch = o.to_mont(a_c), o.to_mont(b_c), o.to_mont(ch_c)
+        res = o.prove(a, b, ch)
+        assert res["status"] == 0
+        assert o.from_mont1(res["c_1"]) == t["c_1"]
+        assert [o.from_mont(r) for r in res["evals"]] == t["evals"]
+        assert [o.from_mont(r) for r in res["coeffs"]] == t["coeffs"]
+        assert o.from_mont1(res["final_eval"]) == t["final_eval"]
+        if n >= 2:
+            S = pyref.g_grid_sums(a_c, b_c, p)
+            assert o.from_mont(o.grid_sums(a, b)) == sum(S, [])
+        # relabel + g_new against pyref
+    n = 2
+    A = [rng.randrange(p) for _ in range(1 << (2 * n))]
+    B = [rng.randrange(p) for _ in range(1 << (2 * n))]
+    pt = [rng.randrange(p) for _ in range(2 * n)]
+    fa, fb = pyref.g_new(n, A, B, pt, p)
+    ga, gb = o.g_new(n, o.to_mont(A), o.to_mont(B), o.to_mont(pt))
+    assert o.from_mont(ga) == fa and o.from_mont(gb) == fb
+
+
+def test_prover_rejects_tampering():
+    """the verifier restatement does reject a wrong claim (sum-check-protocol/src/lib.rs:286-291)"""
+    p = 389
+    a_c = [3, 1, 4, 1, 5, 9, 2, 6]
+    b_c = [2, 7, 1, 8, 2, 8, 1, 8]
+    v = pyref.VerifierRef(3, lambda pt: pyref.g_evaluate(a_c, b_c, pt, p), p)
+    pr = pyref.ProverRef(a_c, b_c, p)
+    v.set_c_1((pr.c_1 + 1) % p)
+    with pytest.raises(ValueError):
+        v.round(pr.round(1, 0), 5)

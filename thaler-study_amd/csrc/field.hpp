@@ -1,0 +1,198 @@
+// 64-bit prime-field arithmetic in Montgomery form (R = 2^64), host + gfx950 device.
+//
+// Table elements are exactly the in-memory words of ark-ff's
+// `Fp64<MontBackend<_, 1>>` (the field type every reference crate instantiates, e.g.
+// /root/reference/sum-check-protocol/src/lib.rs:349-354): one u64 holding x*2^64 mod p,
+// fully reduced to [0, p).  Two arithmetic policies share one interface:
+//
+//   GoldilocksMont - p = 2^64 - 2^32 + 1.  p^-1 = 2^32 + 1 (mod 2^64), so the Montgomery
+//                    reduction is shifts/adds only, and sums of products are accumulated
+//                    unreduced in 160 bits (one reduction per thread, not per product).
+//   MontGeneric    - any odd p < 2^64 with runtime constants (toy moduli 5 / 389 / 1572869
+//                    used by the reference's tests); every product is reduced.
+//
+// Interface (F = policy object, passed by value to kernels):
+//   F.add(a,b) F.sub(a,b) F.dbl(a) F.mul(a,b)         residues in, residue out
+//   F::Acc acc; F.acc_zero(acc); F.acc_mac(acc,a,b); F.acc_get(acc) -> residue of sum(a_i*b_i)
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SC_HD __host__ __device__ __forceinline__
+#else
+#define SC_HD inline
+#endif
+
+namespace sc {
+
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+// 64 x 64 -> 128 product.
+SC_HD void mul_wide(u64 a, u64 b, u64& hi, u64& lo) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  lo = a * b;
+  hi = __umul64hi(a, b);
+#else
+  unsigned __int128 t = (unsigned __int128)a * b;
+  lo = (u64)t;
+  hi = (u64)(t >> 64);
+#endif
+}
+
+// splitmix64 output function on state x (x is "seed + index" in the synthetic instance,
+// BASELINE.md section 3): z = x + gamma, then the two xor-shift-multiply rounds.
+SC_HD u64 splitmix64(u64 x) {
+  u64 z = x + 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// Runtime field description crossing the C ABI (include/sumcheck_hip.h: sc_field).
+struct FieldParams {
+  u64 p;          // odd modulus, 2 < p < 2^64
+  u64 p_inv_neg;  // -p^-1 mod 2^64
+  u64 r_mod_p;    // 2^64 mod p   (Montgomery form of 1)
+  u64 r2_mod_p;   // 2^128 mod p  (to_mont multiplier)
+};
+
+// ---------------------------------------------------------------------------------
+struct MontGeneric {
+  u64 p, p_inv_neg, r1, r2;
+
+  MontGeneric() = default;
+  SC_HD explicit MontGeneric(const FieldParams& f)
+      : p(f.p), p_inv_neg(f.p_inv_neg), r1(f.r_mod_p), r2(f.r2_mod_p) {}
+
+  SC_HD u64 modulus() const { return p; }
+  SC_HD u64 one() const { return r1; }
+
+  SC_HD u64 add(u64 a, u64 b) const {
+    u64 s = a + b;
+    bool carry = s < a;
+    return (carry || s >= p) ? s - p : s;
+  }
+  SC_HD u64 sub(u64 a, u64 b) const {
+    u64 d = a - b;
+    return (a < b) ? d + p : d;
+  }
+  SC_HD u64 dbl(u64 a) const { return add(a, a); }
+
+  // (hi:lo) < p * 2^64  ->  (hi:lo) * 2^-64 mod p
+  SC_HD u64 redc(u64 hi, u64 lo) const {
+    u64 m = lo * p_inv_neg;
+    u64 mh, ml;
+    mul_wide(m, p, mh, ml);
+    (void)ml;                       // lo + ml == 0 (mod 2^64); carry out iff lo != 0
+    u64 t = hi + mh;
+    bool c1 = t < hi;
+    u64 t2 = t + (lo != 0 ? 1u : 0u);
+    bool c2 = t2 < t;
+    return (c1 || c2 || t2 >= p) ? t2 - p : t2;
+  }
+  SC_HD u64 mul(u64 a, u64 b) const {
+    u64 hi, lo;
+    mul_wide(a, b, hi, lo);
+    return redc(hi, lo);
+  }
+  SC_HD u64 to_mont(u64 canonical) const { return mul(canonical, r2); }
+  SC_HD u64 from_mont(u64 m) const { return redc(0, m); }
+  // canonical value of an arbitrary 64-bit word
+  SC_HD u64 reduce_word(u64 z) const { return z % p; }
+
+  typedef u64 Acc;
+  SC_HD void acc_zero(Acc& a) const { a = 0; }
+  SC_HD void acc_mac(Acc& a, u64 x, u64 y) const { a = add(a, mul(x, y)); }
+  SC_HD u64 acc_get(const Acc& a) const { return a; }
+};
+
+// ---------------------------------------------------------------------------------
+struct GoldilocksMont {
+  static constexpr u64 P = 0xFFFFFFFF00000001ull;
+  static constexpr u64 EPS = 0x00000000FFFFFFFFull;  // 2^64 mod p
+  // 2^64 mod p and 2^128 mod p
+  static constexpr u64 R1 = 0x00000000FFFFFFFFull;
+  static constexpr u64 R2 = 0xFFFFFFFE00000001ull;
+
+  GoldilocksMont() = default;
+  SC_HD explicit GoldilocksMont(const FieldParams&) {}
+
+  SC_HD u64 modulus() const { return P; }
+  SC_HD u64 one() const { return R1; }
+
+  SC_HD u64 add(u64 a, u64 b) const {
+    u64 s = a + b;
+    bool carry = s < a;
+    return (carry || s >= P) ? s - P : s;
+  }
+  SC_HD u64 sub(u64 a, u64 b) const {
+    u64 d = a - b;
+    return (a < b) ? d + P : d;
+  }
+  SC_HD u64 dbl(u64 a) const { return add(a, a); }
+
+  // floor(m * p / 2^64) for the m with m*p == lo (mod 2^64), i.e. m = lo * (2^32+1).
+  // m*p = (m - (m>>32)) * 2^64 + (m - (m<<32)); the low word borrows iff m < (m<<32).
+  SC_HD static u64 mp_high(u64 lo) {
+    u64 m = lo + (lo << 32);
+    u64 borrow = (m < (m << 32)) ? 1u : 0u;
+    return m - (m >> 32) - borrow;
+  }
+  // (hi:lo) with hi < p  ->  (hi:lo) * 2^-64 mod p
+  SC_HD u64 redc(u64 hi, u64 lo) const { return sub(hi, mp_high(lo)); }
+  SC_HD u64 mul(u64 a, u64 b) const {
+    u64 hi, lo;
+    mul_wide(a, b, hi, lo);
+    return redc(hi, lo);
+  }
+  SC_HD u64 to_mont(u64 canonical) const { return mul(canonical, R2); }
+  SC_HD u64 from_mont(u64 m) const { return redc(0, m); }
+  SC_HD u64 reduce_word(u64 z) const { return z >= P ? z - P : z; }
+
+  // Unreduced sum of up to 2^32 128-bit products: w0 + w1*2^64 + w2*2^128.
+  struct Acc {
+    u64 w0, w1;
+    u32 w2;
+  };
+  SC_HD void acc_zero(Acc& a) const { a.w0 = 0; a.w1 = 0; a.w2 = 0; }
+  SC_HD void acc_mac(Acc& a, u64 x, u64 y) const {
+    u64 hi, lo;
+    mul_wide(x, y, hi, lo);
+    u64 s0 = a.w0 + lo;
+    u64 c0 = s0 < lo ? 1u : 0u;
+    u64 s1 = a.w1 + hi;
+    u64 c1 = s1 < hi ? 1u : 0u;
+    u64 s1b = s1 + c0;
+    c1 += (s1b < s1) ? 1u : 0u;
+    a.w0 = s0;
+    a.w1 = s1b;
+    a.w2 += (u32)c1;
+  }
+  // (w2*2^128 + w1*2^64 + w0) * 2^-64 mod p  =  w1 - floor(m p / 2^64) + w2 * 2^64  (mod p)
+  SC_HD u64 acc_get(const Acc& a) const {
+    u64 x = reduce_word(a.w1);
+    u64 y = mp_high(a.w0);                       // < p
+    u64 z = ((u64)a.w2 << 32) - (u64)a.w2;       // w2 * (2^32-1) < p
+    return add(sub(x, y), z);
+  }
+};
+
+// Host-side helper: derive the Montgomery constants of an odd modulus.
+inline bool field_params_from_modulus(u64 p, FieldParams* out) {
+  if (p < 3 || (p & 1) == 0) return false;
+  u64 inv = 1;  // Newton iteration for p^-1 mod 2^64
+  for (int i = 0; i < 7; ++i) inv *= 2 - p * inv;
+  out->p = p;
+  out->p_inv_neg = (u64)0 - inv;
+#if !defined(__HIP_DEVICE_COMPILE__)
+  unsigned __int128 r = ((unsigned __int128)1 << 64) % p;
+  out->r_mod_p = (u64)r;
+  out->r2_mod_p = (u64)((r * r) % p);
+#endif
+  return true;
+}
+
+}  // namespace sc
