@@ -1,0 +1,186 @@
+/*
+ * sumcheck_hip.h - C ABI of libsumcheck_hip.so, the MI355X (gfx950) sumcheck prover hot path.
+ *
+ * Drop-in boundary.  In the reference (montekki/thaler-study, Rust) this path sits behind
+ * the generic trait `SumCheckPolynomial<F>` (sum-check-protocol/src/lib.rs:121-156) driven
+ * by `Prover<F,P>` (:73-117) / `Verifier<F,P>` (:227-331); the table arithmetic itself is
+ * ark_poly::DenseMultilinearExtension.  There is no FFI in the reference; these entry
+ * points are what a thin `-sys` crate would bind (INTEGRATION.md shows the Rust side).
+ * Each function cites the reference interface (file:line, relative to the reference
+ * root) it replaces.
+ *
+ * Conventions
+ *  - Every uint64_t field element is the Montgomery residue x*2^64 mod p in [0,p): exactly
+ *    the memory word of ark-ff's `Fp64<MontBackend<_,1>>`, so `&[F]` crosses zero-copy.
+ *  - Tables are multilinear-extension evaluation tables of length 2^k; variable 0 is index
+ *    bit 0 (ark-poly order, "LE") unless an `order` argument says otherwise.
+ *  - Every function returns an int status (SC_OK = 0).  Nothing throws or aborts across the
+ *    ABI; sc_last_error() gives the message for the last non-zero status on that context.
+ *    The reference's prover methods are infallible by signature, so the Rust shim panics
+ *    on a non-zero status (SURVEY.md section 8b "Errors").
+ *  - A context is NOT thread-safe (the reference's `round` takes `&mut self`); use one
+ *    context per prover thread.  Different contexts may be used concurrently.
+ *  - A context owns one HIP stream on one device.  Calls are synchronous from the caller's
+ *    point of view unless stated otherwise.
+ *  - There is no CPU fallback: every entry point that computes fails with SC_ERR_HIP when
+ *    no gfx950 device is usable.
+ */
+#ifndef SUMCHECK_HIP_H
+#define SUMCHECK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SC_OK 0
+#define SC_ERR_ARG 1         /* bad argument (null, non power-of-two length, wrong round index ...) */
+#define SC_ERR_HIP 2         /* HIP runtime / no device */
+#define SC_ERR_RCCL 3        /* collective layer */
+#define SC_ERR_OOM 4         /* device or host allocation failed */
+#define SC_ERR_STATE 5       /* call sequence violates the protocol state machine */
+#define SC_ERR_UNSUPPORTED 6
+
+#define SC_ORDER_LE 0 /* variable 0 = index bit 0: ark_poly::DenseMultilinearExtension */
+#define SC_ORDER_BE 1 /* variable 0 = index MSB: multilinear-extensions/src/lib.rs:6-60 */
+
+/* Field description.  Mirrors `#[derive(MontConfig)] #[modulus = "..."]`
+ * (sum-check-protocol/src/lib.rs:349-354) as runtime constants. */
+typedef struct sc_field {
+  uint64_t p;         /* odd prime modulus, 2 < p < 2^64 */
+  uint64_t p_inv_neg; /* -p^-1 mod 2^64 */
+  uint64_t r_mod_p;   /* 2^64 mod p  (Montgomery form of 1) */
+  uint64_t r2_mod_p;  /* 2^128 mod p */
+} sc_field;
+
+typedef struct sc_ctx sc_ctx;
+typedef struct sc_table sc_table;
+typedef struct sc_prover sc_prover;
+
+/* ---- field helpers (host, O(1)) ------------------------------------------------------- */
+
+/* Fill an sc_field from a modulus.  p = 2^64-2^32+1 selects the Goldilocks kernels. */
+int sc_field_from_modulus(uint64_t p, sc_field* out);
+/* canonical integer <-> Montgomery word (F::from_bigint / into_bigint) */
+uint64_t sc_field_to_mont(const sc_field* f, uint64_t canonical);
+uint64_t sc_field_from_mont(const sc_field* f, uint64_t mont);
+/* interpolate_quadratic_poly through (0,e0),(1,e1),(2,e2): matrix-multiplication/src/lib.rs:17-60,
+ * :124-130.  c[d] = coefficient of X^d. */
+int sc_interpolate_quadratic(const sc_field* f, const uint64_t e[3], uint64_t c[3]);
+
+/* ---- context ------------------------------------------------------------------------- */
+
+int sc_ctx_create(const sc_field* f, int device, sc_ctx** out);
+int sc_ctx_destroy(sc_ctx* ctx);
+/* message of the last failing call on ctx (ctx == NULL: last failing sc_ctx_create) */
+const char* sc_last_error(const sc_ctx* ctx);
+/* Tunables: "vars_per_pass" (1|2), "tail_log" (shard log-size at which a sharded prover
+ * gathers), "max_blocks", "final_mode" (0 second kernel, 1 in-kernel last-block). */
+int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value);
+int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* value);
+int sc_ctx_synchronize(sc_ctx* ctx);
+/* the context's hipStream_t (for HIP-event timing by a benchmark harness) */
+void* sc_ctx_stream(const sc_ctx* ctx);
+/* device-time accounting of the pass kernels launched since the last reset:
+ * out[0] = number of pass launches, out[1] = sum of their durations in ms (HIP events on
+ * the context's stream; enabled by option "time_kernels" = 1). */
+int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset);
+
+/* ---- sharding (one process per GPU) ------------------------------ */
+
+/* 128-byte RCCL unique id, created on rank 0 and broadcast by the caller. */
+int sc_comm_unique_id(uint8_t id[128]);
+/* Join an RCCL communicator.  After this call every table of ctx is the rank-th contiguous
+ * shard (top log2(world) index bits = rank) of a table world times as long. */
+int sc_ctx_comm_init_rccl(sc_ctx* ctx, const uint8_t id[128], int rank, int world);
+/* Same sharding semantics with caller-supplied host collectives (used by tests and by
+ * transports other than RCCL).  allreduce sums count uint64 words elementwise in place
+ * across ranks (plain wrapping u64 adds; the library only ever sends 32-bit limbs);
+ * allgather concatenates count words of every rank in rank order into recv. */
+typedef int (*sc_allreduce_fn)(void* user, uint64_t* buf, size_t count);
+typedef int (*sc_allgather_fn)(void* user, const uint64_t* send, uint64_t* recv, size_t count);
+int sc_ctx_comm_init_host(sc_ctx* ctx, int rank, int world, sc_allreduce_fn allreduce,
+                          sc_allgather_fn allgather, void* user);
+int sc_ctx_comm_rank(const sc_ctx* ctx, int* rank, int* world);
+
+/* ---- tables: DenseMultilinearExtension<F> on the device ------------------------------- */
+
+/* DenseMultilinearExtension::from_evaluations_vec (matrix-multiplication/src/lib.rs:81,85) */
+int sc_table_upload(sc_ctx* ctx, const uint64_t* host, size_t len, sc_table** out);
+/* Synthetic fill on the device:
+ * t[i] = to_mont(splitmix64(seed + start + i) mod p), i < len. */
+int sc_table_generate(sc_ctx* ctx, uint64_t seed, uint64_t start, size_t len, sc_table** out);
+/* `.clone()` (every caller: Prover::new(g.clone()), matrix-multiplication/src/lib.rs:337) */
+int sc_table_clone(sc_ctx* ctx, const sc_table* t, sc_table** out);
+/* DenseMultilinearExtension::to_evaluations (matrix-multiplication/src/lib.rs:138-139) */
+int sc_table_download(sc_ctx* ctx, const sc_table* t, uint64_t* host, size_t len);
+size_t sc_table_len(const sc_table* t);
+const uint64_t* sc_table_device_ptr(const sc_table* t);
+int sc_table_free(sc_ctx* ctx, sc_table* t);
+
+/* DenseMultilinearExtension::fix_variables(&r[..k]) (matrix-multiplication/src/lib.rs:83,86,
+ * 104-105): new[b] = t[2b] + r*(t[2b+1]-t[2b]) per variable for SC_ORDER_LE; stride-half
+ * pairing for SC_ORDER_BE.  *out has len >> k entries.  Input is not modified. */
+int sc_table_fix_variables(sc_ctx* ctx, const sc_table* in, const uint64_t* r, size_t k, int order,
+                           sc_table** out);
+/* Polynomial::evaluate (matrix-multiplication/src/lib.rs:97-98) for SC_ORDER_LE;
+ * vsbw_/cti_multilinear_from_evaluations (multilinear-extensions/src/lib.rs:6-48) for
+ * SC_ORDER_BE.  n must equal log2(len) (times world when sharded: r then holds all n). */
+int sc_table_evaluate(sc_ctx* ctx, const sc_table* t, const uint64_t* r, size_t n, int order,
+                      uint64_t* out);
+/* DenseMultilinearExtension::relabel(a, b, k) (matrix-multiplication/src/lib.rs:82) */
+int sc_table_relabel(sc_ctx* ctx, const sc_table* in, size_t a, size_t b, size_t k, sc_table** out);
+
+/* ---- product of two tables: matrix_multiplication::G --------------------------------- */
+
+/* G::new (matrix-multiplication/src/lib.rs:77-92): A, B are 2^n x 2^n row-major tables of
+ * 2^(2n) entries; point has 2n entries; outputs have 2^n entries. */
+int sc_matmul_g_new(sc_ctx* ctx, const sc_table* A, const sc_table* B, size_t n,
+                    const uint64_t* point, sc_table** a_out, sc_table** b_out);
+/* G::to_evaluations (matrix-multiplication/src/lib.rs:137-146): out[i] = a[i]*b[i] */
+int sc_prod2_to_evaluations(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_table** out);
+/* Prover::new's claim: sum_i a[i]*b[i] (sum-check-protocol/src/lib.rs:89) - never
+ * materialises the product vector. */
+int sc_prod2_sum(sc_ctx* ctx, const sc_table* a, const sc_table* b, uint64_t* out_c1);
+/* G::to_univariate's three sums H(0),H(1),H(2) (matrix-multiplication/src/lib.rs:110-122) */
+int sc_prod2_round_sums(sc_ctx* ctx, const sc_table* a, const sc_table* b, uint64_t out_e[3]);
+/* G::fix_variables(&[r]) followed by to_univariate on the result, fused: one read of the
+ * inputs, one write of the folded tables (matrix-multiplication/src/lib.rs:103-131). */
+int sc_prod2_fold_and_sums(sc_ctx* ctx, const sc_table* a, const sc_table* b, const uint64_t r[1],
+                           sc_table** a_out, sc_table** b_out, uint64_t out_e[3]);
+/* G::evaluate (matrix-multiplication/src/lib.rs:96-101) */
+int sc_prod2_evaluate(sc_ctx* ctx, const sc_table* a, const sc_table* b, const uint64_t* point,
+                      size_t n, uint64_t* out);
+
+/* ---- Prover<F, G> (sum-check-protocol/src/lib.rs:73-117) ------------------------------ */
+
+/* Prover::new(g) (:88-97).  Borrows a and b (they must outlive the prover and are never
+ * written, so the verifier's oracle copy needs no clone).  Computes c_1. */
+int sc_prover_create(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_prover** out);
+/* Prover::c_1 (:100-102) */
+int sc_prover_c1(const sc_prover* pr, uint64_t* out);
+/* Prover::num_vars (:114-116) */
+int sc_prover_num_vars(const sc_prover* pr, size_t* out);
+/* Prover::round(r_prev, j) (:105-112).  Rounds must be called in order j = 0,1,...;
+ * r_prev is ignored for j == 0 like in the reference.  out_e = (H(0),H(1),H(2)) of the
+ * round polynomial; sc_interpolate_quadratic turns it into the coefficients that
+ * `univariate::SparsePolynomial` holds. */
+int sc_prover_round(sc_prover* pr, uint64_t r_prev, size_t j, uint64_t out_e[3]);
+int sc_prover_destroy(sc_prover* pr);
+
+/* Whole interactive run in one call, the loop of mm_benchmark.rs:88-96: Prover::new, then
+ * n rounds; after each round the challenge is obtained from `draw` (called on the host
+ * with the round's three sums already read back - the verifier's rng.draw() at
+ * sum-check-protocol/src/lib.rs:283, or a Fiat-Shamir hash).  draw == NULL uses the
+ * synthetic challenger r_j = to_mont(splitmix64(seed_r + j + 1) mod p).
+ * evals (3*n words) and challenges (n words) may be NULL. */
+typedef uint64_t (*sc_draw_fn)(void* user, size_t round, const uint64_t evals[3]);
+int sc_prove(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_draw_fn draw, void* user,
+             uint64_t seed_r, uint64_t* c1, uint64_t* evals, uint64_t* challenges);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SUMCHECK_HIP_H */

@@ -1,0 +1,133 @@
+"""The sharded (one rank per GPU) prover on ONE GPU: N virtual ranks = N threads, each with
+its own context/stream on device 0 and its own shard, joined by in-process host collectives.
+The control flow per rank is the one the 8-GPU run uses; only the transport differs.  Also
+the RCCL transport itself with world = 1."""
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import load_package
+from util import GOLD, challenges, oracle, pid, pyref
+
+pytestmark = pytest.mark.gpu
+
+
+class Loopback:
+    """sum / concatenate across `world` threads"""
+
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world)
+        self.slots = [None] * world
+        self.n_allreduce = 0
+        self.n_allgather = 0
+
+    def collectives(self, rank):
+        def allreduce(arr):
+            self.slots[rank] = arr.copy()
+            self.barrier.wait()
+            total = np.zeros_like(arr)
+            for s in self.slots:
+                total += s
+            self.barrier.wait()
+            arr[:] = total
+            if rank == 0:
+                self.n_allreduce += 1
+
+        def allgather(send):
+            self.slots[rank] = send.copy()
+            self.barrier.wait()
+            out = np.concatenate(self.slots)
+            self.barrier.wait()
+            if rank == 0:
+                self.n_allgather += 1
+            return out
+
+        return allreduce, allgather
+
+
+def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove"):
+    lb = Loopback(world)
+    results = [None] * world
+    errors = []
+
+    def body(rank):
+        try:
+            ctx = pkg.Context(pkg.Field(p))
+            ctx.set_option("tail_log", tail_log)
+            ctx.set_option("vars_per_pass", vpp)
+            ar, ag = lb.collectives(rank)
+            ctx.comm_init_host(rank, world, ar, ag)
+            start, length = pkg.distributed.shard_range(n, rank, world)
+            nl = length.bit_length() - 1
+            a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, nl, start=start)
+            b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, nl, start=start)
+            g = pkg.matrix_multiplication.G(a, b)
+            assert g.num_vars() == n
+            c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+            final = g.evaluate([int(x) for x in ch])
+            e0 = g.round_evals() if nl >= 1 else None
+            s0 = g.hypercube_sum()
+            results[rank] = (c1, evals, ch, final, e0, s0)
+            ctx.close()
+        except Exception as e:  # pragma: no cover
+            import traceback
+            traceback.print_exc()
+            errors.append(e)
+            lb.barrier.abort()
+
+    threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=300)
+    assert not errors, errors
+    return results, lb
+
+
+@pytest.mark.parametrize("vpp", [1, 2])
+@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+def test_virtual_ranks_match_oracle(p, world, vpp):
+    pkg = load_package()
+    import thaler_study_amd.distributed  # noqa: F401
+    o = oracle(p)
+    g = world.bit_length() - 1
+    for n, tail_log in [(g, 0), (g + 1, 0), (g + 2, 0), (g + 5, 0), (12, 0), (12, 5), (15, 12), (16, 3)]:
+        oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+        ch = challenges(o, n)
+        ref = o.prove(oa, ob, ch)
+        results, lb = run_virtual_ranks(pkg, p, n, world, tail_log, vpp)
+        for rank, (c1, evals, chn, final, e0, s0) in enumerate(results):
+            assert c1 == ref["c_1"], (n, tail_log, rank)
+            assert np.array_equal(evals, ref["evals"]), (n, tail_log, rank)
+            assert final == ref["final_eval"], (n, tail_log, rank)
+            assert s0 == ref["c_1"]
+            if e0 is not None:
+                assert e0 == [int(x) for x in ref["evals"][0]]
+        # with tail_log 0 and enough local variables the run really used per-pass all-reduces
+        if tail_log == 0 and n - g >= 4:
+            assert lb.n_allreduce >= 2
+        assert lb.n_allgather >= 2  # the tail gather of both tables
+
+
+def test_rccl_world1():
+    """the in-library RCCL transport (ncclCommInitRank / AllReduce / AllGather) with one rank"""
+    pkg = load_package()
+    import thaler_study_amd.distributed as D
+    o = oracle(GOLD)
+    for n, tail_log in [(14, 4), (10, 12), (3, 0)]:
+        ctx = pkg.Context(pkg.Field(GOLD))
+        ctx.set_option("tail_log", tail_log)
+        D.attach_rccl(ctx, 0, 1)
+        assert ctx.rank_world() == (0, 1)
+        a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
+        b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, n)
+        g = pkg.matrix_multiplication.G(a, b)
+        c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+        ref = o.prove(o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n), ch)
+        assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+        assert g.evaluate([int(x) for x in ch]) == ref["final_eval"]
+        del a, b, g
+        ctx.close()

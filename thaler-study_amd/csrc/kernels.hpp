@@ -1,0 +1,366 @@
+// gfx950 device kernels of the sumcheck prover hot path.
+//
+// All kernels stream evaluation tables of 64-bit field words; they are bound by HBM
+// bandwidth, not by VALU (DESIGN.md "Kernels").  Wavefront = 64 lanes; every thread owns a
+// contiguous run of table entries so that both halves of a fold pair (LE order: entries
+// 2b and 2b+1, matrix-multiplication/src/lib.rs:114-121 of the reference) sit in the same
+// lane and every global access is a 16-byte dwordx4.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "field.hpp"
+
+namespace sc {
+
+constexpr int kBlock = 256;        // 4 waves per workgroup
+constexpr int kWave = 64;
+constexpr int kMaxSums = 9;
+constexpr int kPartialStride = 16; // u64 words per block row in the partials buffer (128 B)
+
+typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+
+template <int N>
+__device__ __forceinline__ void load_run(const u64* __restrict__ p, u64 (&v)[N]) {
+  static_assert(N >= 2 && (N % 2) == 0, "runs are whole 16-byte pieces");
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) {
+    ull2 x = __builtin_nontemporal_load(reinterpret_cast<const ull2*>(p) + i);
+    v[2 * i] = x.x;
+    v[2 * i + 1] = x.y;
+  }
+}
+template <int N>
+__device__ __forceinline__ void store_run(u64* __restrict__ p, const u64 (&v)[N]) {
+  static_assert(N >= 2 && (N % 2) == 0, "runs are whole 16-byte pieces");
+#pragma unroll
+  for (int i = 0; i < N / 2; ++i) {
+    ull2 x;
+    x.x = v[2 * i];
+    x.y = v[2 * i + 1];
+    reinterpret_cast<ull2*>(p)[i] = x;
+  }
+}
+
+// Fold KF variables (LE) of a run of IN entries in registers; the first IN >> KF entries
+// of v hold the result.  new[b] = t[2b] + r*(t[2b+1] - t[2b])  (ark-poly fix_variables).
+template <class F, int KF, int IN>
+__device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], u64 r0, u64 r1) {
+  if constexpr (KF >= 1) {
+#pragma unroll
+    for (int b = 0; b < IN / 2; ++b) v[b] = f.add(v[2 * b], f.mul(r0, f.sub(v[2 * b + 1], v[2 * b])));
+  }
+  if constexpr (KF >= 2) {
+#pragma unroll
+    for (int b = 0; b < IN / 4; ++b) v[b] = f.add(v[2 * b], f.mul(r1, f.sub(v[2 * b + 1], v[2 * b])));
+  }
+}
+
+// Round sums of the product of two tables over one run of OUT = 2^KS entries.
+//  KS = 1: acc[0..2] = H(0), H(1), H(2)   (matrix-multiplication/src/lib.rs:116-120)
+//  KS = 2: acc[3u+v] = a(u,v)*b(u,v), (u,v) in {0,1,2}^2, u on index bit 0, v on bit 1
+template <class F, int KS>
+__device__ __forceinline__ void accumulate_run(const F& f, typename F::Acc* acc, const u64* a,
+                                               const u64* b) {
+  if constexpr (KS == 1) {
+    f.acc_mac(acc[0], a[0], b[0]);
+    f.acc_mac(acc[1], a[1], b[1]);
+    f.acc_mac(acc[2], f.sub(f.dbl(a[1]), a[0]), f.sub(f.dbl(b[1]), b[0]));
+  } else {
+    u64 ea[3][3], eb[3][3];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      ea[0][h] = a[2 * h];
+      ea[1][h] = a[2 * h + 1];
+      ea[2][h] = f.sub(f.dbl(a[2 * h + 1]), a[2 * h]);
+      eb[0][h] = b[2 * h];
+      eb[1][h] = b[2 * h + 1];
+      eb[2][h] = f.sub(f.dbl(b[2 * h + 1]), b[2 * h]);
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      ea[u][2] = f.sub(f.dbl(ea[u][1]), ea[u][0]);
+      eb[u][2] = f.sub(f.dbl(eb[u][1]), eb[u][0]);
+    }
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) f.acc_mac(acc[3 * u + v], ea[u][v], eb[u][v]);
+  }
+}
+
+__device__ __forceinline__ u64 shfl_down_u64(u64 v, int off) {
+  return (u64)__shfl_down((unsigned long long)v, off, kWave);
+}
+
+// Block-wide modular sum of NS per-thread residues; result valid in threads [0, NS).
+template <class F, int NS>
+__device__ __forceinline__ void block_reduce(const F& f, u64 (&res)[NS], u64* lds /*[4][NS]*/) {
+#pragma unroll
+  for (int off = kWave / 2; off >= 1; off >>= 1) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) res[s] = f.add(res[s], shfl_down_u64(res[s], off));
+  }
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (lane == 0) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) lds[wave * NS + s] = res[s];
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    u64 t = lds[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < kBlock / kWave; ++w) t = f.add(t, lds[w * NS + threadIdx.x]);
+    res[0] = t;  // thread s holds sum s in res[0]
+  }
+}
+
+// Split a residue into 32-bit limbs so that a plain u64 sum across <= 2^32 ranks cannot
+// wrap ("modular all-reduce").
+__device__ __forceinline__ void write_split(u64* out, int s, u64 v) {
+  out[2 * s] = v & 0xFFFFFFFFull;
+  out[2 * s + 1] = v >> 32;
+}
+
+// ------------------------------------------------------------------------------------
+// Wave-private LDS transposition.
+//
+// Global accesses are only ever "lane i <-> 16-byte piece base+i" (one dwordx4 per lane,
+// 1 KiB contiguous per wave-instruction): that pattern streams at ~6.4 TB/s on MI355X,
+// while letting each lane walk its own 32..128-byte run costs 15-75 % of the bandwidth
+// (profiles/r01_*).  The arithmetic, however, wants every lane to own a run of NP
+// consecutive pieces.  Each wave therefore bounces its tile (64*NP pieces) through a
+// private LDS region: written in load order, read back in run order.  The slot of piece
+// q = NP*l + m is NP*l + (m ^ ((l >> log2(16/NP)) & (NP-1))): with that XOR both the
+// ds_write_b128 (8 consecutive lanes = 128 contiguous bytes, permuted) and the
+// ds_read_b128 (lane stride NP*16 bytes) are bank-conflict free for every 16-lane group
+// the hardware forms (MI355X_MICROARCH.md, LDS table).  No workgroup barrier is needed:
+// the region is private to the wave and LDS operations of one wave execute in order.
+template <int NP>
+__device__ __forceinline__ int swz_slot(int q) {
+  if constexpr (NP == 1) return q;
+  constexpr int SH = (NP == 2) ? 3 : (NP == 4) ? 2 : 1;  // log2(16 / NP)
+  const int l = q / NP;
+  return (q & ~(NP - 1)) | ((q ^ (l >> SH)) & (NP - 1));
+}
+__device__ __forceinline__ void wave_lds_fence() {
+  // orders this wave's LDS writes before its later LDS reads (s_waitcnt lgkmcnt(0)) and
+  // stops the compiler from moving them across
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+  __builtin_amdgcn_wave_barrier();
+}
+// in: v[k] = piece 64k + lane of the wave tile; out: v[m] = piece NP*lane + m
+template <int NP>
+__device__ __forceinline__ void transpose_to_runs(ull2* __restrict__ lds, ull2 (&v)[NP], int lane) {
+  if constexpr (NP > 1) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) lds[swz_slot<NP>(64 * k + lane)] = v[k];
+    wave_lds_fence();
+#pragma unroll
+    for (int m = 0; m < NP; ++m) v[m] = lds[swz_slot<NP>(NP * lane + m)];
+    wave_lds_fence();
+  }
+}
+// in: v[m] = piece NP*lane + m; out: v[k] = piece 64k + lane
+template <int NP>
+__device__ __forceinline__ void transpose_to_pieces(ull2* __restrict__ lds, ull2 (&v)[NP], int lane) {
+  if constexpr (NP > 1) {
+#pragma unroll
+    for (int m = 0; m < NP; ++m) lds[swz_slot<NP>(NP * lane + m)] = v[m];
+    wave_lds_fence();
+#pragma unroll
+    for (int k = 0; k < NP; ++k) v[k] = lds[swz_slot<NP>(64 * k + lane)];
+    wave_lds_fence();
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// The pass kernel: fold KF pending variables of both tables, write the folded tables,
+// and accumulate the round sums of the FOLDED tables for the next KS rounds - one read of
+// the inputs, one write of the outputs (reference: Prover::round =
+// fix_variables + to_univariate, sum-check-protocol/src/lib.rs:105-112).
+//
+// unit = one run of IN = 2^(KF+KS) input entries per table -> OUT = 2^KS output entries,
+// owned by one lane; a wave tile is 64 units.  gridDim.x == 1: the single block writes the
+// final split-limb sums to `sums_out`; otherwise block b writes its partial residues to
+// partials[b*kPartialStride + s] and final_reduce_kernel finishes.
+template <class F, int KF, int KS>
+__global__ void __launch_bounds__(kBlock)
+pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
+            u64* __restrict__ B2, u64 r0, u64 r1, size_t n_units, u64* __restrict__ partials,
+            u64* __restrict__ sums_out) {
+  constexpr int IN = 1 << (KF + KS), OUT = 1 << KS, NS = (KS == 1) ? 3 : 9;
+  constexpr int NP = IN / 2, NPO = OUT / 2;  // 16-byte pieces per lane, in and out
+  constexpr int kWaves = kBlock / kWave;
+  __shared__ ull2 lds_t[(NP > 1 || NPO > 1) ? kWaves * kWave * NP : 1];
+  __shared__ u64 lds[kWaves * NS];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  ull2* const my_lds = lds_t + ((NP > 1 || NPO > 1) ? wave * kWave * NP : 0);
+
+  typename F::Acc acc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) f.acc_zero(acc[s]);
+
+  const size_t n_tiles = (n_units + kWave - 1) / kWave;
+  const size_t in_pieces = n_units * NP, out_pieces = n_units * NPO;
+  const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(A);
+  const ull2* __restrict__ Bp = reinterpret_cast<const ull2*>(B);
+  ull2* __restrict__ A2p = reinterpret_cast<ull2*>(A2);
+  ull2* __restrict__ B2p = reinterpret_cast<ull2*>(B2);
+
+  for (size_t tile = (size_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (size_t)gridDim.x * kWaves) {
+    const size_t q0 = tile * kWave * NP;
+    ull2 pa[NP], pb[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const size_t q = q0 + (size_t)k * kWave + lane;
+      const ull2 zero = {0, 0};
+      pa[k] = (q < in_pieces) ? Ap[q] : zero;   // inactive lanes carry zeros: they add
+      pb[k] = (q < in_pieces) ? Bp[q] : zero;   // nothing to the sums and store nothing
+    }
+    transpose_to_runs<NP>(my_lds, pa, lane);
+    transpose_to_runs<NP>(my_lds, pb, lane);
+    u64 a[IN], b[IN];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      a[2 * k] = pa[k].x; a[2 * k + 1] = pa[k].y;
+      b[2 * k] = pb[k].x; b[2 * k + 1] = pb[k].y;
+    }
+    fold_run<F, KF, IN>(f, a, r0, r1);
+    fold_run<F, KF, IN>(f, b, r0, r1);
+    if constexpr (KF > 0) {
+      ull2 oa[NPO], ob[NPO];
+#pragma unroll
+      for (int m = 0; m < NPO; ++m) {
+        oa[m].x = a[2 * m]; oa[m].y = a[2 * m + 1];
+        ob[m].x = b[2 * m]; ob[m].y = b[2 * m + 1];
+      }
+      transpose_to_pieces<NPO>(my_lds, oa, lane);
+      transpose_to_pieces<NPO>(my_lds, ob, lane);
+      const size_t o0 = tile * kWave * NPO;
+#pragma unroll
+      for (int k = 0; k < NPO; ++k) {
+        const size_t q = o0 + (size_t)k * kWave + lane;
+        if (q < out_pieces) {
+          A2p[q] = oa[k];
+          B2p[q] = ob[k];
+        }
+      }
+    }
+    accumulate_run<F, KS>(f, acc, a, b);
+  }
+
+  u64 res[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) res[s] = f.acc_get(acc[s]);
+  block_reduce<F, NS>(f, res, lds);
+  if (threadIdx.x < NS) {
+    if (gridDim.x == 1) write_split(sums_out, threadIdx.x, res[0]);
+    else partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = res[0];
+  }
+}
+
+// One block: sums_out[2s], sums_out[2s+1] = split limbs of sum_b partials[b][s].
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+final_reduce_kernel(F f, const u64* __restrict__ partials, int n_blocks, int ns,
+                    u64* __restrict__ sums_out) {
+  __shared__ u64 lds[kBlock];
+  const int s = threadIdx.x & 15, g = threadIdx.x >> 4;  // 16 groups x 16 sum slots
+  u64 t = 0;
+  if (s < ns)
+    for (int b = g; b < n_blocks; b += kBlock / 16) t = f.add(t, partials[(size_t)b * kPartialStride + s]);
+  lds[threadIdx.x] = t;
+  __syncthreads();
+  if (threadIdx.x < ns) {
+    u64 v = lds[threadIdx.x];
+    for (int k = 1; k < kBlock / 16; ++k) v = f.add(v, lds[k * 16 + threadIdx.x]);
+    write_split(sums_out, threadIdx.x, v);
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Single-table folds (DenseMultilinearExtension::fix_variables on its own).
+
+// LE: thread folds a run of 2^(KF+1) entries down to 2 outputs (one 16-byte store).
+template <class F, int KF>
+__global__ void __launch_bounds__(kBlock)
+fold_le_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, u64 r0, u64 r1, size_t n_units) {
+  constexpr int IN = 2 << KF;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t u = (size_t)blockIdx.x * kBlock + threadIdx.x; u < n_units; u += stride) {
+    u64 v[IN];
+    load_run<IN>(T + u * IN, v);
+    fold_run<F, KF, IN>(f, v, r0, r1);
+    u64 o[2] = {v[0], v[1]};
+    store_run<2>(T2 + u * 2, o);
+  }
+}
+// LE, scalar tail: tables so short that a run would not fit (len_out == 1).
+template <class F>
+__global__ void fold_le_small_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, u64 r,
+                                     size_t n_out) {
+  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n_out) T2[b] = f.add(T[2 * b], f.mul(r, f.sub(T[2 * b + 1], T[2 * b])));
+}
+// BE (variable = current MSB): out[b] = t[b] + r*(t[b+half] - t[b]); two entries per thread
+// when half is even, scalar otherwise.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+fold_be_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, u64 r, size_t half) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  if ((half & 1) == 0) {
+    for (size_t u = (size_t)blockIdx.x * kBlock + threadIdx.x; u < half / 2; u += stride) {
+      u64 lo[2], hi[2];
+      load_run<2>(T + 2 * u, lo);
+      load_run<2>(T + half + 2 * u, hi);
+      u64 o[2] = {f.add(lo[0], f.mul(r, f.sub(hi[0], lo[0]))), f.add(lo[1], f.mul(r, f.sub(hi[1], lo[1])))};
+      store_run<2>(T2 + 2 * u, o);
+    }
+  } else {
+    for (size_t b = (size_t)blockIdx.x * kBlock + threadIdx.x; b < half; b += stride)
+      T2[b] = f.add(T[b], f.mul(r, f.sub(T[b + half], T[b])));
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Elementwise / utility kernels.
+
+// t[i] = to_mont(splitmix64(seed + start + i) mod p)   
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+generate_kernel(F f, u64 seed, u64 start, size_t len, u64* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += stride)
+    out[i] = f.to_mont(f.reduce_word(splitmix64(seed + start + i)));
+}
+
+// G::to_evaluations: out[i] = a[i]*b[i]   (matrix-multiplication/src/lib.rs:137-146)
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+mul_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ out, size_t len) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += stride)
+    out[i] = f.mul(A[i], B[i]);
+}
+
+// DenseMultilinearExtension::relabel: out[swap_fields(i)] = t[i]; the swap is an involution
+// so it is applied to the (coalesced) output index.
+__global__ void __launch_bounds__(kBlock)
+relabel_kernel(const u64* __restrict__ T, u64* __restrict__ out, size_t len, unsigned a, unsigned b,
+               unsigned k) {
+  const size_t mask = ((size_t)1 << k) - 1;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < len; j += stride) {
+    size_t fa = (j >> a) & mask, fb = (j >> b) & mask;
+    size_t i = (j & ~((mask << a) | (mask << b))) | (fb << a) | (fa << b);
+    out[j] = T[i];
+  }
+}
+
+// Sharded evaluate helper: out_split = split limbs of w * v (one thread).
+template <class F>
+__global__ void scale_split_kernel(F f, const u64* __restrict__ v, u64 w, u64* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) write_split(out, 0, f.mul(w, v[0]));
+}
+
+}  // namespace sc

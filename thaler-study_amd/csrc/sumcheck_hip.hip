@@ -1,0 +1,1183 @@
+// libsumcheck_hip.so - host engine + C ABI (include/sumcheck_hip.h) over the gfx950 kernels.
+//
+// Layout of this file:
+//   1. context, error plumbing, device-buffer pool, workspace
+//   2. collective transports (none / RCCL via dlopen / caller-supplied host callbacks)
+//   3. kernel launch helpers (field dispatch Goldilocks vs generic Montgomery)
+//   4. table API (upload/generate/clone/download/fix_variables/evaluate/relabel)
+//   5. product-of-two-tables API (matrix_multiplication::G)
+//   6. the prover state machine (sum_check_protocol::Prover) with the
+//      two-variables-per-pass schedule and the sharded (one rank per GPU) mode
+//
+// There is deliberately no CPU path: without a usable HIP device every computing entry
+// point fails with SC_ERR_HIP.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/sumcheck_hip.h"
+#include "kernels.hpp"
+
+using sc::u64;
+
+// =====================================================================================
+// 1. context
+// =====================================================================================
+
+namespace {
+
+struct RcclApi {
+  void* handle = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
+                            hipStream_t) = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+RcclApi g_rccl;
+std::string g_create_error;
+
+bool load_rccl(std::string* why) {
+  if (g_rccl.handle) return true;
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  void* h = nullptr;
+  for (const char* n : names) {
+    h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    if (h) break;
+  }
+  if (!h) {
+    *why = std::string("dlopen(librccl) failed: ") + dlerror();
+    return false;
+  }
+  RcclApi a;
+  a.handle = h;
+  a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+  a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
+  a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
+  a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
+  a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather) {
+    *why = "librccl is missing a required symbol";
+    return false;
+  }
+  g_rccl = a;
+  return true;
+}
+
+enum class Transport { kNone, kRccl, kHost };
+
+}  // namespace
+
+struct sc_ctx {
+  sc::FieldParams fp;
+  bool gold = false;
+  int device = 0;
+  hipStream_t stream = nullptr;
+  mutable std::string err;
+
+  // options
+  int vars_per_pass = 2;
+  int tail_log = 12;
+  int max_blocks = 2048;
+  int time_kernels = 0;
+
+  // workspace
+  u64* d_partials = nullptr;  // [max_blocks][kPartialStride]
+  u64* d_sums = nullptr;      // 2*kMaxSums split limbs (+ spare)
+  u64* h_sums = nullptr;      // pinned mirror
+  size_t partial_rows = 0;
+
+  // device-buffer pool (free blocks by capacity in words; live blocks by pointer)
+  std::multimap<size_t, u64*> pool_free;
+  std::map<u64*, size_t> pool_live;
+
+  // sharding
+  Transport transport = Transport::kNone;
+  int rank = 0, world = 1, log_world = 0;
+  ncclComm_t comm = nullptr;
+  sc_allreduce_fn host_allreduce = nullptr;
+  sc_allgather_fn host_allgather = nullptr;
+  void* host_user = nullptr;
+
+  // kernel timing
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  double kt_ms = 0.0;
+  long kt_n = 0;
+  bool kt_pending = false;
+};
+
+struct sc_table {
+  u64* d = nullptr;
+  size_t len = 0;
+};
+
+namespace {
+
+int fail(const sc_ctx* ctx, int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  if (ctx) ctx->err = buf;
+  else g_create_error = buf;
+  return code;
+}
+
+#define SC_HIP(ctx, call)                                                                  \
+  do {                                                                                     \
+    hipError_t e_ = (call);                                                                \
+    if (e_ != hipSuccess)                                                                  \
+      return fail(ctx, e_ == hipErrorOutOfMemory ? SC_ERR_OOM : SC_ERR_HIP, "%s: %s (%s:%d)", \
+                  #call, hipGetErrorString(e_), __FILE__, __LINE__);                       \
+  } while (0)
+
+#define SC_TRY(expr)            \
+  do {                          \
+    int rc_ = (expr);           \
+    if (rc_ != SC_OK) return rc_; \
+  } while (0)
+
+inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+inline int log2_of(size_t x) {
+  int l = 0;
+  while (((size_t)1 << l) < x) ++l;
+  return l;
+}
+
+// ---- host field arithmetic (O(1) work per round: Lagrange weights, limb recombination) --
+
+struct HostField {
+  sc::MontGeneric f;
+  explicit HostField(const sc::FieldParams& p) : f(p) {}
+  u64 add(u64 a, u64 b) const { return f.add(a, b); }
+  u64 sub(u64 a, u64 b) const { return f.sub(a, b); }
+  u64 mul(u64 a, u64 b) const { return f.mul(a, b); }
+  u64 one() const { return f.r1; }
+  u64 neg(u64 a) const { return a ? f.p - a : 0; }
+  u64 pow(u64 a, u64 e) const {
+    u64 r = one();
+    while (e) {
+      if (e & 1) r = mul(r, a);
+      a = mul(a, a);
+      e >>= 1;
+    }
+    return r;
+  }
+  u64 inv(u64 a) const { return pow(a, f.p - 2); }
+  // (sum of low limbs) + 2^32 * (sum of high limbs)  mod p
+  u64 recombine(u64 lo_sum, u64 hi_sum) const {
+    unsigned __int128 v = ((unsigned __int128)hi_sum << 32) + lo_sum;
+    return (u64)(v % f.p);
+  }
+};
+
+// ---- pool ---------------------------------------------------------------------------
+
+int pool_alloc(sc_ctx* ctx, size_t words, u64** out) {
+  if (words < 32) words = 32;
+  auto it = ctx->pool_free.lower_bound(words);
+  if (it != ctx->pool_free.end() && it->first <= 2 * words) {
+    *out = it->second;
+    ctx->pool_live[it->second] = it->first;
+    ctx->pool_free.erase(it);
+    return SC_OK;
+  }
+  u64* p = nullptr;
+  hipError_t e = hipMalloc(&p, words * sizeof(u64));
+  if (e != hipSuccess) {
+    // release cached blocks and retry once
+    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+    ctx->pool_free.clear();
+    e = hipMalloc(&p, words * sizeof(u64));
+    if (e != hipSuccess)
+      return fail(ctx, SC_ERR_OOM, "hipMalloc(%zu bytes): %s", words * sizeof(u64), hipGetErrorString(e));
+  }
+  ctx->pool_live[p] = words;
+  *out = p;
+  return SC_OK;
+}
+
+void pool_release(sc_ctx* ctx, u64* p) {
+  if (!p) return;
+  auto it = ctx->pool_live.find(p);
+  if (it == ctx->pool_live.end()) return;
+  ctx->pool_free.emplace(it->second, p);
+  ctx->pool_live.erase(it);
+}
+
+int new_table(sc_ctx* ctx, size_t len, sc_table** out) {
+  sc_table* t = new (std::nothrow) sc_table;
+  if (!t) return fail(ctx, SC_ERR_OOM, "host allocation failed");
+  int rc = pool_alloc(ctx, len, &t->d);
+  if (rc != SC_OK) {
+    delete t;
+    return rc;
+  }
+  t->len = len;
+  *out = t;
+  return SC_OK;
+}
+
+int set_device(sc_ctx* ctx) {
+  SC_HIP(ctx, hipSetDevice(ctx->device));
+  return SC_OK;
+}
+
+inline bool is_sharded(const sc_ctx* ctx) { return ctx->transport != Transport::kNone; }
+
+int grid_for(const sc_ctx* ctx, size_t n_threads_needed) {
+  size_t g = (n_threads_needed + sc::kBlock - 1) / sc::kBlock;
+  if (g < 1) g = 1;
+  if (g > (size_t)ctx->max_blocks) g = ctx->max_blocks;
+  return (int)g;
+}
+
+// =====================================================================================
+// 3. launch helpers
+// =====================================================================================
+
+#define SC_DISPATCH_FIELD(ctx, F, f, ...)      \
+  do {                                         \
+    if ((ctx)->gold) {                         \
+      typedef sc::GoldilocksMont F;            \
+      F f((ctx)->fp);                          \
+      __VA_ARGS__;                             \
+    } else {                                   \
+      typedef sc::MontGeneric F;               \
+      F f((ctx)->fp);                          \
+      __VA_ARGS__;                             \
+    }                                          \
+  } while (0)
+
+template <class F>
+void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const u64* B, u64* A2,
+                   u64* B2, u64 r0, u64 r1, size_t n_units, int grid) {
+  dim3 g(grid), b(sc::kBlock);
+  hipStream_t s = ctx->stream;
+  u64* P = ctx->d_partials;
+  u64* S = ctx->d_sums;
+#define SC_PASS(KF, KS) \
+  hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS>), g, b, 0, s, f, A, B, A2, B2, r0, r1, n_units, P, S)
+  switch (kf * 4 + ks) {
+    case 0 * 4 + 1: SC_PASS(0, 1); break;
+    case 0 * 4 + 2: SC_PASS(0, 2); break;
+    case 1 * 4 + 1: SC_PASS(1, 1); break;
+    case 1 * 4 + 2: SC_PASS(1, 2); break;
+    case 2 * 4 + 1: SC_PASS(2, 1); break;
+    case 2 * 4 + 2: SC_PASS(2, 2); break;
+    default: break;
+  }
+#undef SC_PASS
+  if (grid > 1) {
+    int ns = ks == 1 ? 3 : 9;
+    hipLaunchKernelGGL((sc::final_reduce_kernel<F>), dim3(1), b, 0, s, f, P, grid, ns, S);
+  }
+}
+
+// Launch one pass over tables of 2^log_in entries; leaves 2*NS split limbs in ctx->d_sums.
+int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, u64 r0,
+                u64 r1, int log_in) {
+  if (kf < 0 || kf > 2 || ks < 1 || ks > 2 || log_in < kf + ks)
+    return fail(ctx, SC_ERR_ARG, "launch_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
+  size_t n_units = (size_t)1 << (log_in - kf - ks);
+  int grid = grid_for(ctx, n_units);
+  if (ctx->time_kernels) SC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, r0, r1, n_units, grid));
+  SC_HIP(ctx, hipGetLastError());
+  if (ctx->time_kernels) {
+    SC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->kt_pending = true;
+  }
+  return SC_OK;
+}
+
+void account_kernel_time(sc_ctx* ctx) {
+  if (!ctx->time_kernels || !ctx->kt_pending) return;
+  ctx->kt_pending = false;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) {
+    ctx->kt_ms += ms;
+    ctx->kt_n += 1;
+  }
+}
+
+// =====================================================================================
+// 2. collectives
+// =====================================================================================
+
+// Finish a pass: (optionally) sum the split limbs in d_sums across ranks, bring them to the
+// host and recombine into ns residues.
+int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, u64* out) {
+  const size_t count = 2 * (size_t)ns;
+  if (across_ranks && ctx->transport == Transport::kRccl) {
+    ncclResult_t r = g_rccl.AllReduce(ctx->d_sums, ctx->d_sums, count, ncclUint64, ncclSum, ctx->comm,
+                                      ctx->stream);
+    if (r != ncclSuccess)
+      return fail(ctx, SC_ERR_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+  }
+  SC_HIP(ctx, hipMemcpyAsync(ctx->h_sums, ctx->d_sums, count * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  account_kernel_time(ctx);
+  if (across_ranks && ctx->transport == Transport::kHost) {
+    if (ctx->host_allreduce(ctx->host_user, ctx->h_sums, count) != 0)
+      return fail(ctx, SC_ERR_RCCL, "host all-reduce callback failed");
+  }
+  HostField hf(ctx->fp);
+  for (int s = 0; s < ns; ++s) out[s] = hf.recombine(ctx->h_sums[2 * s], ctx->h_sums[2 * s + 1]);
+  return SC_OK;
+}
+
+// All-gather `len` words per rank of a device buffer into a new pool buffer of len*world.
+int gather_table(sc_ctx* ctx, const u64* local, size_t len, u64** out_full) {
+  u64* full = nullptr;
+  SC_TRY(pool_alloc(ctx, len * ctx->world, &full));
+  if (ctx->transport == Transport::kRccl) {
+    ncclResult_t r = g_rccl.AllGather(local, full, len, ncclUint64, ctx->comm, ctx->stream);
+    if (r != ncclSuccess) {
+      pool_release(ctx, full);
+      return fail(ctx, SC_ERR_RCCL, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
+  } else {
+    std::vector<u64> send(len), recv(len * ctx->world);
+    SC_HIP(ctx, hipMemcpyAsync(send.data(), local, len * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->host_allgather(ctx->host_user, send.data(), recv.data(), len) != 0) {
+      pool_release(ctx, full);
+      return fail(ctx, SC_ERR_RCCL, "host all-gather callback failed");
+    }
+    SC_HIP(ctx, hipMemcpyAsync(full, recv.data(), recv.size() * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  }
+  *out_full = full;
+  return SC_OK;
+}
+
+// =====================================================================================
+// shared helpers for the table API
+// =====================================================================================
+
+// Fold k variables of a device table (LE or BE), producing a pool buffer.  `in` is never
+// written.  Uses two variables per launch where the length allows.
+int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, int order, u64** out,
+               size_t* out_len) {
+  const u64* cur = in;
+  u64* owned = nullptr;  // intermediate we own (never `in`)
+  size_t cur_len = len;
+  size_t done = 0;
+  if (k == 0) {
+    u64* cp = nullptr;
+    SC_TRY(pool_alloc(ctx, len, &cp));
+    SC_HIP(ctx, hipMemcpyAsync(cp, in, len * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream));
+    *out = cp;
+    *out_len = len;
+    return SC_OK;
+  }
+  while (done < k) {
+    int step;
+    u64* nxt = nullptr;
+    if (order == SC_ORDER_LE) {
+      step = (k - done >= 2 && cur_len >= 8) ? 2 : 1;
+      size_t nlen = cur_len >> step;
+      SC_TRY(pool_alloc(ctx, nlen, &nxt));
+      u64 r0 = r[done], r1 = step == 2 ? r[done + 1] : 0;
+      if (nlen >= 2) {
+        size_t n_units = nlen / 2;
+        int grid = grid_for(ctx, n_units);
+        if (step == 2)
+          SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_le_kernel<F, 2>), dim3(grid), dim3(sc::kBlock), 0,
+                                                          ctx->stream, f, cur, nxt, r0, r1, n_units));
+        else
+          SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_le_kernel<F, 1>), dim3(grid), dim3(sc::kBlock), 0,
+                                                          ctx->stream, f, cur, nxt, r0, r1, n_units));
+      } else {
+        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_le_small_kernel<F>), dim3(1), dim3(64), 0,
+                                                        ctx->stream, f, cur, nxt, r0, nlen));
+      }
+      cur_len = nlen;
+    } else {
+      step = 1;
+      size_t half = cur_len / 2;
+      SC_TRY(pool_alloc(ctx, half, &nxt));
+      int grid = grid_for(ctx, (half + 1) / 2);
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_be_kernel<F>), dim3(grid), dim3(sc::kBlock), 0,
+                                                      ctx->stream, f, cur, nxt, r[done], half));
+      cur_len = half;
+    }
+    SC_HIP(ctx, hipGetLastError());
+    if (owned) pool_release(ctx, owned);  // stream-ordered reuse: single stream per context
+    owned = nxt;
+    cur = nxt;
+    done += step;
+  }
+  *out = owned;
+  *out_len = cur_len;
+  return SC_OK;
+}
+
+int check_table(const sc_ctx* ctx, const sc_table* t, const char* what) {
+  if (!t || !t->d || !is_pow2(t->len)) return fail(ctx, SC_ERR_ARG, "%s: table is null or not 2^k long", what);
+  return SC_OK;
+}
+
+}  // namespace
+
+// =====================================================================================
+// C ABI: field helpers
+// =====================================================================================
+
+extern "C" int sc_field_from_modulus(uint64_t p, sc_field* out) {
+  if (!out) return SC_ERR_ARG;
+  sc::FieldParams fp;
+  if (!sc::field_params_from_modulus(p, &fp)) return SC_ERR_ARG;
+  out->p = fp.p;
+  out->p_inv_neg = fp.p_inv_neg;
+  out->r_mod_p = fp.r_mod_p;
+  out->r2_mod_p = fp.r2_mod_p;
+  return SC_OK;
+}
+
+static sc::FieldParams to_params(const sc_field* f) {
+  sc::FieldParams fp;
+  fp.p = f->p;
+  fp.p_inv_neg = f->p_inv_neg;
+  fp.r_mod_p = f->r_mod_p;
+  fp.r2_mod_p = f->r2_mod_p;
+  return fp;
+}
+
+extern "C" uint64_t sc_field_to_mont(const sc_field* f, uint64_t canonical) {
+  HostField hf(to_params(f));
+  return hf.mul(canonical % f->p, f->r2_mod_p);
+}
+extern "C" uint64_t sc_field_from_mont(const sc_field* f, uint64_t mont) {
+  HostField hf(to_params(f));
+  return hf.mul(mont, 1);
+}
+
+// matrix-multiplication/src/lib.rs:17-60 with x = 0, 1, 2: Lagrange basis polynomials
+// scaled by y_i / denominator_i and summed coefficient-wise.
+extern "C" int sc_interpolate_quadratic(const sc_field* f, const uint64_t e[3], uint64_t c[3]) {
+  if (!f || !e || !c || f->p < 3) return SC_ERR_ARG;
+  HostField hf(to_params(f));
+  u64 x[3] = {0, hf.one(), hf.add(hf.one(), hf.one())};
+  c[0] = c[1] = c[2] = 0;
+  for (int i = 0; i < 3; ++i) {
+    int j = (i + 1) % 3, k = (i + 2) % 3;
+    u64 dinv = hf.inv(hf.mul(hf.sub(x[i], x[j]), hf.sub(x[i], x[k])));
+    u64 w = hf.mul(e[i], dinv);
+    c[0] = hf.add(c[0], hf.mul(hf.mul(x[j], x[k]), w));
+    c[1] = hf.add(c[1], hf.mul(hf.sub(hf.neg(x[j]), x[k]), w));
+    c[2] = hf.add(c[2], w);
+  }
+  return SC_OK;
+}
+
+// =====================================================================================
+// C ABI: context
+// =====================================================================================
+
+extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
+  if (!f || !out) return fail(nullptr, SC_ERR_ARG, "sc_ctx_create: null argument");
+  sc_field chk;
+  if (sc_field_from_modulus(f->p, &chk) != SC_OK || chk.p_inv_neg != f->p_inv_neg ||
+      chk.r_mod_p != f->r_mod_p || chk.r2_mod_p != f->r2_mod_p)
+    return fail(nullptr, SC_ERR_ARG, "sc_ctx_create: inconsistent field constants for p=%llu",
+                (unsigned long long)f->p);
+  int ndev = 0;
+  hipError_t e = hipGetDeviceCount(&ndev);
+  if (e != hipSuccess || ndev == 0)
+    return fail(nullptr, SC_ERR_HIP, "no HIP device available (%s); this library has no CPU path",
+                e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= ndev) return fail(nullptr, SC_ERR_ARG, "device %d out of range [0,%d)", device, ndev);
+  sc_ctx* ctx = new (std::nothrow) sc_ctx;
+  if (!ctx) return fail(nullptr, SC_ERR_OOM, "host allocation failed");
+  ctx->fp = to_params(f);
+  ctx->gold = (f->p == sc::GoldilocksMont::P);
+  ctx->device = device;
+#define SC_CREATE_HIP(call)                                                                \
+  do {                                                                                     \
+    hipError_t e2_ = (call);                                                               \
+    if (e2_ != hipSuccess) {                                                               \
+      int rc_ = fail(nullptr, SC_ERR_HIP, "%s: %s", #call, hipGetErrorString(e2_));        \
+      sc_ctx_destroy(ctx);                                                                 \
+      return rc_;                                                                          \
+    }                                                                                      \
+  } while (0)
+  SC_CREATE_HIP(hipSetDevice(device));
+  SC_CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
+  ctx->partial_rows = 4096;
+  SC_CREATE_HIP(hipMalloc(&ctx->d_partials, ctx->partial_rows * sc::kPartialStride * sizeof(u64)));
+  SC_CREATE_HIP(hipMalloc(&ctx->d_sums, 64 * sizeof(u64)));
+  SC_CREATE_HIP(hipHostMalloc(&ctx->h_sums, 64 * sizeof(u64), hipHostMallocDefault));
+  SC_CREATE_HIP(hipEventCreate(&ctx->ev0));
+  SC_CREATE_HIP(hipEventCreate(&ctx->ev1));
+#undef SC_CREATE_HIP
+  *out = ctx;
+  return SC_OK;
+}
+
+extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
+  if (!ctx) return SC_OK;
+  (void)hipSetDevice(ctx->device);
+  if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+  for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+  for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
+  if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+  if (ctx->d_sums) (void)hipFree(ctx->d_sums);
+  if (ctx->h_sums) (void)hipHostFree(ctx->h_sums);
+  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return SC_OK;
+}
+
+extern "C" const char* sc_last_error(const sc_ctx* ctx) {
+  return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
+  if (!ctx || !key) return SC_ERR_ARG;
+  std::string k(key);
+  if (k == "vars_per_pass") {
+    if (value != 1 && value != 2) return fail(ctx, SC_ERR_ARG, "vars_per_pass must be 1 or 2");
+    ctx->vars_per_pass = (int)value;
+  } else if (k == "tail_log") {
+    if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "tail_log out of range");
+    ctx->tail_log = (int)value;
+  } else if (k == "max_blocks") {
+    if (value < 1 || value > (int64_t)ctx->partial_rows) return fail(ctx, SC_ERR_ARG, "max_blocks out of range");
+    ctx->max_blocks = (int)value;
+  } else if (k == "time_kernels") {
+    ctx->time_kernels = value ? 1 : 0;
+  } else {
+    return fail(ctx, SC_ERR_ARG, "unknown option '%s'", key);
+  }
+  return SC_OK;
+}
+
+extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* value) {
+  if (!ctx || !key || !value) return SC_ERR_ARG;
+  std::string k(key);
+  if (k == "vars_per_pass") *value = ctx->vars_per_pass;
+  else if (k == "tail_log") *value = ctx->tail_log;
+  else if (k == "max_blocks") *value = ctx->max_blocks;
+  else if (k == "time_kernels") *value = ctx->time_kernels;
+  else return fail(ctx, SC_ERR_ARG, "unknown option '%s'", key);
+  return SC_OK;
+}
+
+extern "C" int sc_ctx_synchronize(sc_ctx* ctx) {
+  if (!ctx) return SC_ERR_ARG;
+  SC_TRY(set_device(ctx));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+extern "C" void* sc_ctx_stream(const sc_ctx* ctx) { return ctx ? (void*)ctx->stream : nullptr; }
+
+extern "C" int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset) {
+  if (!ctx || !out) return SC_ERR_ARG;
+  out[0] = (double)ctx->kt_n;
+  out[1] = ctx->kt_ms;
+  if (reset) {
+    ctx->kt_n = 0;
+    ctx->kt_ms = 0.0;
+  }
+  return SC_OK;
+}
+
+// =====================================================================================
+// C ABI: sharding
+// =====================================================================================
+
+extern "C" int sc_comm_unique_id(uint8_t id[128]) {
+  std::string why;
+  if (!id) return SC_ERR_ARG;
+  if (!load_rccl(&why)) return fail(nullptr, SC_ERR_RCCL, "%s", why.c_str());
+  static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+  ncclUniqueId u;
+  ncclResult_t r = g_rccl.GetUniqueId(&u);
+  if (r != ncclSuccess) return fail(nullptr, SC_ERR_RCCL, "ncclGetUniqueId failed (%d)", (int)r);
+  memcpy(id, &u, 128);
+  return SC_OK;
+}
+
+static int set_world(sc_ctx* ctx, int rank, int world) {
+  if (world < 1 || !is_pow2((size_t)world) || rank < 0 || rank >= world)
+    return fail(ctx, SC_ERR_ARG, "rank %d / world %d: world must be a power of two", rank, world);
+  if (ctx->transport != Transport::kNone) return fail(ctx, SC_ERR_STATE, "communicator already initialised");
+  ctx->rank = rank;
+  ctx->world = world;
+  ctx->log_world = log2_of((size_t)world);
+  return SC_OK;
+}
+
+extern "C" int sc_ctx_comm_init_rccl(sc_ctx* ctx, const uint8_t id[128], int rank, int world) {
+  if (!ctx || !id) return SC_ERR_ARG;
+  std::string why;
+  if (!load_rccl(&why)) return fail(ctx, SC_ERR_RCCL, "%s", why.c_str());
+  SC_TRY(set_device(ctx));
+  SC_TRY(set_world(ctx, rank, world));
+  ncclUniqueId u;
+  memcpy(&u, id, 128);
+  ncclResult_t r = g_rccl.CommInitRank(&ctx->comm, world, u, rank);
+  if (r != ncclSuccess) {
+    ctx->world = 1;
+    ctx->rank = 0;
+    ctx->log_world = 0;
+    return fail(ctx, SC_ERR_RCCL, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+  }
+  ctx->transport = Transport::kRccl;
+  return SC_OK;
+}
+
+extern "C" int sc_ctx_comm_init_host(sc_ctx* ctx, int rank, int world, sc_allreduce_fn allreduce,
+                                     sc_allgather_fn allgather, void* user) {
+  if (!ctx || !allreduce || !allgather) return SC_ERR_ARG;
+  SC_TRY(set_world(ctx, rank, world));
+  ctx->host_allreduce = allreduce;
+  ctx->host_allgather = allgather;
+  ctx->host_user = user;
+  ctx->transport = Transport::kHost;
+  return SC_OK;
+}
+
+extern "C" int sc_ctx_comm_rank(const sc_ctx* ctx, int* rank, int* world) {
+  if (!ctx) return SC_ERR_ARG;
+  if (rank) *rank = ctx->rank;
+  if (world) *world = ctx->world;
+  return SC_OK;
+}
+
+// =====================================================================================
+// C ABI: tables
+// =====================================================================================
+
+extern "C" int sc_table_upload(sc_ctx* ctx, const uint64_t* host, size_t len, sc_table** out) {
+  if (!ctx || !host || !out) return SC_ERR_ARG;
+  if (!is_pow2(len)) return fail(ctx, SC_ERR_ARG, "sc_table_upload: len %zu is not a power of two", len);
+  SC_TRY(set_device(ctx));
+  sc_table* t = nullptr;
+  SC_TRY(new_table(ctx, len, &t));
+  hipError_t e = hipMemcpyAsync(t->d, host, len * sizeof(u64), hipMemcpyHostToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    sc_table_free(ctx, t);
+    return fail(ctx, SC_ERR_HIP, "upload: %s", hipGetErrorString(e));
+  }
+  *out = t;
+  return SC_OK;
+}
+
+extern "C" int sc_table_generate(sc_ctx* ctx, uint64_t seed, uint64_t start, size_t len, sc_table** out) {
+  if (!ctx || !out) return SC_ERR_ARG;
+  if (!is_pow2(len)) return fail(ctx, SC_ERR_ARG, "sc_table_generate: len %zu is not a power of two", len);
+  SC_TRY(set_device(ctx));
+  sc_table* t = nullptr;
+  SC_TRY(new_table(ctx, len, &t));
+  int grid = grid_for(ctx, len);
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::generate_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
+                                                  f, (u64)seed, (u64)start, len, t->d));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    sc_table_free(ctx, t);
+    return fail(ctx, SC_ERR_HIP, "generate: %s", hipGetErrorString(e));
+  }
+  *out = t;
+  return SC_OK;
+}
+
+extern "C" int sc_table_clone(sc_ctx* ctx, const sc_table* t, sc_table** out) {
+  if (!ctx || !out) return SC_ERR_ARG;
+  SC_TRY(check_table(ctx, t, "sc_table_clone"));
+  SC_TRY(set_device(ctx));
+  sc_table* c = nullptr;
+  SC_TRY(new_table(ctx, t->len, &c));
+  hipError_t e = hipMemcpyAsync(c->d, t->d, t->len * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    sc_table_free(ctx, c);
+    return fail(ctx, SC_ERR_HIP, "clone: %s", hipGetErrorString(e));
+  }
+  *out = c;
+  return SC_OK;
+}
+
+extern "C" int sc_table_download(sc_ctx* ctx, const sc_table* t, uint64_t* host, size_t len) {
+  if (!ctx || !host) return SC_ERR_ARG;
+  SC_TRY(check_table(ctx, t, "sc_table_download"));
+  if (len != t->len) return fail(ctx, SC_ERR_ARG, "sc_table_download: len %zu != table len %zu", len, t->len);
+  SC_TRY(set_device(ctx));
+  SC_HIP(ctx, hipMemcpyAsync(host, t->d, len * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+extern "C" size_t sc_table_len(const sc_table* t) { return t ? t->len : 0; }
+extern "C" const uint64_t* sc_table_device_ptr(const sc_table* t) { return t ? t->d : nullptr; }
+
+extern "C" int sc_table_free(sc_ctx* ctx, sc_table* t) {
+  if (!t) return SC_OK;
+  if (!ctx) return SC_ERR_ARG;
+  pool_release(ctx, t->d);
+  delete t;
+  return SC_OK;
+}
+
+extern "C" int sc_table_fix_variables(sc_ctx* ctx, const sc_table* in, const uint64_t* r, size_t k, int order,
+                                      sc_table** out) {
+  if (!ctx || !out || (k && !r)) return SC_ERR_ARG;
+  SC_TRY(check_table(ctx, in, "sc_table_fix_variables"));
+  if (order != SC_ORDER_LE && order != SC_ORDER_BE) return fail(ctx, SC_ERR_ARG, "bad order %d", order);
+  int nv = log2_of(in->len);
+  if (k > (size_t)nv) {
+    if (ctx->world > 1)
+      return fail(ctx, SC_ERR_UNSUPPORTED, "fix_variables of %zu variables crosses shards (local has %d)", k, nv);
+    return fail(ctx, SC_ERR_ARG, "fix_variables: k=%zu > num_vars=%d", k, nv);
+  }
+  if (ctx->world > 1 && order == SC_ORDER_BE && k > 0)
+    return fail(ctx, SC_ERR_UNSUPPORTED, "BE fix_variables pairs entries of different shards");
+  SC_TRY(set_device(ctx));
+  sc_table* t = new (std::nothrow) sc_table;
+  if (!t) return fail(ctx, SC_ERR_OOM, "host allocation failed");
+  int rc = fold_chain(ctx, in->d, in->len, r, k, order, &t->d, &t->len);
+  if (rc != SC_OK) {
+    delete t;
+    return rc;
+  }
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *out = t;
+  return SC_OK;
+}
+
+// Local evaluate of a device table at a full point (len == 2^n_local); result left in a
+// 1-entry pool buffer.
+static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* r, int order, u64** out1) {
+  int nv = log2_of(len);
+  std::vector<u64> pt(r, r + nv);
+  // BE evaluate == LE evaluate at the reversed point (same multilinear polynomial, the
+  // index bits are just named in the opposite order).
+  if (order == SC_ORDER_BE) std::reverse(pt.begin(), pt.end());
+  size_t out_len = 0;
+  return fold_chain(ctx, d, len, pt.data(), (size_t)nv, SC_ORDER_LE, out1, &out_len);
+}
+
+extern "C" int sc_table_evaluate(sc_ctx* ctx, const sc_table* t, const uint64_t* r, size_t n, int order,
+                                 uint64_t* out) {
+  if (!ctx || !out || (n && !r)) return SC_ERR_ARG;
+  SC_TRY(check_table(ctx, t, "sc_table_evaluate"));
+  if (order != SC_ORDER_LE && order != SC_ORDER_BE) return fail(ctx, SC_ERR_ARG, "bad order %d", order);
+  int nl = log2_of(t->len);
+  if (n != (size_t)(nl + ctx->log_world))
+    return fail(ctx, SC_ERR_ARG, "evaluate: point has %zu entries, table has %d variables", n, nl + ctx->log_world);
+  SC_TRY(set_device(ctx));
+  const int g = ctx->log_world;
+  // local part: LE -> low nl variables are r[0..nl); BE -> the shard index is the leading
+  // variables r[0..g), the local ones are r[g..n).
+  const u64* r_local = (order == SC_ORDER_LE) ? r : r + g;
+  u64* v1 = nullptr;
+  SC_TRY(evaluate_local(ctx, t->d, t->len, r_local, order, &v1));
+  HostField hf(ctx->fp);
+  u64 w = hf.one();
+  for (int i = 0; i < g; ++i) {
+    // rank bit i (LE) is variable nl+i; in BE order rank bit (g-1-i) is variable i
+    u64 ri = (order == SC_ORDER_LE) ? r[nl + i] : r[g - 1 - i];
+    bool bit = (ctx->rank >> i) & 1;
+    w = hf.mul(w, bit ? ri : hf.sub(hf.one(), ri));
+  }
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::scale_split_kernel<F>), dim3(1), dim3(64), 0, ctx->stream, f,
+                                                  (const u64*)v1, w, ctx->d_sums));
+  pool_release(ctx, v1);
+  SC_HIP(ctx, hipGetLastError());
+  u64 res = 0;
+  SC_TRY(collect_sums(ctx, 1, is_sharded(ctx), &res));
+  *out = res;
+  return SC_OK;
+}
+
+extern "C" int sc_table_relabel(sc_ctx* ctx, const sc_table* in, size_t a, size_t b, size_t k, sc_table** out) {
+  if (!ctx || !out) return SC_ERR_ARG;
+  SC_TRY(check_table(ctx, in, "sc_table_relabel"));
+  if (ctx->world > 1) return fail(ctx, SC_ERR_UNSUPPORTED, "relabel on a sharded table");
+  int nv = log2_of(in->len);
+  if (a > b) std::swap(a, b);
+  if (a + k > b || b + k > (size_t)nv) return fail(ctx, SC_ERR_ARG, "relabel(%zu,%zu,%zu) on %d variables", a, b, k, nv);
+  SC_TRY(set_device(ctx));
+  sc_table* t = nullptr;
+  SC_TRY(new_table(ctx, in->len, &t));
+  int grid = grid_for(ctx, in->len);
+  hipLaunchKernelGGL(sc::relabel_kernel, dim3(grid), dim3(sc::kBlock), 0, ctx->stream, (const u64*)in->d, t->d, in->len,
+                     (unsigned)a, (unsigned)b, (unsigned)k);
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    sc_table_free(ctx, t);
+    return fail(ctx, SC_ERR_HIP, "relabel: %s", hipGetErrorString(e));
+  }
+  *out = t;
+  return SC_OK;
+}
+
+// =====================================================================================
+// C ABI: product of two tables
+// =====================================================================================
+
+static int check_pair(const sc_ctx* ctx, const sc_table* a, const sc_table* b, const char* what) {
+  SC_TRY(check_table(ctx, a, what));
+  SC_TRY(check_table(ctx, b, what));
+  if (a->len != b->len) return fail(ctx, SC_ERR_ARG, "%s: table lengths differ (%zu vs %zu)", what, a->len, b->len);
+  return SC_OK;
+}
+
+extern "C" int sc_matmul_g_new(sc_ctx* ctx, const sc_table* A, const sc_table* B, size_t n, const uint64_t* point,
+                               sc_table** a_out, sc_table** b_out) {
+  if (!ctx || !point || !a_out || !b_out) return SC_ERR_ARG;
+  SC_TRY(check_pair(ctx, A, B, "sc_matmul_g_new"));
+  if (ctx->world > 1) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_matmul_g_new on sharded tables");
+  if (A->len != ((size_t)1 << (2 * n))) return fail(ctx, SC_ERR_ARG, "sc_matmul_g_new: tables must have 2^(2n) entries");
+  // matrix-multiplication/src/lib.rs:81-86
+  sc_table* At = nullptr;
+  SC_TRY(sc_table_relabel(ctx, A, 0, n, n, &At));
+  int rc = sc_table_fix_variables(ctx, At, point, n, SC_ORDER_LE, a_out);
+  sc_table_free(ctx, At);
+  SC_TRY(rc);
+  rc = sc_table_fix_variables(ctx, B, point + n, n, SC_ORDER_LE, b_out);
+  if (rc != SC_OK) {
+    sc_table_free(ctx, *a_out);
+    *a_out = nullptr;
+  }
+  return rc;
+}
+
+extern "C" int sc_prod2_to_evaluations(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_table** out) {
+  if (!ctx || !out) return SC_ERR_ARG;
+  SC_TRY(check_pair(ctx, a, b, "sc_prod2_to_evaluations"));
+  SC_TRY(set_device(ctx));
+  sc_table* t = nullptr;
+  SC_TRY(new_table(ctx, a->len, &t));
+  int grid = grid_for(ctx, a->len);
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::mul_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                  (const u64*)a->d, (const u64*)b->d, t->d, a->len));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    sc_table_free(ctx, t);
+    return fail(ctx, SC_ERR_HIP, "to_evaluations: %s", hipGetErrorString(e));
+  }
+  *out = t;
+  return SC_OK;
+}
+
+// Round sums of (a, b) as they are (no fold); handles the degenerate 1-entry tables.
+static int round_sums_now(sc_ctx* ctx, const u64* a, const u64* b, int log_len, bool across, u64 e[3]) {
+  if (log_len < 1) return fail(ctx, SC_ERR_ARG, "round sums need at least one variable");
+  SC_TRY(launch_pass(ctx, 0, 1, a, b, nullptr, nullptr, 0, 0, log_len));
+  return collect_sums(ctx, 3, across, e);
+}
+
+extern "C" int sc_prod2_round_sums(sc_ctx* ctx, const sc_table* a, const sc_table* b, uint64_t out_e[3]) {
+  if (!ctx || !out_e) return SC_ERR_ARG;
+  SC_TRY(check_pair(ctx, a, b, "sc_prod2_round_sums"));
+  SC_TRY(set_device(ctx));
+  if (a->len < 2) return fail(ctx, SC_ERR_ARG, "sc_prod2_round_sums: tables have no variable left");
+  return round_sums_now(ctx, a->d, b->d, log2_of(a->len), is_sharded(ctx), out_e);
+}
+
+extern "C" int sc_prod2_sum(sc_ctx* ctx, const sc_table* a, const sc_table* b, uint64_t* out_c1) {
+  if (!ctx || !out_c1) return SC_ERR_ARG;
+  SC_TRY(check_pair(ctx, a, b, "sc_prod2_sum"));
+  SC_TRY(set_device(ctx));
+  HostField hf(ctx->fp);
+  if (a->len == 1) {
+    // zero variables on this rank: the (partial) sum is the single product
+    u64* prod = nullptr;
+    SC_TRY(pool_alloc(ctx, 1, &prod));
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::mul_kernel<F>), dim3(1), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                    (const u64*)a->d, (const u64*)b->d, prod, (size_t)1));
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::scale_split_kernel<F>), dim3(1), dim3(64), 0, ctx->stream, f,
+                                                    (const u64*)prod, hf.one(), ctx->d_sums));
+    pool_release(ctx, prod);
+    SC_HIP(ctx, hipGetLastError());
+    return collect_sums(ctx, 1, is_sharded(ctx), out_c1);
+  }
+  u64 e[3];
+  SC_TRY(round_sums_now(ctx, a->d, b->d, log2_of(a->len), is_sharded(ctx), e));
+  *out_c1 = hf.add(e[0], e[1]);  // c_1 = H(0) + H(1)
+  return SC_OK;
+}
+
+extern "C" int sc_prod2_fold_and_sums(sc_ctx* ctx, const sc_table* a, const sc_table* b, const uint64_t r[1],
+                                      sc_table** a_out, sc_table** b_out, uint64_t out_e[3]) {
+  if (!ctx || !r || !a_out || !b_out || !out_e) return SC_ERR_ARG;
+  SC_TRY(check_pair(ctx, a, b, "sc_prod2_fold_and_sums"));
+  SC_TRY(set_device(ctx));
+  int nv = log2_of(a->len);
+  if (nv < 2) return fail(ctx, SC_ERR_ARG, "sc_prod2_fold_and_sums: need >= 2 variables (fold one, sum over one)");
+  sc_table *ta = nullptr, *tb = nullptr;
+  SC_TRY(new_table(ctx, a->len / 2, &ta));
+  int rc = new_table(ctx, a->len / 2, &tb);
+  if (rc == SC_OK) rc = launch_pass(ctx, 1, 1, a->d, b->d, ta->d, tb->d, r[0], 0, nv);
+  if (rc == SC_OK) rc = collect_sums(ctx, 3, is_sharded(ctx), out_e);
+  if (rc != SC_OK) {
+    sc_table_free(ctx, ta);
+    sc_table_free(ctx, tb);
+    return rc;
+  }
+  *a_out = ta;
+  *b_out = tb;
+  return SC_OK;
+}
+
+extern "C" int sc_prod2_evaluate(sc_ctx* ctx, const sc_table* a, const sc_table* b, const uint64_t* point, size_t n,
+                                 uint64_t* out) {
+  if (!ctx || !out) return SC_ERR_ARG;
+  SC_TRY(check_pair(ctx, a, b, "sc_prod2_evaluate"));
+  u64 va = 0, vb = 0;
+  SC_TRY(sc_table_evaluate(ctx, a, point, n, SC_ORDER_LE, &va));
+  SC_TRY(sc_table_evaluate(ctx, b, point, n, SC_ORDER_LE, &vb));
+  HostField hf(ctx->fp);
+  *out = hf.mul(va, vb);
+  return SC_OK;
+}
+
+// =====================================================================================
+// C ABI: the prover
+// =====================================================================================
+//
+// Schedule.  The reference folds one variable and re-sums every round
+// (sum-check-protocol/src/lib.rs:105-112).  Here one device pass serves up to two rounds:
+// it folds the (<= 2) challenges received since the previous pass and accumulates the 3x3
+// grid S[u][v] of the folded tables.  Round j is H(u) = S[u][0] + S[u][1]; round j+1,
+// once r_j is known, is H'(v) = sum_u L_u(r_j) S[u][v] with the Lagrange basis on {0,1,2}
+// - exact field identities, so every round polynomial equals the reference's bit for bit.
+struct sc_prover {
+  sc_ctx* ctx = nullptr;
+  const u64* a0 = nullptr;  // caller's tables (borrowed, never written)
+  const u64* b0 = nullptr;
+  const u64* cur_a = nullptr;
+  const u64* cur_b = nullptr;
+  u64* own_a = nullptr;  // pool buffers backing cur_* when they are not the caller's
+  u64* own_b = nullptr;
+  int cur_log = 0;       // log2 length of cur_* on this rank
+  bool sharded = false;  // still one shard per rank (sums need the all-reduce)
+  size_t num_vars = 0;   // global
+  size_t next_round = 0;
+  std::vector<u64> pending;  // challenges not yet folded into cur_*
+  // cache of the last pass
+  int cache_ks = 0;
+  size_t cache_round = 0;
+  u64 S[9];
+  u64 c1 = 0;
+};
+
+namespace {
+
+int prover_pass(sc_prover* pr, size_t j) {
+  sc_ctx* ctx = pr->ctx;
+  const int kf = (int)pr->pending.size();
+  const size_t remaining = pr->num_vars - j;  // variables left including round j's
+  const int ks = (ctx->vars_per_pass == 2 && remaining >= 2) ? 2 : 1;
+  if (kf > 2) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges", kf);
+
+  // Sharded: pairs (2b, 2b+1) stay shard-local while the local table still has the kf+ks
+  // variables this pass touches; below tail_log the latency of a collective per pass costs
+  // more than finishing redundantly on every rank, so gather once and go on unsharded.
+  if (pr->sharded && (pr->cur_log < kf + ks || pr->cur_log <= ctx->tail_log)) {
+    u64 *fa = nullptr, *fb = nullptr;
+    size_t len = (size_t)1 << pr->cur_log;
+    SC_TRY(gather_table(ctx, pr->cur_a, len, &fa));
+    int rc = gather_table(ctx, pr->cur_b, len, &fb);
+    if (rc != SC_OK) {
+      pool_release(ctx, fa);
+      return rc;
+    }
+    pool_release(ctx, pr->own_a);
+    pool_release(ctx, pr->own_b);
+    pr->own_a = fa;
+    pr->own_b = fb;
+    pr->cur_a = fa;
+    pr->cur_b = fb;
+    pr->cur_log += ctx->log_world;
+    pr->sharded = false;
+  }
+  if (pr->cur_log < kf + ks)
+    return fail(ctx, SC_ERR_STATE, "prover: table has %d variables, pass needs %d", pr->cur_log, kf + ks);
+
+  u64 *na = nullptr, *nb = nullptr;
+  if (kf > 0) {
+    size_t out_len = (size_t)1 << (pr->cur_log - kf);
+    SC_TRY(pool_alloc(ctx, out_len, &na));
+    int rc = pool_alloc(ctx, out_len, &nb);
+    if (rc != SC_OK) {
+      pool_release(ctx, na);
+      return rc;
+    }
+  }
+  u64 r0 = kf > 0 ? pr->pending[0] : 0, r1 = kf > 1 ? pr->pending[1] : 0;
+  int rc = launch_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, r0, r1, pr->cur_log);
+  if (rc == SC_OK) rc = collect_sums(ctx, ks == 1 ? 3 : 9, pr->sharded, pr->S);
+  if (rc != SC_OK) {
+    pool_release(ctx, na);
+    pool_release(ctx, nb);
+    return rc;
+  }
+  if (kf > 0) {
+    pool_release(ctx, pr->own_a);
+    pool_release(ctx, pr->own_b);
+    pr->own_a = na;
+    pr->own_b = nb;
+    pr->cur_a = na;
+    pr->cur_b = nb;
+    pr->cur_log -= kf;
+    pr->pending.clear();
+  }
+  pr->cache_ks = ks;
+  pr->cache_round = j;
+  return SC_OK;
+}
+
+// answer round j from the cache (which must cover it)
+void prover_answer(const sc_prover* pr, size_t j, u64 e[3]) {
+  HostField hf(pr->ctx->fp);
+  if (pr->cache_ks == 1) {
+    e[0] = pr->S[0];
+    e[1] = pr->S[1];
+    e[2] = pr->S[2];
+  } else if (j == pr->cache_round) {
+    for (int u = 0; u < 3; ++u) e[u] = hf.add(pr->S[3 * u], pr->S[3 * u + 1]);
+  } else {
+    // second round of the pass: interpolate the grid in u at r = pending[0]
+    u64 r = pr->pending[0];
+    u64 one = hf.one(), two = hf.add(one, one);
+    u64 inv2 = hf.inv(two);
+    u64 rm1 = hf.sub(r, one), rm2 = hf.sub(r, two);
+    u64 L0 = hf.mul(hf.mul(rm1, rm2), inv2);       // (r-1)(r-2)/2
+    u64 L1 = hf.neg(hf.mul(r, rm2));               // -r(r-2)
+    u64 L2 = hf.mul(hf.mul(r, rm1), inv2);         // r(r-1)/2
+    for (int v = 0; v < 3; ++v)
+      e[v] = hf.add(hf.add(hf.mul(L0, pr->S[v]), hf.mul(L1, pr->S[3 + v])), hf.mul(L2, pr->S[6 + v]));
+  }
+}
+
+bool cache_covers(const sc_prover* pr, size_t j) {
+  if (pr->cache_ks == 0) return false;
+  if (j == pr->cache_round) return pr->pending.empty();
+  return pr->cache_ks == 2 && j == pr->cache_round + 1 && pr->pending.size() == 1;
+}
+
+}  // namespace
+
+extern "C" int sc_prover_create(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_prover** out) {
+  if (!ctx || !out) return SC_ERR_ARG;
+  SC_TRY(check_pair(ctx, a, b, "sc_prover_create"));
+  SC_TRY(set_device(ctx));
+  sc_prover* pr = new (std::nothrow) sc_prover;
+  if (!pr) return fail(ctx, SC_ERR_OOM, "host allocation failed");
+  pr->ctx = ctx;
+  pr->a0 = pr->cur_a = a->d;
+  pr->b0 = pr->cur_b = b->d;
+  pr->cur_log = log2_of(a->len);
+  pr->sharded = is_sharded(ctx);
+  pr->num_vars = (size_t)pr->cur_log + ctx->log_world;
+  HostField hf(ctx->fp);
+  if (pr->num_vars == 0) {
+    // no variable: c_1 is the single product, no rounds follow
+    int rc = sc_prod2_sum(ctx, a, b, &pr->c1);
+    if (rc != SC_OK) {
+      delete pr;
+      return rc;
+    }
+    *out = pr;
+    return SC_OK;
+  }
+  // Prover::new's claim rides on round 0's pass: c_1 = H(0) + H(1)
+  int rc = prover_pass(pr, 0);
+  if (rc != SC_OK) {
+    sc_prover_destroy(pr);
+    return rc;
+  }
+  u64 e[3];
+  prover_answer(pr, 0, e);
+  pr->c1 = hf.add(e[0], e[1]);
+  *out = pr;
+  return SC_OK;
+}
+
+extern "C" int sc_prover_c1(const sc_prover* pr, uint64_t* out) {
+  if (!pr || !out) return SC_ERR_ARG;
+  *out = pr->c1;
+  return SC_OK;
+}
+
+extern "C" int sc_prover_num_vars(const sc_prover* pr, size_t* out) {
+  if (!pr || !out) return SC_ERR_ARG;
+  *out = pr->num_vars;
+  return SC_OK;
+}
+
+extern "C" int sc_prover_round(sc_prover* pr, uint64_t r_prev, size_t j, uint64_t out_e[3]) {
+  if (!pr || !out_e) return SC_ERR_ARG;
+  sc_ctx* ctx = pr->ctx;
+  if (j != pr->next_round)
+    return fail(ctx, SC_ERR_STATE, "sc_prover_round: expected round %zu, got %zu", pr->next_round, j);
+  if (j >= pr->num_vars) return fail(ctx, SC_ERR_STATE, "sc_prover_round: all %zu rounds done", pr->num_vars);
+  if (r_prev >= ctx->fp.p && j != 0) return fail(ctx, SC_ERR_ARG, "sc_prover_round: challenge is not reduced");
+  SC_TRY(set_device(ctx));
+  if (j != 0) pr->pending.push_back(r_prev);  // sum-check-protocol/src/lib.rs:106-109
+  if (!cache_covers(pr, j)) SC_TRY(prover_pass(pr, j));
+  prover_answer(pr, j, out_e);
+  pr->next_round = j + 1;
+  return SC_OK;
+}
+
+extern "C" int sc_prover_destroy(sc_prover* pr) {
+  if (!pr) return SC_OK;
+  pool_release(pr->ctx, pr->own_a);
+  pool_release(pr->ctx, pr->own_b);
+  delete pr;
+  return SC_OK;
+}
+
+extern "C" int sc_prove(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_draw_fn draw, void* user,
+                        uint64_t seed_r, uint64_t* c1, uint64_t* evals, uint64_t* challenges) {
+  if (!ctx) return SC_ERR_ARG;
+  sc_prover* pr = nullptr;
+  SC_TRY(sc_prover_create(ctx, a, b, &pr));
+  if (c1) *c1 = pr->c1;
+  HostField hf(ctx->fp);
+  u64 r_j = hf.one();  // callers pass F::one() for round 0 (matrix-multiplication/src/lib.rs:356)
+  int rc = SC_OK;
+  for (size_t j = 0; j < pr->num_vars; ++j) {
+    u64 e[3];
+    rc = sc_prover_round(pr, r_j, j, e);
+    if (rc != SC_OK) break;
+    if (evals) memcpy(evals + 3 * j, e, sizeof(e));
+    r_j = draw ? draw(user, j, e)
+               : hf.mul(sc::splitmix64(seed_r + j + 1) % ctx->fp.p, ctx->fp.r2_mod_p);
+    if (r_j >= ctx->fp.p) {
+      rc = fail(ctx, SC_ERR_ARG, "sc_prove: draw() returned an unreduced challenge");
+      break;
+    }
+    if (challenges) challenges[j] = r_j;
+  }
+  sc_prover_destroy(pr);
+  return rc;
+}

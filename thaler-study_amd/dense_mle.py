@@ -1,0 +1,182 @@
+"""Device-resident `ark_poly::DenseMultilinearExtension<F>` and the GPU context.
+
+Mirrors the methods the reference's hot path calls: from_evaluations_vec
+(matrix-multiplication/src/lib.rs:81), relabel (:82), fix_variables (:83,:104), evaluate (:97),
+to_evaluations (:138), num_vars (:88), Clone.  Variable 0 is index bit 0.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from ._lib import SC_OK, SumcheckHipError, u64, u64p, voidp
+from .field import Field
+
+
+def _u64p(a):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+def _words(xs):
+    return np.ascontiguousarray(np.array([int(x) for x in xs], dtype=np.uint64))
+
+
+class Context:
+    """one GPU, one stream, one field (sc_ctx).  Not thread-safe, like `&mut Prover`."""
+
+    def __init__(self, field, device=0):
+        self.lib = _lib.load()
+        self.field = field if isinstance(field, Field) else Field(field)
+        h = voidp()
+        rc = self.lib.sc_ctx_create(self.field.ref(), device, ctypes.byref(h))
+        if rc != SC_OK:
+            raise SumcheckHipError(rc, self.lib.sc_last_error(None).decode())
+        self.h = h
+        self._keep = []
+
+    def check(self, rc):
+        if rc != SC_OK:
+            raise SumcheckHipError(rc, self.lib.sc_last_error(self.h).decode())
+
+    def close(self):
+        if self.h:
+            self.lib.sc_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, key, value):
+        self.check(self.lib.sc_ctx_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = ctypes.c_int64()
+        self.check(self.lib.sc_ctx_get_option(self.h, key.encode(), ctypes.byref(v)))
+        return v.value
+
+    def synchronize(self):
+        self.check(self.lib.sc_ctx_synchronize(self.h))
+
+    def kernel_time(self, reset=True):
+        out = (ctypes.c_double * 2)()
+        self.check(self.lib.sc_ctx_kernel_time(self.h, out, 1 if reset else 0))
+        return int(out[0]), float(out[1])
+
+    # ---- sharding -----------------------------------------------------------------------
+    def comm_init_rccl(self, unique_id, rank, world):
+        buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))
+        self.check(self.lib.sc_ctx_comm_init_rccl(self.h, buf, rank, world))
+
+    def comm_init_host(self, rank, world, allreduce, allgather):
+        """allreduce(np.uint64 array) sums in place across ranks; allgather(send) -> concatenation"""
+        def _ar(_user, buf, count):
+            try:
+                a = np.ctypeslib.as_array(buf, shape=(count,))
+                allreduce(a)
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        def _ag(_user, send, recv, count):
+            try:
+                s = np.ctypeslib.as_array(send, shape=(count,))
+                r = np.ctypeslib.as_array(recv, shape=(count * world,))
+                r[:] = allgather(s.copy())
+                return 0
+            except Exception:
+                import traceback
+                traceback.print_exc()
+                return 1
+
+        ar, ag = _lib.ALLREDUCE_FN(_ar), _lib.ALLGATHER_FN(_ag)
+        self._keep += [ar, ag]
+        self.check(self.lib.sc_ctx_comm_init_host(self.h, rank, world, ar, ag, None))
+
+    def rank_world(self):
+        r, w = ctypes.c_int(), ctypes.c_int()
+        self.check(self.lib.sc_ctx_comm_rank(self.h, ctypes.byref(r), ctypes.byref(w)))
+        return r.value, w.value
+
+    @staticmethod
+    def rccl_unique_id():
+        lib = _lib.load()
+        buf = (ctypes.c_uint8 * 128)()
+        rc = lib.sc_comm_unique_id(buf)
+        if rc != SC_OK:
+            raise SumcheckHipError(rc, lib.sc_last_error(None).decode())
+        return bytes(buf)
+
+
+class DenseMultilinearExtension:
+    """evaluation table of a multilinear polynomial, resident in HBM (sc_table)"""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    # constructors ------------------------------------------------------------------------
+    @classmethod
+    def from_evaluations_vec(cls, ctx, num_vars, evaluations):
+        ev = np.ascontiguousarray(np.asarray(evaluations, dtype=np.uint64))
+        if ev.size != 1 << num_vars:
+            raise ValueError("The size of evaluations should be 2^num_vars.")
+        h = voidp()
+        ctx.check(ctx.lib.sc_table_upload(ctx.h, _u64p(ev), ev.size, ctypes.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def generate(cls, ctx, seed, num_vars, start=0):
+        h = voidp()
+        ctx.check(ctx.lib.sc_table_generate(ctx.h, seed, start, 1 << num_vars, ctypes.byref(h)))
+        return cls(ctx, h)
+
+    def clone(self):
+        h = voidp()
+        self.ctx.check(self.ctx.lib.sc_table_clone(self.ctx.h, self.h, ctypes.byref(h)))
+        return DenseMultilinearExtension(self.ctx, h)
+
+    def __del__(self):
+        try:
+            if self.h and self.ctx.h:
+                self.ctx.lib.sc_table_free(self.ctx.h, self.h)
+                self.h = None
+        except Exception:
+            pass
+
+    # accessors ---------------------------------------------------------------------------
+    def __len__(self):
+        return int(self.ctx.lib.sc_table_len(self.h))
+
+    def num_vars(self):
+        return len(self).bit_length() - 1
+
+    def to_evaluations(self):
+        out = np.empty(len(self), dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.sc_table_download(self.ctx.h, self.h, _u64p(out), out.size))
+        return out
+
+    # operations --------------------------------------------------------------------------
+    def fix_variables(self, partial_point, order=_lib.ORDER_LE):
+        r = _words(partial_point)
+        h = voidp()
+        self.ctx.check(self.ctx.lib.sc_table_fix_variables(self.ctx.h, self.h, _u64p(r), r.size, order,
+                                                          ctypes.byref(h)))
+        return DenseMultilinearExtension(self.ctx, h)
+
+    def evaluate(self, point, order=_lib.ORDER_LE):
+        r = _words(point)
+        out = u64()
+        self.ctx.check(self.ctx.lib.sc_table_evaluate(self.ctx.h, self.h, _u64p(r), r.size, order,
+                                                     ctypes.byref(out)))
+        return int(out.value)
+
+    def relabel(self, a, b, k):
+        h = voidp()
+        self.ctx.check(self.ctx.lib.sc_table_relabel(self.ctx.h, self.h, a, b, k, ctypes.byref(h)))
+        return DenseMultilinearExtension(self.ctx, h)

@@ -1,0 +1,35 @@
+"""quick timing probe (not the bench): whole-prover wall time and pass-kernel device time"""
+import sys, time, os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import __graft_entry__ as ge
+pkg = ge.load_package()
+sys.path.insert(0, os.path.join(ge.ROOT, "oracle"))
+import pyref
+mm = pkg.matrix_multiplication
+ns = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [20, 24, 26, 28]
+for vpp in (1, 2):
+    ctx = pkg.Context(pkg.Field(pkg.GOLDILOCKS))
+    ctx.set_option("vars_per_pass", vpp)
+    for n in ns:
+        a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
+        b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, n)
+        g = mm.G(a, b)
+        for _ in range(2):
+            mm.prove(ctx, g, pyref.SEED_R)
+        ts = []
+        for _ in range(5):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            mm.prove(ctx, g, pyref.SEED_R)
+            ts.append(time.perf_counter() - t0)
+        t = sorted(ts)[len(ts) // 2]
+        ctx.set_option("time_kernels", 1)
+        ctx.kernel_time(reset=True)
+        mm.prove(ctx, g, pyref.SEED_R)
+        nk, kms = ctx.kernel_time(reset=True)
+        ctx.set_option("time_kernels", 0)
+        alg = 64 * 2**n - 96
+        print("vpp=%d n=%d wall=%.3f ms  muladds/s=%.3e  alg GB/s=%.0f  | pass kernels: %d launches %.3f ms -> alg GB/s=%.0f"
+              % (vpp, n, t * 1e3, (5 * 2**n - 7) / t, alg / t / 1e9, nk, kms, alg / (kms * 1e-3) / 1e9), flush=True)
+        del a, b, g
+    ctx.close()
