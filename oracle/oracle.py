@@ -70,6 +70,8 @@ class Oracle:
         L.sco_prover_c1.restype = u64
         L.sco_prove.argtypes = [FP, u64p, u64p, ctypes.c_size_t, u64p, u64p, u64p, u64p, u64p]
         L.sco_prove.restype = ctypes.c_int
+        L.sco_prover_run.argtypes = [FP, u64p, u64p, ctypes.c_size_t, u64p, u64p, u64p]
+        L.sco_prover_run.restype = None
         L.sco_vsbw.argtypes = [FP, u64p, u64p, ctypes.c_size_t]
         L.sco_vsbw.restype = u64
         L.sco_cti.argtypes = [FP, u64p, u64p, ctypes.c_size_t]
@@ -186,6 +188,15 @@ class Oracle:
 
     def c1(self, a, b):
         return int(self.lib.sco_prover_c1(self.fp, _ptr(a), _ptr(b), self._nv(a)))
+
+    def prover_run(self, a, b, challenges):
+        """the criterion bench's timed region (no verifier): returns (c_1, evals[n,3])"""
+        nv = self._nv(a)
+        ch = np.ascontiguousarray(np.asarray(challenges, dtype=np.uint64))
+        c1 = u64(0)
+        ev = np.empty((nv, 3), dtype=np.uint64)
+        self.lib.sco_prover_run(self.fp, _ptr(a), _ptr(b), nv, _ptr(ch), ctypes.byref(c1), _ptr(ev))
+        return int(c1.value), ev
 
     def prove(self, a, b, challenges):
         """returns dict(status, c_1, evals[n,3], coeffs[n,3], final_eval) in Montgomery form"""

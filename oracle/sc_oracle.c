@@ -301,6 +301,44 @@ int sco_prove(const sco_field* f, const u64* a, const u64* b, size_t nv, const u
   return status;
 }
 
+/*
+ * The timed region of the reference's criterion bench, benches/mm_benchmark.rs:88-96:
+ * Prover::new(g.clone()) then num_vars calls of prover.round(r_j, j) - no verifier.
+ * challenges[j] is what the bench draws after round j (r_j for round j+1).
+ * This is the function bench.py times as the single-core CPU baseline ("port").
+ */
+void sco_prover_run(const sco_field* f, const u64* a, const u64* b, size_t nv, const u64* challenges,
+                    u64* c1_out, u64* evals) {
+  size_t len = (size_t)1 << nv;
+  u64* ga = (u64*)malloc(len * sizeof(u64));                 /* g.clone() :90 */
+  u64* gb = (u64*)malloc(len * sizeof(u64));
+  memcpy(ga, a, len * sizeof(u64));
+  memcpy(gb, b, len * sizeof(u64));
+  u64 c1 = sco_prover_c1(f, ga, gb, nv);                     /* Prover::new */
+  if (c1_out) *c1_out = c1;
+  size_t cur = nv;
+  for (size_t j = 0; j < nv; ++j) {
+    if (j != 0) {
+      u64 r_prev = challenges[j - 1];
+      u64* na = (u64*)malloc((len >> j) * sizeof(u64));
+      u64* nb = (u64*)malloc((len >> j) * sizeof(u64));
+      sco_mle_fix_variables(f, ga, cur, &r_prev, 1, na);
+      sco_mle_fix_variables(f, gb, cur, &r_prev, 1, nb);
+      free(ga);
+      free(gb);
+      ga = na;
+      gb = nb;
+      cur -= 1;
+    }
+    u64 e[3], c[3];
+    sco_g_round_evals(f, ga, gb, cur, e);
+    sco_interpolate_quadratic(f, e, c);
+    if (evals) memcpy(evals + 3 * j, e, sizeof(e));
+  }
+  free(ga);
+  free(gb);
+}
+
 /* ---- multilinear-extensions crate (BE: r[0] <-> index MSB) ------------------------ */
 
 /* vsbw_multilinear_from_evaluations, multilinear-extensions/src/lib.rs:6-24. */

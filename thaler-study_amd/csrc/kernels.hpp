@@ -15,7 +15,6 @@ namespace sc {
 constexpr int kBlock = 256;        // 4 waves per workgroup
 constexpr int kWave = 64;
 constexpr int kMaxSums = 9;
-constexpr int kPartialStride = 16; // u64 words per block row in the partials buffer (128 B)
 
 typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 
@@ -187,7 +186,7 @@ template <class F, int KF, int KS>
 __global__ void __launch_bounds__(kBlock)
 pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
             u64* __restrict__ B2, u64 r0, u64 r1, size_t n_units, u64* __restrict__ partials,
-            u64* __restrict__ sums_out) {
+            u64* __restrict__ sums_out, int n_rows, int nt_load, int nt_store) {
   constexpr int IN = 1 << (KF + KS), OUT = 1 << KS, NS = (KS == 1) ? 3 : 9;
   constexpr int NP = IN / 2, NPO = OUT / 2;  // 16-byte pieces per lane, in and out
   constexpr int kWaves = kBlock / kWave;
@@ -214,8 +213,16 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     for (int k = 0; k < NP; ++k) {
       const size_t q = q0 + (size_t)k * kWave + lane;
       const ull2 zero = {0, 0};
-      pa[k] = (q < in_pieces) ? Ap[q] : zero;   // inactive lanes carry zeros: they add
-      pb[k] = (q < in_pieces) ? Bp[q] : zero;   // nothing to the sums and store nothing
+      // inactive lanes carry zeros: they add nothing to the sums and store nothing.
+      // Tables far larger than the 256 MiB Infinity Cache are read once: stream them
+      // (nontemporal) instead of letting them evict each other.
+      if (q < in_pieces) {
+        pa[k] = nt_load ? __builtin_nontemporal_load(Ap + q) : Ap[q];
+        pb[k] = nt_load ? __builtin_nontemporal_load(Bp + q) : Bp[q];
+      } else {
+        pa[k] = zero;
+        pb[k] = zero;
+      }
     }
     transpose_to_runs<NP>(my_lds, pa, lane);
     transpose_to_runs<NP>(my_lds, pb, lane);
@@ -241,8 +248,13 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
       for (int k = 0; k < NPO; ++k) {
         const size_t q = o0 + (size_t)k * kWave + lane;
         if (q < out_pieces) {
-          A2p[q] = oa[k];
-          B2p[q] = ob[k];
+          if (nt_store) {
+            __builtin_nontemporal_store(oa[k], A2p + q);
+            __builtin_nontemporal_store(ob[k], B2p + q);
+          } else {
+            A2p[q] = oa[k];
+            B2p[q] = ob[k];
+          }
         }
       }
     }
@@ -255,26 +267,30 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   block_reduce<F, NS>(f, res, lds);
   if (threadIdx.x < NS) {
     if (gridDim.x == 1) write_split(sums_out, threadIdx.x, res[0]);
-    else partials[(size_t)blockIdx.x * kPartialStride + threadIdx.x] = res[0];
+    else partials[(size_t)threadIdx.x * n_rows + blockIdx.x] = res[0];  // [sum][block]
   }
 }
 
-// One block: sums_out[2s], sums_out[2s+1] = split limbs of sum_b partials[b][s].
+// One block: sums_out[2s], sums_out[2s+1] = split limbs of sum_b partials[s][b].
+// Wave w reduces sum slots w, w+4, ...; lanes stride over the blocks (coalesced).
 template <class F>
 __global__ void __launch_bounds__(kBlock)
-final_reduce_kernel(F f, const u64* __restrict__ partials, int n_blocks, int ns,
+final_reduce_kernel(F f, const u64* __restrict__ partials, int n_blocks, int n_rows, int ns,
                     u64* __restrict__ sums_out) {
-  __shared__ u64 lds[kBlock];
-  const int s = threadIdx.x & 15, g = threadIdx.x >> 4;  // 16 groups x 16 sum slots
-  u64 t = 0;
-  if (s < ns)
-    for (int b = g; b < n_blocks; b += kBlock / 16) t = f.add(t, partials[(size_t)b * kPartialStride + s]);
-  lds[threadIdx.x] = t;
-  __syncthreads();
-  if (threadIdx.x < ns) {
-    u64 v = lds[threadIdx.x];
-    for (int k = 1; k < kBlock / 16; ++k) v = f.add(v, lds[k * 16 + threadIdx.x]);
-    write_split(sums_out, threadIdx.x, v);
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  for (int s = wave; s < ns; s += kBlock / kWave) {
+    const u64* __restrict__ row = partials + (size_t)s * n_rows;
+    u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    int b = lane;
+    for (; b + 3 * kWave < n_blocks; b += 4 * kWave) {
+      u64 x0 = row[b], x1 = row[b + kWave], x2 = row[b + 2 * kWave], x3 = row[b + 3 * kWave];
+      t0 = f.add(t0, x0); t1 = f.add(t1, x1); t2 = f.add(t2, x2); t3 = f.add(t3, x3);
+    }
+    for (; b < n_blocks; b += kWave) t0 = f.add(t0, row[b]);
+    u64 t = f.add(f.add(t0, t1), f.add(t2, t3));
+#pragma unroll
+    for (int off = kWave / 2; off >= 1; off >>= 1) t = f.add(t, shfl_down_u64(t, off));
+    if (lane == 0) write_split(sums_out, s, t);
   }
 }
 

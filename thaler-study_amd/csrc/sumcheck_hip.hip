@@ -94,9 +94,11 @@ struct sc_ctx {
   int tail_log = 12;
   int max_blocks = 2048;
   int time_kernels = 0;
+  int nt_load_log = 25;   // tables of >= 2^this entries are loaded nontemporal
+  int nt_store_log = 25;  // outputs of >= 2^this entries are stored nontemporal
 
   // workspace
-  u64* d_partials = nullptr;  // [max_blocks][kPartialStride]
+  u64* d_partials = nullptr;  // [kMaxSums + spare][partial_rows]
   u64* d_sums = nullptr;      // 2*kMaxSums split limbs (+ spare)
   u64* h_sums = nullptr;      // pinned mirror
   size_t partial_rows = 0;
@@ -266,13 +268,17 @@ int grid_for(const sc_ctx* ctx, size_t n_threads_needed) {
 
 template <class F>
 void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const u64* B, u64* A2,
-                   u64* B2, u64 r0, u64 r1, size_t n_units, int grid) {
+                   u64* B2, u64 r0, u64 r1, size_t n_units, int grid, int log_in) {
   dim3 g(grid), b(sc::kBlock);
+  const int rows = (int)ctx->partial_rows;
+  const int nt_ld = log_in >= ctx->nt_load_log ? 1 : 0;
+  const int nt_st = (log_in - kf) >= ctx->nt_store_log ? 1 : 0;
   hipStream_t s = ctx->stream;
   u64* P = ctx->d_partials;
   u64* S = ctx->d_sums;
 #define SC_PASS(KF, KS) \
-  hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS>), g, b, 0, s, f, A, B, A2, B2, r0, r1, n_units, P, S)
+  hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS>), g, b, 0, s, f, A, B, A2, B2, r0, r1, n_units, P, S, rows, nt_ld, \
+                     nt_st)
   switch (kf * 4 + ks) {
     case 0 * 4 + 1: SC_PASS(0, 1); break;
     case 0 * 4 + 2: SC_PASS(0, 2); break;
@@ -285,7 +291,7 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
 #undef SC_PASS
   if (grid > 1) {
     int ns = ks == 1 ? 3 : 9;
-    hipLaunchKernelGGL((sc::final_reduce_kernel<F>), dim3(1), b, 0, s, f, P, grid, ns, S);
+    hipLaunchKernelGGL((sc::final_reduce_kernel<F>), dim3(1), b, 0, s, f, P, grid, rows, ns, S);
   }
 }
 
@@ -297,7 +303,7 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   size_t n_units = (size_t)1 << (log_in - kf - ks);
   int grid = grid_for(ctx, n_units);
   if (ctx->time_kernels) SC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, r0, r1, n_units, grid));
+  SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, r0, r1, n_units, grid, log_in));
   SC_HIP(ctx, hipGetLastError());
   if (ctx->time_kernels) {
     SC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -521,7 +527,7 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
   SC_CREATE_HIP(hipSetDevice(device));
   SC_CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   ctx->partial_rows = 4096;
-  SC_CREATE_HIP(hipMalloc(&ctx->d_partials, ctx->partial_rows * sc::kPartialStride * sizeof(u64)));
+  SC_CREATE_HIP(hipMalloc(&ctx->d_partials, ctx->partial_rows * 16 * sizeof(u64)));
   SC_CREATE_HIP(hipMalloc(&ctx->d_sums, 64 * sizeof(u64)));
   SC_CREATE_HIP(hipHostMalloc(&ctx->h_sums, 64 * sizeof(u64), hipHostMallocDefault));
   SC_CREATE_HIP(hipEventCreate(&ctx->ev0));
@@ -566,6 +572,10 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
     ctx->max_blocks = (int)value;
   } else if (k == "time_kernels") {
     ctx->time_kernels = value ? 1 : 0;
+  } else if (k == "nt_load_log") {
+    ctx->nt_load_log = (int)value;
+  } else if (k == "nt_store_log") {
+    ctx->nt_store_log = (int)value;
   } else {
     return fail(ctx, SC_ERR_ARG, "unknown option '%s'", key);
   }
@@ -579,6 +589,8 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   else if (k == "tail_log") *value = ctx->tail_log;
   else if (k == "max_blocks") *value = ctx->max_blocks;
   else if (k == "time_kernels") *value = ctx->time_kernels;
+  else if (k == "nt_load_log") *value = ctx->nt_load_log;
+  else if (k == "nt_store_log") *value = ctx->nt_store_log;
   else return fail(ctx, SC_ERR_ARG, "unknown option '%s'", key);
   return SC_OK;
 }

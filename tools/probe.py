@@ -1,4 +1,5 @@
-"""quick timing probe (not the bench): whole-prover wall time and pass-kernel device time"""
+"""quick timing probe (not the bench): whole-prover wall time and pass-kernel device time
+usage: probe.py n1,n2 [vpp list] [opt=val ...]"""
 import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import __graft_entry__ as ge
@@ -7,9 +8,13 @@ sys.path.insert(0, os.path.join(ge.ROOT, "oracle"))
 import pyref
 mm = pkg.matrix_multiplication
 ns = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [20, 24, 26, 28]
-for vpp in (1, 2):
+vpps = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2]
+opts = dict(kv.split("=") for kv in sys.argv[3:])
+for vpp in vpps:
     ctx = pkg.Context(pkg.Field(pkg.GOLDILOCKS))
     ctx.set_option("vars_per_pass", vpp)
+    for k, v in opts.items():
+        ctx.set_option(k, int(v))
     for n in ns:
         a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
         b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, n)
@@ -17,7 +22,7 @@ for vpp in (1, 2):
         for _ in range(2):
             mm.prove(ctx, g, pyref.SEED_R)
         ts = []
-        for _ in range(5):
+        for _ in range(7):
             ctx.synchronize()
             t0 = time.perf_counter()
             mm.prove(ctx, g, pyref.SEED_R)
@@ -29,7 +34,7 @@ for vpp in (1, 2):
         nk, kms = ctx.kernel_time(reset=True)
         ctx.set_option("time_kernels", 0)
         alg = 64 * 2**n - 96
-        print("vpp=%d n=%d wall=%.3f ms  muladds/s=%.3e  alg GB/s=%.0f  | pass kernels: %d launches %.3f ms -> alg GB/s=%.0f"
-              % (vpp, n, t * 1e3, (5 * 2**n - 7) / t, alg / t / 1e9, nk, kms, alg / (kms * 1e-3) / 1e9), flush=True)
+        print("%s vpp=%d n=%d wall=%.3f ms  muladds/s=%.3e  alg GB/s=%.0f  | pass kernels: %d launches %.3f ms -> alg GB/s=%.0f"
+              % (opts, vpp, n, t * 1e3, (5 * 2**n - 7) / t, alg / t / 1e9, nk, kms, alg / (kms * 1e-3) / 1e9), flush=True)
         del a, b, g
     ctx.close()
