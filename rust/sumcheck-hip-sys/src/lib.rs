@@ -1,0 +1,157 @@
+//! Raw declarations of `include/sumcheck_hip.h`.  One item per C entry point, same order.
+#![allow(non_camel_case_types)]
+use core::ffi::{c_char, c_int, c_void};
+
+pub const SC_OK: c_int = 0;
+pub const SC_ERR_ARG: c_int = 1;
+pub const SC_ERR_HIP: c_int = 2;
+pub const SC_ERR_RCCL: c_int = 3;
+pub const SC_ERR_OOM: c_int = 4;
+pub const SC_ERR_STATE: c_int = 5;
+pub const SC_ERR_UNSUPPORTED: c_int = 6;
+pub const SC_ORDER_LE: c_int = 0;
+pub const SC_ORDER_BE: c_int = 1;
+
+#[repr(C)]
+#[derive(Clone, Copy, Debug)]
+pub struct sc_field {
+    pub p: u64,
+    pub p_inv_neg: u64,
+    pub r_mod_p: u64,
+    pub r2_mod_p: u64,
+}
+
+#[repr(C)]
+pub struct sc_ctx {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct sc_table {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct sc_prover {
+    _private: [u8; 0],
+}
+
+pub type sc_allreduce_fn = Option<unsafe extern "C" fn(user: *mut c_void, buf: *mut u64, count: usize) -> c_int>;
+pub type sc_allgather_fn =
+    Option<unsafe extern "C" fn(user: *mut c_void, send: *const u64, recv: *mut u64, count: usize) -> c_int>;
+pub type sc_draw_fn = Option<unsafe extern "C" fn(user: *mut c_void, round: usize, evals: *const u64) -> u64>;
+
+extern "C" {
+    pub fn sc_field_from_modulus(p: u64, out: *mut sc_field) -> c_int;
+    pub fn sc_field_to_mont(f: *const sc_field, canonical: u64) -> u64;
+    pub fn sc_field_from_mont(f: *const sc_field, mont: u64) -> u64;
+    pub fn sc_interpolate_quadratic(f: *const sc_field, e: *const u64, c: *mut u64) -> c_int;
+
+    pub fn sc_ctx_create(f: *const sc_field, device: c_int, out: *mut *mut sc_ctx) -> c_int;
+    pub fn sc_ctx_destroy(ctx: *mut sc_ctx) -> c_int;
+    pub fn sc_last_error(ctx: *const sc_ctx) -> *const c_char;
+    pub fn sc_ctx_set_option(ctx: *mut sc_ctx, key: *const c_char, value: i64) -> c_int;
+    pub fn sc_ctx_get_option(ctx: *const sc_ctx, key: *const c_char, value: *mut i64) -> c_int;
+    pub fn sc_ctx_synchronize(ctx: *mut sc_ctx) -> c_int;
+    pub fn sc_ctx_stream(ctx: *const sc_ctx) -> *mut c_void;
+    pub fn sc_ctx_kernel_time(ctx: *mut sc_ctx, out: *mut f64, reset: c_int) -> c_int;
+
+    pub fn sc_comm_unique_id(id: *mut u8) -> c_int;
+    pub fn sc_ctx_comm_init_rccl(ctx: *mut sc_ctx, id: *const u8, rank: c_int, world: c_int) -> c_int;
+    pub fn sc_ctx_comm_init_host(
+        ctx: *mut sc_ctx,
+        rank: c_int,
+        world: c_int,
+        allreduce: sc_allreduce_fn,
+        allgather: sc_allgather_fn,
+        user: *mut c_void,
+    ) -> c_int;
+    pub fn sc_ctx_comm_rank(ctx: *const sc_ctx, rank: *mut c_int, world: *mut c_int) -> c_int;
+
+    pub fn sc_table_upload(ctx: *mut sc_ctx, host: *const u64, len: usize, out: *mut *mut sc_table) -> c_int;
+    pub fn sc_table_generate(ctx: *mut sc_ctx, seed: u64, start: u64, len: usize, out: *mut *mut sc_table) -> c_int;
+    pub fn sc_table_clone(ctx: *mut sc_ctx, t: *const sc_table, out: *mut *mut sc_table) -> c_int;
+    pub fn sc_table_download(ctx: *mut sc_ctx, t: *const sc_table, host: *mut u64, len: usize) -> c_int;
+    pub fn sc_table_len(t: *const sc_table) -> usize;
+    pub fn sc_table_device_ptr(t: *const sc_table) -> *const u64;
+    pub fn sc_table_free(ctx: *mut sc_ctx, t: *mut sc_table) -> c_int;
+    pub fn sc_table_fix_variables(
+        ctx: *mut sc_ctx,
+        input: *const sc_table,
+        r: *const u64,
+        k: usize,
+        order: c_int,
+        out: *mut *mut sc_table,
+    ) -> c_int;
+    pub fn sc_table_evaluate(
+        ctx: *mut sc_ctx,
+        t: *const sc_table,
+        r: *const u64,
+        n: usize,
+        order: c_int,
+        out: *mut u64,
+    ) -> c_int;
+    pub fn sc_table_relabel(
+        ctx: *mut sc_ctx,
+        input: *const sc_table,
+        a: usize,
+        b: usize,
+        k: usize,
+        out: *mut *mut sc_table,
+    ) -> c_int;
+
+    pub fn sc_matmul_g_new(
+        ctx: *mut sc_ctx,
+        a: *const sc_table,
+        b: *const sc_table,
+        n: usize,
+        point: *const u64,
+        a_out: *mut *mut sc_table,
+        b_out: *mut *mut sc_table,
+    ) -> c_int;
+    pub fn sc_prod2_to_evaluations(
+        ctx: *mut sc_ctx,
+        a: *const sc_table,
+        b: *const sc_table,
+        out: *mut *mut sc_table,
+    ) -> c_int;
+    pub fn sc_prod2_sum(ctx: *mut sc_ctx, a: *const sc_table, b: *const sc_table, out_c1: *mut u64) -> c_int;
+    pub fn sc_prod2_round_sums(ctx: *mut sc_ctx, a: *const sc_table, b: *const sc_table, out_e: *mut u64) -> c_int;
+    pub fn sc_prod2_fold_and_sums(
+        ctx: *mut sc_ctx,
+        a: *const sc_table,
+        b: *const sc_table,
+        r: *const u64,
+        a_out: *mut *mut sc_table,
+        b_out: *mut *mut sc_table,
+        out_e: *mut u64,
+    ) -> c_int;
+    pub fn sc_prod2_evaluate(
+        ctx: *mut sc_ctx,
+        a: *const sc_table,
+        b: *const sc_table,
+        point: *const u64,
+        n: usize,
+        out: *mut u64,
+    ) -> c_int;
+
+    pub fn sc_prover_create(
+        ctx: *mut sc_ctx,
+        a: *const sc_table,
+        b: *const sc_table,
+        out: *mut *mut sc_prover,
+    ) -> c_int;
+    pub fn sc_prover_c1(pr: *const sc_prover, out: *mut u64) -> c_int;
+    pub fn sc_prover_num_vars(pr: *const sc_prover, out: *mut usize) -> c_int;
+    pub fn sc_prover_round(pr: *mut sc_prover, r_prev: u64, j: usize, out_e: *mut u64) -> c_int;
+    pub fn sc_prover_destroy(pr: *mut sc_prover) -> c_int;
+    pub fn sc_prove(
+        ctx: *mut sc_ctx,
+        a: *const sc_table,
+        b: *const sc_table,
+        draw: sc_draw_fn,
+        user: *mut c_void,
+        seed_r: u64,
+        c1: *mut u64,
+        evals: *mut u64,
+        challenges: *mut u64,
+    ) -> c_int;
+}

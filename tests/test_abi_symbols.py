@@ -1,0 +1,70 @@
+"""CPU-only: the C-ABI library is built for gfx950, loads, and exports exactly the symbols
+include/sumcheck_hip.h declares; computing entry points fail loudly without a GPU."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT, has_gpu, load_package
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "sumcheck_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(sc_[a-z0-9_]+)\s*\(", text)) - {"sc_allreduce_fn", "sc_allgather_fn", "sc_draw_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    pkg = load_package()
+    pkg.build()
+    lib = pkg.load()
+    declared = header_functions()
+    assert len(declared) >= 35
+    assert sorted(pkg._lib.SIGNATURES) == declared, "ctypes stub and header disagree"
+    for name in declared:
+        assert hasattr(lib, name), name
+    out = subprocess.check_output(["nm", "-D", "--defined-only", pkg._lib.LIB_PATH], text=True)
+    exported = set(re.findall(r" T (sc_[a-z0-9_]+)", out))
+    assert exported == set(declared), exported ^ set(declared)
+
+
+def test_code_object_is_gfx950():
+    pkg = load_package()
+    blob = open(pkg._lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    assert b"pass_kernel" in blob
+
+
+def test_no_product_dependency_on_oracle():
+    """the product tree must not import, link or mention the oracle"""
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "thaler-study_amd")):
+        for f in files:
+            if f.endswith((".py", ".hpp", ".hip", ".h", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "sc_oracle" not in text and "pyref" not in text and "import oracle" not in text, f
+
+
+def test_host_field_helpers_need_no_gpu():
+    pkg = load_package()
+    lib = pkg.load()
+    f = pkg._lib.ScField()
+    assert lib.sc_field_from_modulus(pkg.GOLDILOCKS, ctypes.byref(f)) == 0
+    assert f.r_mod_p == 0xFFFFFFFF and f.r2_mod_p == 0xFFFFFFFE00000001
+    assert lib.sc_field_from_modulus(4, ctypes.byref(f)) == 1
+    F = pkg.Field(389)
+    assert lib.sc_field_to_mont(F.ref(), 5) == F.from_int(5)
+    assert lib.sc_field_from_mont(F.ref(), F.from_int(77)) == 77
+    e = (ctypes.c_uint64 * 3)(F.from_int(3), F.from_int(10), F.from_int(23))   # 3 + 4x + 3x^2
+    c = (ctypes.c_uint64 * 3)()
+    assert lib.sc_interpolate_quadratic(F.ref(), e, c) == 0
+    assert [F.to_int(x) for x in c] == [3, 4, 3]
+
+
+@pytest.mark.skipif(has_gpu(), reason="checks the no-GPU failure mode")
+def test_fails_loudly_without_gpu():
+    pkg = load_package()
+    with pytest.raises(pkg.SumcheckHipError) as ei:
+        pkg.Context(pkg.Field(pkg.GOLDILOCKS))
+    assert ei.value.code == 2 and "no CPU path" in str(ei.value)

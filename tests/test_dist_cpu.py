@@ -1,0 +1,141 @@
+"""World-size-2 (and 4) gloo tests on CPU for the N > 1 path: the shard plan, the 32-bit
+limb all-reduce, the tail gather and the torch.distributed adapter that
+`Context.comm_init_host` uses.  The GPU kernels cannot run here, so the oracle stands in
+for them inside a Python model of the engine's schedule; the model and the engine are
+compared against the same full-table oracle transcript (the engine in
+tests/test_gpu_sharded.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_package
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allgather, pyref):
+    """Python model of sc_prover_* in sharded mode (thaler-study_amd/csrc/sumcheck_hip.hip,
+    prover_pass / prover_answer), with oracle calls in place of kernels."""
+    from util_field import lagrange_weights
+    start, length = D.shard_range(n, rank, world)
+    a = o.generate_range(pyref.SEED_A, start, length)
+    b = o.generate_range(pyref.SEED_B, start, length)
+    ch = [o.challenge(pyref.SEED_R, j + 1) for j in range(n)]
+    g = world.bit_length() - 1
+    sharded, pending, cache = True, [], None
+    evals = []
+    n_allreduce = 0
+    for j in range(n):
+        if j:
+            pending.append(ch[j - 1])
+        covered = cache is not None and (
+            (cache[1] == j and not pending) or (cache[0] == 2 and cache[1] + 1 == j and len(pending) == 1))
+        if not covered:
+            kf = len(pending)
+            ks = 2 if (vpp == 2 and n - j >= 2) else 1
+            cur_log = int(a.size).bit_length() - 1
+            if sharded and (cur_log < kf + ks or cur_log <= tail_log):
+                a = allgather(a)
+                b = allgather(b)
+                sharded = False
+            if kf:
+                a = o.fix_variables(a, pending)
+                b = o.fix_variables(b, pending)
+                pending = []
+            S = o.grid_sums(a, b) if ks == 2 else o.round_evals(a, b)
+            if sharded:
+                limbs = D.split_limbs([int(x) for x in S])
+                allreduce(limbs)
+                n_allreduce += 1
+                S = D.recombine_limbs(limbs, p)
+            cache = (ks, j, [int(x) for x in S])
+        ks, j0, S = cache
+        if ks == 1:
+            e = S
+        elif j == j0:
+            e = [(S[3 * u] + S[3 * u + 1]) % p for u in range(3)]
+        else:
+            L = lagrange_weights(o, pending[0])
+            e = [o.lib.sco_add(o.fp, o.lib.sco_add(o.fp, o.lib.sco_mul(o.fp, L[0], S[v]),
+                                                   o.lib.sco_mul(o.fp, L[1], S[3 + v])),
+                               o.lib.sco_mul(o.fp, L[2], S[6 + v])) for v in range(3)]
+        evals.append([int(x) for x in e])
+    return evals, ch, n_allreduce
+
+
+def _worker(rank, world, port, cases, q):
+    try:
+        import torch.distributed as dist
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        pkg = load_package()
+        D = pkg.distributed
+        import pyref
+        from oracle import Oracle
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        os.environ["RANK"], os.environ["WORLD_SIZE"] = str(rank), str(world)
+        r, w, _ = D.init_process_group_from_env("gloo")
+        assert (r, w) == (rank, world)
+        allreduce, allgather = D.torch_collectives()
+        # control plane: bytes broadcast (what carries the RCCL unique id)
+        payload = D.broadcast_bytes(bytes(range(128)) if rank == 0 else None)
+        assert payload == bytes(range(128))
+        out = []
+        for (p, n, tail_log, vpp) in cases:
+            o = Oracle(p)
+            evals, ch, nar = model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allgather, pyref)
+            full = o.prove(o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n), np.array(ch, dtype=np.uint64))
+            ok = full["status"] == 0 and evals == [[int(x) for x in row] for row in full["evals"]]
+            out.append((p, n, tail_log, vpp, ok, nar))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, out))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, "ERR %s\n%s" % (e, traceback.format_exc())))
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_gloo_sharded_schedule(world):
+    GOLD = 2**64 - 2**32 + 1
+    cases = [(GOLD, 10, 0, 2), (GOLD, 10, 0, 1), (GOLD, 11, 4, 2), (389, 9, 0, 2), (GOLD, 3, 0, 2),
+             (GOLD, world.bit_length() - 1, 0, 2), (5, 8, 2, 1)]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + world + (os.getpid() % 200)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, cases, q)) for r in range(world)]
+    for pr in procs:
+        pr.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for pr in procs:
+        pr.join(timeout=60)
+    for rank, out in results:
+        assert not isinstance(out, str), out
+        for (p, n, tail_log, vpp, ok, nar) in out:
+            assert ok, (rank, p, n, tail_log, vpp)
+        # with tail_log 0 and n = 10 the run used several limb all-reduces
+        assert out[0][5] >= 3
+
+
+def test_shard_plan_and_limbs():
+    pkg = load_package()
+    D = pkg.distributed
+    assert D.shard_range(28, 3, 8) == (3 << 25, 1 << 25)
+    assert D.shard_range(3, 7, 8) == (7, 1)
+    with pytest.raises(ValueError):
+        D.shard_range(2, 0, 8)
+    with pytest.raises(ValueError):
+        D.shard_range(10, 0, 3)
+    p = 2**64 - 2**32 + 1
+    vals = [0, 1, p - 1, 2**32, 2**32 - 1, 0x123456789ABCDEF0 % p]
+    limbs = D.split_limbs(vals)
+    assert all(int(x) < 2**32 for x in limbs)
+    assert D.recombine_limbs(limbs, p) == vals
+    # eight ranks worth of the worst case cannot wrap a u64 slot and recombines mod p
+    total = np.zeros_like(limbs)
+    for _ in range(8):
+        total += D.split_limbs([p - 1] * len(vals))
+    assert D.recombine_limbs(total, p) == [(8 * (p - 1)) % p] * len(vals)
