@@ -447,3 +447,24 @@ def test_full_size_vs_oracle_n24(pkg):
     assert a.evaluate(pt) == o.evaluate(oa, pt)
     assert a.evaluate(pt, order=pkg.ORDER_BE) == o.vsbw(oa, pt)
     assert np.array_equal(a.fix_variables(pt[:1]).to_evaluations(), o.fix_variables(oa, pt[:1]))
+
+
+def test_stress_inkernel_handoff(pkg):
+    """the ticket hand-off of finish_pass under back-to-back launches whose partials differ:
+    a stale partial (or mailbox word) from the previous launch would change a round sum"""
+    ctx = ctx_for(pkg, GOLD)
+    o = oracle(GOLD)
+    mm = pkg.matrix_multiplication
+    for n in (13, 16, 19):
+        gs, refs = [], []
+        for k in range(3):
+            a = pkg.DenseMultilinearExtension.generate(ctx, 100 + 2 * k, n)
+            b = pkg.DenseMultilinearExtension.generate(ctx, 101 + 2 * k, n)
+            gs.append(mm.G(a, b))
+            ch = challenges(o, n)
+            refs.append(o.prove(o.generate(100 + 2 * k, n), o.generate(101 + 2 * k, n), ch))
+        for it in range(150):
+            k = it % 3
+            c1, evals, _ = mm.prove(ctx, gs[k], pyref.SEED_R)
+            assert c1 == refs[k]["c_1"], (n, it)
+            assert np.array_equal(evals, refs[k]["evals"]), (n, it)

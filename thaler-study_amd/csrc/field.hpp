@@ -30,11 +30,19 @@ namespace sc {
 typedef uint64_t u64;
 typedef uint32_t u32;
 
-// 64 x 64 -> 128 product.
+// 64 x 64 -> 128 product.  Device: four 32x32+64 multiply-adds (v_mad_u64_u32); asking the
+// compiler for `a*b` and `__umul64hi(a,b)` separately costs seven quarter-rate multiplies.
 SC_HD void mul_wide(u64 a, u64 b, u64& hi, u64& lo) {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SC_FIELD_V0)
   lo = a * b;
   hi = __umul64hi(a, b);
+#elif defined(__HIP_DEVICE_COMPILE__)
+  const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
+  const u64 p00 = (u64)a0 * b0;
+  const u64 mid = (u64)a0 * b1 + (p00 >> 32);     // < 2^64: (2^32-1)^2 + 2^32-1
+  const u64 mid2 = (u64)a1 * b0 + (u32)mid;
+  hi = (u64)a1 * b1 + (mid >> 32) + (mid2 >> 32);  // < 2^64: (2^32-1)^2 + 2(2^32-1)
+  lo = (mid2 << 32) | (u32)p00;
 #else
   unsigned __int128 t = (unsigned __int128)a * b;
   lo = (u64)t;
@@ -123,14 +131,19 @@ struct GoldilocksMont {
   SC_HD u64 modulus() const { return P; }
   SC_HD u64 one() const { return R1; }
 
+  // a + b >= p  <=>  a + b + (2^64 - p) carries out of 64 bits, and 2^64 - p = EPS:
+  // two add-with-carry pairs and a select, no 64-bit compare against p.
   SC_HD u64 add(u64 a, u64 b) const {
-    u64 s = a + b;
-    bool carry = s < a;
-    return (carry || s >= P) ? s - P : s;
+    u64 s, u;
+    const bool c1 = __builtin_add_overflow(a, b, &s);
+    const bool c2 = __builtin_add_overflow(s, EPS, &u);
+    return (c1 | c2) ? u : s;
   }
+  // a - b + p on borrow; +p == -EPS (mod 2^64)
   SC_HD u64 sub(u64 a, u64 b) const {
-    u64 d = a - b;
-    return (a < b) ? d + P : d;
+    u64 d;
+    const bool bw = __builtin_sub_overflow(a, b, &d);
+    return d - (bw ? EPS : (u64)0);
   }
   SC_HD u64 dbl(u64 a) const { return add(a, a); }
 
@@ -161,15 +174,13 @@ struct GoldilocksMont {
   SC_HD void acc_mac(Acc& a, u64 x, u64 y) const {
     u64 hi, lo;
     mul_wide(x, y, hi, lo);
-    u64 s0 = a.w0 + lo;
-    u64 c0 = s0 < lo ? 1u : 0u;
-    u64 s1 = a.w1 + hi;
-    u64 c1 = s1 < hi ? 1u : 0u;
-    u64 s1b = s1 + c0;
-    c1 += (s1b < s1) ? 1u : 0u;
-    a.w0 = s0;
-    a.w1 = s1b;
-    a.w2 += (u32)c1;
+    typedef unsigned __int128 u128;
+    const u128 prod = ((u128)hi << 64) | lo;
+    u128 sum;
+    const bool c = __builtin_add_overflow(((u128)a.w1 << 64) | a.w0, prod, &sum);
+    a.w0 = (u64)sum;
+    a.w1 = (u64)(sum >> 64);
+    a.w2 += c ? 1u : 0u;
   }
   // (w2*2^128 + w1*2^64 + w0) * 2^-64 mod p  =  w1 - floor(m p / 2^64) + w2 * 2^64  (mod p)
   SC_HD u64 acc_get(const Acc& a) const {

@@ -179,19 +179,108 @@ __device__ __forceinline__ void transpose_to_pieces(ull2* __restrict__ lds, ull2
 // fix_variables + to_univariate, sum-check-protocol/src/lib.rs:105-112).
 //
 // unit = one run of IN = 2^(KF+KS) input entries per table -> OUT = 2^KS output entries,
-// owned by one lane; a wave tile is 64 units.  gridDim.x == 1: the single block writes the
-// final split-limb sums to `sums_out`; otherwise block b writes its partial residues to
-// partials[b*kPartialStride + s] and final_reduce_kernel finishes.
+// owned by one lane; a wave tile is 64 units.  Sums leave through finish_pass (PassOut).
+// Where a pass leaves its sums.
+//  * grid of one block: that block publishes directly.
+//  * larger grids: every block stores its partial residues (sum-major rows), takes a ticket,
+//    and the block that draws the last ticket reduces all partials and publishes - one
+//    launch per pass instead of pass + reduce (+ copy).  Hand-off follows
+//    cdna_hip_programming.md Guideline 16: partials are stored write-through (sc1), the
+//    storing wave drains them, lane 0 releases at agent scope and then adds to the ticket;
+//    the last block acquires at agent scope behind a workgroup barrier and reads with sc1
+//    loads.  The ticket counter only grows (base = value before this launch), so nothing
+//    has to be re-zeroed between launches.
+//  * publish target: `mailbox` (pinned host memory the host spins on: 2*NS split limbs, then
+//    the sequence word at index kMailboxSeq) or, for the sharded transports that still have
+//    to all-reduce on the device, `sums_dev`.
+constexpr int kMailboxSeq = 24;
+struct PassOut {
+  u64* partials;
+  int n_rows;
+  unsigned* ticket;
+  unsigned ticket_base;
+  u64* sums_dev;
+  u64* mailbox;
+  u64 seq;
+};
+
+__device__ __forceinline__ void publish_value(const PassOut& o, int s, u64 v) {
+  if (o.mailbox) {
+    __hip_atomic_store(o.mailbox + 2 * s, v & 0xFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(o.mailbox + 2 * s + 1, v >> 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    write_split(o.sums_dev, s, v);
+  }
+}
+// after a workgroup barrier that follows every publish_value of the block
+__device__ __forceinline__ void publish_seq(const PassOut& o) {
+  if (o.mailbox && threadIdx.x == 0)
+    __hip_atomic_store(o.mailbox + kMailboxSeq, o.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Tail of every pass: res[0] of thread s < NS holds the block's residue of sum s.
+template <class F, int NS>
+__device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my_res, int* lds_flag) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (gridDim.x == 1) {
+    if (threadIdx.x < NS) publish_value(o, threadIdx.x, my_res);
+    __syncthreads();
+    publish_seq(o);
+    return;
+  }
+  if (threadIdx.x < NS)
+    __hip_atomic_store(o.partials + (size_t)threadIdx.x * o.n_rows + blockIdx.x, my_res, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // wave 0 holds every storing lane
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(o.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t - o.ticket_base == gridDim.x - 1) ? 1 : 0;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *lds_flag = last;
+  }
+  __syncthreads();
+  if (!*lds_flag) return;
+  const int n_blocks = gridDim.x;
+  for (int s = wave; s < NS; s += kBlock / kWave) {
+    const u64* row = o.partials + (size_t)s * o.n_rows;
+    u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+    int b = lane;
+    for (; b + 3 * kWave < n_blocks; b += 4 * kWave) {
+      const u64 x0 = __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 x1 = __hip_atomic_load(row + b + kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 x2 = __hip_atomic_load(row + b + 2 * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 x3 = __hip_atomic_load(row + b + 3 * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      t0 = f.add(t0, x0); t1 = f.add(t1, x1); t2 = f.add(t2, x2); t3 = f.add(t3, x3);
+    }
+    for (; b < n_blocks; b += kWave)
+      t0 = f.add(t0, __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    u64 t = f.add(f.add(t0, t1), f.add(t2, t3));
+#pragma unroll
+    for (int off = kWave / 2; off >= 1; off >>= 1) t = f.add(t, shfl_down_u64(t, off));
+    if (lane == 0) publish_value(o, s, t);
+  }
+  __syncthreads();
+  publish_seq(o);
+}
+
+#ifndef SC_PASS_BOUNDS
+#define SC_PASS_BOUNDS __launch_bounds__(kBlock)
+#endif
 template <class F, int KF, int KS>
-__global__ void __launch_bounds__(kBlock)
+__global__ void SC_PASS_BOUNDS
 pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
-            u64* __restrict__ B2, u64 r0, u64 r1, size_t n_units, u64* __restrict__ partials,
-            u64* __restrict__ sums_out, int n_rows, int nt_load, int nt_store) {
+            u64* __restrict__ B2, u64 r0, u64 r1, size_t n_units, PassOut out, int nt_load, int nt_store) {
   constexpr int IN = 1 << (KF + KS), OUT = 1 << KS, NS = (KS == 1) ? 3 : 9;
   constexpr int NP = IN / 2, NPO = OUT / 2;  // 16-byte pieces per lane, in and out
   constexpr int kWaves = kBlock / kWave;
   __shared__ ull2 lds_t[(NP > 1 || NPO > 1) ? kWaves * kWave * NP : 1];
   __shared__ u64 lds[kWaves * NS];
+  __shared__ int lds_flag;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   ull2* const my_lds = lds_t + ((NP > 1 || NPO > 1) ? wave * kWave * NP : 0);
 
@@ -206,16 +295,14 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   ull2* __restrict__ A2p = reinterpret_cast<ull2*>(A2);
   ull2* __restrict__ B2p = reinterpret_cast<ull2*>(B2);
 
-  for (size_t tile = (size_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (size_t)gridDim.x * kWaves) {
+  // inactive lanes carry zeros: they add nothing to the sums and store nothing.  Tables far
+  // larger than the 256 MiB Infinity Cache are read once: stream them (nontemporal).
+  auto load_tile = [&](size_t tile, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
     const size_t q0 = tile * kWave * NP;
-    ull2 pa[NP], pb[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
       const size_t q = q0 + (size_t)k * kWave + lane;
       const ull2 zero = {0, 0};
-      // inactive lanes carry zeros: they add nothing to the sums and store nothing.
-      // Tables far larger than the 256 MiB Infinity Cache are read once: stream them
-      // (nontemporal) instead of letting them evict each other.
       if (q < in_pieces) {
         pa[k] = nt_load ? __builtin_nontemporal_load(Ap + q) : Ap[q];
         pb[k] = nt_load ? __builtin_nontemporal_load(Bp + q) : Bp[q];
@@ -224,6 +311,8 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
         pb[k] = zero;
       }
     }
+  };
+  auto process_tile = [&](size_t tile, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
     transpose_to_runs<NP>(my_lds, pa, lane);
     transpose_to_runs<NP>(my_lds, pb, lane);
     u64 a[IN], b[IN];
@@ -259,39 +348,40 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
       }
     }
     accumulate_run<F, KS>(f, acc, a, b);
+  };
+
+  const size_t tile_stride = (size_t)gridDim.x * kWaves;
+  size_t tile = (size_t)blockIdx.x * kWaves + wave;
+#if defined(SC_PREFETCH)
+  // software pipeline: the next tile's loads are in flight while this one is computed
+  if (tile < n_tiles) {
+    ull2 ca[NP], cb[NP];
+    load_tile(tile, ca, cb);
+    while (true) {
+      const size_t nxt = tile + tile_stride;
+      ull2 na[NP], nb[NP];
+      const bool more = nxt < n_tiles;
+      if (more) load_tile(nxt, na, nb);
+      process_tile(tile, ca, cb);
+      if (!more) break;
+#pragma unroll
+      for (int k = 0; k < NP; ++k) { ca[k] = na[k]; cb[k] = nb[k]; }
+      tile = nxt;
+    }
   }
+#else
+  for (; tile < n_tiles; tile += tile_stride) {
+    ull2 pa[NP], pb[NP];
+    load_tile(tile, pa, pb);
+    process_tile(tile, pa, pb);
+  }
+#endif
 
   u64 res[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) res[s] = f.acc_get(acc[s]);
   block_reduce<F, NS>(f, res, lds);
-  if (threadIdx.x < NS) {
-    if (gridDim.x == 1) write_split(sums_out, threadIdx.x, res[0]);
-    else partials[(size_t)threadIdx.x * n_rows + blockIdx.x] = res[0];  // [sum][block]
-  }
-}
-
-// One block: sums_out[2s], sums_out[2s+1] = split limbs of sum_b partials[s][b].
-// Wave w reduces sum slots w, w+4, ...; lanes stride over the blocks (coalesced).
-template <class F>
-__global__ void __launch_bounds__(kBlock)
-final_reduce_kernel(F f, const u64* __restrict__ partials, int n_blocks, int n_rows, int ns,
-                    u64* __restrict__ sums_out) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  for (int s = wave; s < ns; s += kBlock / kWave) {
-    const u64* __restrict__ row = partials + (size_t)s * n_rows;
-    u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
-    int b = lane;
-    for (; b + 3 * kWave < n_blocks; b += 4 * kWave) {
-      u64 x0 = row[b], x1 = row[b + kWave], x2 = row[b + 2 * kWave], x3 = row[b + 3 * kWave];
-      t0 = f.add(t0, x0); t1 = f.add(t1, x1); t2 = f.add(t2, x2); t3 = f.add(t3, x3);
-    }
-    for (; b < n_blocks; b += kWave) t0 = f.add(t0, row[b]);
-    u64 t = f.add(f.add(t0, t1), f.add(t2, t3));
-#pragma unroll
-    for (int off = kWave / 2; off >= 1; off >>= 1) t = f.add(t, shfl_down_u64(t, off));
-    if (lane == 0) write_split(sums_out, s, t);
-  }
+  finish_pass<F, NS>(f, out, res[0], &lds_flag);
 }
 
 // ------------------------------------------------------------------------------------

@@ -16,6 +16,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -102,6 +103,12 @@ struct sc_ctx {
   u64* d_sums = nullptr;      // 2*kMaxSums split limbs (+ spare)
   u64* h_sums = nullptr;      // pinned mirror
   size_t partial_rows = 0;
+  unsigned* d_ticket = nullptr;  // arrival counter of finish_pass (only ever grows)
+  unsigned ticket_base = 0;
+  u64* h_mailbox = nullptr;   // pinned, device-mapped: sums + sequence word written by the kernel
+  u64* d_mailbox = nullptr;   // device alias of h_mailbox
+  u64 mailbox_seq = 0;
+  int use_mailbox = 1;
 
   // device-buffer pool (free blocks by capacity in words; live blocks by pointer)
   std::multimap<size_t, u64*> pool_free;
@@ -268,17 +275,13 @@ int grid_for(const sc_ctx* ctx, size_t n_threads_needed) {
 
 template <class F>
 void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const u64* B, u64* A2,
-                   u64* B2, u64 r0, u64 r1, size_t n_units, int grid, int log_in) {
+                   u64* B2, u64 r0, u64 r1, size_t n_units, int grid, int log_in, const sc::PassOut& out) {
   dim3 g(grid), b(sc::kBlock);
-  const int rows = (int)ctx->partial_rows;
+  hipStream_t s = ctx->stream;
   const int nt_ld = log_in >= ctx->nt_load_log ? 1 : 0;
   const int nt_st = (log_in - kf) >= ctx->nt_store_log ? 1 : 0;
-  hipStream_t s = ctx->stream;
-  u64* P = ctx->d_partials;
-  u64* S = ctx->d_sums;
 #define SC_PASS(KF, KS) \
-  hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS>), g, b, 0, s, f, A, B, A2, B2, r0, r1, n_units, P, S, rows, nt_ld, \
-                     nt_st)
+  hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS>), g, b, 0, s, f, A, B, A2, B2, r0, r1, n_units, out, nt_ld, nt_st)
   switch (kf * 4 + ks) {
     case 0 * 4 + 1: SC_PASS(0, 1); break;
     case 0 * 4 + 2: SC_PASS(0, 2); break;
@@ -289,26 +292,35 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
     default: break;
   }
 #undef SC_PASS
-  if (grid > 1) {
-    int ns = ks == 1 ? 3 : 9;
-    hipLaunchKernelGGL((sc::final_reduce_kernel<F>), dim3(1), b, 0, s, f, P, grid, rows, ns, S);
-  }
 }
 
-// Launch one pass over tables of 2^log_in entries; leaves 2*NS split limbs in ctx->d_sums.
+// Launch one pass over tables of 2^log_in entries.  The 2*NS split limbs end up in the
+// host mailbox (*from_mailbox = true; wait with collect_sums) or in ctx->d_sums when they
+// still have to be all-reduced on the device (RCCL transport).
 int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, u64 r0,
-                u64 r1, int log_in) {
+                u64 r1, int log_in, bool across_ranks, bool* from_mailbox) {
   if (kf < 0 || kf > 2 || ks < 1 || ks > 2 || log_in < kf + ks)
     return fail(ctx, SC_ERR_ARG, "launch_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
   size_t n_units = (size_t)1 << (log_in - kf - ks);
   int grid = grid_for(ctx, n_units);
+  const bool mailbox = ctx->use_mailbox && !(across_ranks && ctx->transport == Transport::kRccl);
+  sc::PassOut out;
+  out.partials = ctx->d_partials;
+  out.n_rows = (int)ctx->partial_rows;
+  out.ticket = ctx->d_ticket;
+  out.ticket_base = ctx->ticket_base;
+  out.sums_dev = ctx->d_sums;
+  out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
+  out.seq = mailbox ? ++ctx->mailbox_seq : 0;
+  if (grid > 1) ctx->ticket_base += (unsigned)grid;
   if (ctx->time_kernels) SC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, r0, r1, n_units, grid, log_in));
+  SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, r0, r1, n_units, grid, log_in, out));
   SC_HIP(ctx, hipGetLastError());
   if (ctx->time_kernels) {
     SC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     ctx->kt_pending = true;
   }
+  *from_mailbox = mailbox;
   return SC_OK;
 }
 
@@ -326,25 +338,58 @@ void account_kernel_time(sc_ctx* ctx) {
 // 2. collectives
 // =====================================================================================
 
-// Finish a pass: (optionally) sum the split limbs in d_sums across ranks, bring them to the
-// host and recombine into ns residues.
-int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, u64* out) {
-  const size_t count = 2 * (size_t)ns;
-  if (across_ranks && ctx->transport == Transport::kRccl) {
-    ncclResult_t r = g_rccl.AllReduce(ctx->d_sums, ctx->d_sums, count, ncclUint64, ncclSum, ctx->comm,
-                                      ctx->stream);
-    if (r != ncclSuccess)
-      return fail(ctx, SC_ERR_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+// Spin on the mailbox sequence word the kernel writes last (system-scope release store).
+int wait_mailbox(sc_ctx* ctx, u64 seq) {
+  const u64* flag = ctx->h_mailbox + sc::kMailboxSeq;
+  unsigned spins = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+    if ((++spins & 0x3FFF) == 0) {
+      hipError_t q = hipStreamQuery(ctx->stream);
+      if (q != hipSuccess && q != hipErrorNotReady)
+        return fail(ctx, SC_ERR_HIP, "pass kernel failed: %s", hipGetErrorString(q));
+      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (q == hipSuccess && el > 2.0)
+        return fail(ctx, SC_ERR_HIP, "pass kernel finished but its mailbox word never arrived");
+      if (el > 120.0) return fail(ctx, SC_ERR_HIP, "timed out waiting for the pass kernel");
+    }
+    __builtin_ia32_pause();
   }
-  SC_HIP(ctx, hipMemcpyAsync(ctx->h_sums, ctx->d_sums, count * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  return SC_OK;
+}
+
+// Finish a pass: bring the 2*ns split limbs to the host (mailbox, or d_sums after an
+// optional RCCL all-reduce), sum them across ranks if a host transport is installed, and
+// recombine into ns residues.
+int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64* out) {
+  const size_t count = 2 * (size_t)ns;
+  u64* src = nullptr;
+  if (from_mailbox) {
+    SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
+    if (ctx->time_kernels) SC_HIP(ctx, hipEventSynchronize(ctx->ev1));
+    src = ctx->h_mailbox;
+  } else {
+    if (across_ranks && ctx->transport == Transport::kRccl) {
+      ncclResult_t r = g_rccl.AllReduce(ctx->d_sums, ctx->d_sums, count, ncclUint64, ncclSum, ctx->comm,
+                                        ctx->stream);
+      if (r != ncclSuccess)
+        return fail(ctx, SC_ERR_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    }
+    SC_HIP(ctx, hipMemcpyAsync(ctx->h_sums, ctx->d_sums, count * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    src = ctx->h_sums;
+  }
   account_kernel_time(ctx);
   if (across_ranks && ctx->transport == Transport::kHost) {
-    if (ctx->host_allreduce(ctx->host_user, ctx->h_sums, count) != 0)
+    if (src != ctx->h_sums) {
+      memcpy(ctx->h_sums, src, count * sizeof(u64));
+      src = ctx->h_sums;
+    }
+    if (ctx->host_allreduce(ctx->host_user, src, count) != 0)
       return fail(ctx, SC_ERR_RCCL, "host all-reduce callback failed");
   }
   HostField hf(ctx->fp);
-  for (int s = 0; s < ns; ++s) out[s] = hf.recombine(ctx->h_sums[2 * s], ctx->h_sums[2 * s + 1]);
+  for (int s = 0; s < ns; ++s) out[s] = hf.recombine(src[2 * s], src[2 * s + 1]);
   return SC_OK;
 }
 
@@ -530,6 +575,12 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
   SC_CREATE_HIP(hipMalloc(&ctx->d_partials, ctx->partial_rows * 16 * sizeof(u64)));
   SC_CREATE_HIP(hipMalloc(&ctx->d_sums, 64 * sizeof(u64)));
   SC_CREATE_HIP(hipHostMalloc(&ctx->h_sums, 64 * sizeof(u64), hipHostMallocDefault));
+  SC_CREATE_HIP(hipMalloc(&ctx->d_ticket, 64));
+  SC_CREATE_HIP(hipMemset(ctx->d_ticket, 0, 64));
+  SC_CREATE_HIP(hipHostMalloc(&ctx->h_mailbox, 64 * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(ctx->h_mailbox, 0, 64 * sizeof(u64));
+  SC_CREATE_HIP(hipHostGetDevicePointer((void**)&ctx->d_mailbox, ctx->h_mailbox, 0));
+  SC_CREATE_HIP(hipDeviceSynchronize());
   SC_CREATE_HIP(hipEventCreate(&ctx->ev0));
   SC_CREATE_HIP(hipEventCreate(&ctx->ev1));
 #undef SC_CREATE_HIP
@@ -547,6 +598,8 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
   if (ctx->h_sums) (void)hipHostFree(ctx->h_sums);
+  if (ctx->h_mailbox) (void)hipHostFree(ctx->h_mailbox);
+  if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
   if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
   if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -572,6 +625,8 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
     ctx->max_blocks = (int)value;
   } else if (k == "time_kernels") {
     ctx->time_kernels = value ? 1 : 0;
+  } else if (k == "use_mailbox") {
+    ctx->use_mailbox = value ? 1 : 0;
   } else if (k == "nt_load_log") {
     ctx->nt_load_log = (int)value;
   } else if (k == "nt_store_log") {
@@ -589,6 +644,7 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   else if (k == "tail_log") *value = ctx->tail_log;
   else if (k == "max_blocks") *value = ctx->max_blocks;
   else if (k == "time_kernels") *value = ctx->time_kernels;
+  else if (k == "use_mailbox") *value = ctx->use_mailbox;
   else if (k == "nt_load_log") *value = ctx->nt_load_log;
   else if (k == "nt_store_log") *value = ctx->nt_store_log;
   else return fail(ctx, SC_ERR_ARG, "unknown option '%s'", key);
@@ -820,7 +876,7 @@ extern "C" int sc_table_evaluate(sc_ctx* ctx, const sc_table* t, const uint64_t*
   pool_release(ctx, v1);
   SC_HIP(ctx, hipGetLastError());
   u64 res = 0;
-  SC_TRY(collect_sums(ctx, 1, is_sharded(ctx), &res));
+  SC_TRY(collect_sums(ctx, 1, is_sharded(ctx), false, &res));
   *out = res;
   return SC_OK;
 }
@@ -901,8 +957,9 @@ extern "C" int sc_prod2_to_evaluations(sc_ctx* ctx, const sc_table* a, const sc_
 // Round sums of (a, b) as they are (no fold); handles the degenerate 1-entry tables.
 static int round_sums_now(sc_ctx* ctx, const u64* a, const u64* b, int log_len, bool across, u64 e[3]) {
   if (log_len < 1) return fail(ctx, SC_ERR_ARG, "round sums need at least one variable");
-  SC_TRY(launch_pass(ctx, 0, 1, a, b, nullptr, nullptr, 0, 0, log_len));
-  return collect_sums(ctx, 3, across, e);
+  bool mb = false;
+  SC_TRY(launch_pass(ctx, 0, 1, a, b, nullptr, nullptr, 0, 0, log_len, across, &mb));
+  return collect_sums(ctx, 3, across, mb, e);
 }
 
 extern "C" int sc_prod2_round_sums(sc_ctx* ctx, const sc_table* a, const sc_table* b, uint64_t out_e[3]) {
@@ -928,7 +985,7 @@ extern "C" int sc_prod2_sum(sc_ctx* ctx, const sc_table* a, const sc_table* b, u
                                                     (const u64*)prod, hf.one(), ctx->d_sums));
     pool_release(ctx, prod);
     SC_HIP(ctx, hipGetLastError());
-    return collect_sums(ctx, 1, is_sharded(ctx), out_c1);
+    return collect_sums(ctx, 1, is_sharded(ctx), false, out_c1);
   }
   u64 e[3];
   SC_TRY(round_sums_now(ctx, a->d, b->d, log2_of(a->len), is_sharded(ctx), e));
@@ -946,8 +1003,9 @@ extern "C" int sc_prod2_fold_and_sums(sc_ctx* ctx, const sc_table* a, const sc_t
   sc_table *ta = nullptr, *tb = nullptr;
   SC_TRY(new_table(ctx, a->len / 2, &ta));
   int rc = new_table(ctx, a->len / 2, &tb);
-  if (rc == SC_OK) rc = launch_pass(ctx, 1, 1, a->d, b->d, ta->d, tb->d, r[0], 0, nv);
-  if (rc == SC_OK) rc = collect_sums(ctx, 3, is_sharded(ctx), out_e);
+  bool mb = false;
+  if (rc == SC_OK) rc = launch_pass(ctx, 1, 1, a->d, b->d, ta->d, tb->d, r[0], 0, nv, is_sharded(ctx), &mb);
+  if (rc == SC_OK) rc = collect_sums(ctx, 3, is_sharded(ctx), mb, out_e);
   if (rc != SC_OK) {
     sc_table_free(ctx, ta);
     sc_table_free(ctx, tb);
@@ -1044,8 +1102,9 @@ int prover_pass(sc_prover* pr, size_t j) {
     }
   }
   u64 r0 = kf > 0 ? pr->pending[0] : 0, r1 = kf > 1 ? pr->pending[1] : 0;
-  int rc = launch_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, r0, r1, pr->cur_log);
-  if (rc == SC_OK) rc = collect_sums(ctx, ks == 1 ? 3 : 9, pr->sharded, pr->S);
+  bool mb = false;
+  int rc = launch_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, r0, r1, pr->cur_log, pr->sharded, &mb);
+  if (rc == SC_OK) rc = collect_sums(ctx, ks == 1 ? 3 : 9, pr->sharded, mb, pr->S);
   if (rc != SC_OK) {
     pool_release(ctx, na);
     pool_release(ctx, nb);
