@@ -1,10 +1,12 @@
 // gfx950 device kernels of the sumcheck prover hot path.
 //
 // All kernels stream evaluation tables of 64-bit field words; they are bound by HBM
-// bandwidth, not by VALU (DESIGN.md "Kernels").  Wavefront = 64 lanes; every thread owns a
-// contiguous run of table entries so that both halves of a fold pair (LE order: entries
-// 2b and 2b+1, matrix-multiplication/src/lib.rs:114-121 of the reference) sit in the same
-// lane and every global access is a 16-byte dwordx4.
+// bandwidth, not by MFMA/VALU (DESIGN.md "Kernels").  Wavefront = 64 lanes.  Every global
+// access is "lane i <-> 16-byte piece base+i" (dwordx4, 1 KiB contiguous per wave
+// instruction); where the arithmetic needs a lane to own a longer run of consecutive
+// entries (both halves of every LE fold pair, entries 2b and 2b+1 -
+// matrix-multiplication/src/lib.rs:114-121 of the reference) the wave's tile is transposed
+// through a wave-private LDS region.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -18,32 +20,10 @@ constexpr int kMaxSums = 9;
 
 typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 
-template <int N>
-__device__ __forceinline__ void load_run(const u64* __restrict__ p, u64 (&v)[N]) {
-  static_assert(N >= 2 && (N % 2) == 0, "runs are whole 16-byte pieces");
-#pragma unroll
-  for (int i = 0; i < N / 2; ++i) {
-    ull2 x = __builtin_nontemporal_load(reinterpret_cast<const ull2*>(p) + i);
-    v[2 * i] = x.x;
-    v[2 * i + 1] = x.y;
-  }
-}
-template <int N>
-__device__ __forceinline__ void store_run(u64* __restrict__ p, const u64 (&v)[N]) {
-  static_assert(N >= 2 && (N % 2) == 0, "runs are whole 16-byte pieces");
-#pragma unroll
-  for (int i = 0; i < N / 2; ++i) {
-    ull2 x;
-    x.x = v[2 * i];
-    x.y = v[2 * i + 1];
-    reinterpret_cast<ull2*>(p)[i] = x;
-  }
-}
-
 // Fold KF variables (LE) of a run of IN entries in registers; the first IN >> KF entries
 // of v hold the result.  new[b] = t[2b] + r*(t[2b+1] - t[2b])  (ark-poly fix_variables).
 template <class F, int KF, int IN>
-__device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], u64 r0, u64 r1) {
+__device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], u64 r0, u64 r1, u64 r2 = 0) {
   if constexpr (KF >= 1) {
 #pragma unroll
     for (int b = 0; b < IN / 2; ++b) v[b] = f.add(v[2 * b], f.mul(r0, f.sub(v[2 * b + 1], v[2 * b])));
@@ -51,6 +31,10 @@ __device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], u64 r0, u64 r
   if constexpr (KF >= 2) {
 #pragma unroll
     for (int b = 0; b < IN / 4; ++b) v[b] = f.add(v[2 * b], f.mul(r1, f.sub(v[2 * b + 1], v[2 * b])));
+  }
+  if constexpr (KF >= 3) {
+#pragma unroll
+    for (int b = 0; b < IN / 8; ++b) v[b] = f.add(v[2 * b], f.mul(r2, f.sub(v[2 * b + 1], v[2 * b])));
   }
 }
 
@@ -185,10 +169,10 @@ __device__ __forceinline__ void transpose_to_pieces(ull2* __restrict__ lds, ull2
 //  * larger grids: every block stores its partial residues (sum-major rows), takes a ticket,
 //    and the block that draws the last ticket reduces all partials and publishes - one
 //    launch per pass instead of pass + reduce (+ copy).  Hand-off follows
-//    cdna_hip_programming.md Guideline 16: partials are stored write-through (sc1), the
-//    storing wave drains them, lane 0 releases at agent scope and then adds to the ticket;
-//    the last block acquires at agent scope behind a workgroup barrier and reads with sc1
-//    loads.  The ticket counter only grows (base = value before this launch), so nothing
+//    cdna_hip_programming.md Guideline 16 (form R1): partials are stored write-through
+//    (sc1), the storing wave drains them (s_waitcnt vmcnt(0)), then lane 0 adds to the
+//    ticket; the block whose add returns the last ticket acquires at agent scope behind a
+//    workgroup barrier and reads the partials with sc1 loads.  The ticket counter only grows (base = value before this launch), so nothing
 //    has to be re-zeroed between launches.
 //  * publish target: `mailbox` (pinned host memory the host spins on: 2*NS split limbs, then
 //    the sequence word at index kMailboxSeq) or, for the sharded transports that still have
@@ -232,8 +216,9 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
     __hip_atomic_store(o.partials + (size_t)threadIdx.x * o.n_rows + blockIdx.x, my_res, __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_AGENT);
   if (threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // wave 0 holds every storing lane
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    // wave 0 holds every storing lane: drain its write-through stores, then signal.  No
+    // agent-scope release fence: that is a whole-L2 write-back per block (~2-6 us each and
+    // 2048 of them per launch); sc1 stores + drain is Guideline 16's R1 form.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(o.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t - o.ticket_base == gridDim.x - 1) ? 1 : 0;
@@ -385,23 +370,45 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
 }
 
 // ------------------------------------------------------------------------------------
-// Single-table folds (DenseMultilinearExtension::fix_variables on its own).
+// Single-table kernels (DenseMultilinearExtension::fix_variables / evaluate on their own,
+// and the two GEMV-shaped halves of matrix_multiplication::G::new).
 
-// LE: thread folds a run of 2^(KF+1) entries down to 2 outputs (one 16-byte store).
+// LE fold of KF in {1,2,3} variables in one pass: coalesced 16-byte loads, wave-private LDS
+// transposition (a lane needs 2^(KF+1) consecutive entries), one coalesced 16-byte store
+// per lane.  n_units = number of output pieces (pairs of output entries).
 template <class F, int KF>
 __global__ void __launch_bounds__(kBlock)
-fold_le_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, u64 r0, u64 r1, size_t n_units) {
-  constexpr int IN = 2 << KF;
-  const size_t stride = (size_t)gridDim.x * kBlock;
-  for (size_t u = (size_t)blockIdx.x * kBlock + threadIdx.x; u < n_units; u += stride) {
+fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, u64 r0, u64 r1, u64 r2, size_t n_units,
+            int nt_load) {
+  constexpr int IN = 2 << KF, NP = IN / 2;
+  constexpr int kWaves = kBlock / kWave;
+  __shared__ ull2 lds_t[kWaves * kWave * NP];
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  ull2* const my_lds = lds_t + wave * kWave * NP;
+  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+  ull2* __restrict__ T2p = reinterpret_cast<ull2*>(T2);
+  const size_t n_tiles = (n_units + kWave - 1) / kWave, in_pieces = n_units * NP;
+  for (size_t tile = (size_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (size_t)gridDim.x * kWaves) {
+    ull2 pv[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const size_t q = tile * kWave * NP + (size_t)k * kWave + lane;
+      const ull2 zero = {0, 0};
+      pv[k] = (q < in_pieces) ? (nt_load ? __builtin_nontemporal_load(Tp + q) : Tp[q]) : zero;
+    }
+    transpose_to_runs<NP>(my_lds, pv, lane);
     u64 v[IN];
-    load_run<IN>(T + u * IN, v);
-    fold_run<F, KF, IN>(f, v, r0, r1);
-    u64 o[2] = {v[0], v[1]};
-    store_run<2>(T2 + u * 2, o);
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { v[2 * k] = pv[k].x; v[2 * k + 1] = pv[k].y; }
+    fold_run<F, KF, IN>(f, v, r0, r1, r2);
+    const size_t qo = tile * kWave + lane;
+    if (qo < n_units) {
+      ull2 o = {v[0], v[1]};
+      T2p[qo] = o;
+    }
   }
 }
-// LE, scalar tail: tables so short that a run would not fit (len_out == 1).
+// LE, scalar tail: outputs that do not fill a 16-byte piece (n_out == 1).
 template <class F>
 __global__ void fold_le_small_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, u64 r,
                                      size_t n_out) {
@@ -415,16 +422,150 @@ __global__ void __launch_bounds__(kBlock)
 fold_be_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, u64 r, size_t half) {
   const size_t stride = (size_t)gridDim.x * kBlock;
   if ((half & 1) == 0) {
+    const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+    ull2* __restrict__ T2p = reinterpret_cast<ull2*>(T2);
     for (size_t u = (size_t)blockIdx.x * kBlock + threadIdx.x; u < half / 2; u += stride) {
-      u64 lo[2], hi[2];
-      load_run<2>(T + 2 * u, lo);
-      load_run<2>(T + half + 2 * u, hi);
-      u64 o[2] = {f.add(lo[0], f.mul(r, f.sub(hi[0], lo[0]))), f.add(lo[1], f.mul(r, f.sub(hi[1], lo[1])))};
-      store_run<2>(T2 + 2 * u, o);
+      const ull2 lo = Tp[u], hi = Tp[half / 2 + u];
+      ull2 o = {f.add(lo.x, f.mul(r, f.sub(hi.x, lo.x))), f.add(lo.y, f.mul(r, f.sub(hi.y, lo.y)))};
+      T2p[u] = o;
     }
   } else {
     for (size_t b = (size_t)blockIdx.x * kBlock + threadIdx.x; b < half; b += stride)
       T2[b] = f.add(T[b], f.mul(r, f.sub(T[b + half], T[b])));
+  }
+}
+
+// Up to 64 challenges by value (kernel argument).
+struct RVec {
+  u64 v[64];
+};
+
+// out[i] = prod_j ( bit_j(i) ? r[off+j] : 1 - r[off+j] ),  i < 2^nbits   (LE bit order)
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+eq_table_kernel(F f, RVec rv, int off, int nbits, u64* __restrict__ out) {
+  const size_t n = (size_t)1 << nbits;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    u64 w = f.one();
+    for (int j = 0; j < nbits; ++j) {
+      const u64 rj = rv.v[off + j];
+      w = f.mul(w, ((i >> j) & 1) ? rj : f.sub(f.one(), rj));
+    }
+    out[i] = w;
+  }
+}
+
+// Polynomial::evaluate of a 2^n-entry table (n >= 8) in ONE streaming pass:
+//   sum_i t[i] * eq(r, i),  eq factored over the index bits as
+//   bit 0 (inside a 16-byte piece) | bits 1..6 (lane) | ta bits (tile within a segment,
+//   weights eqA) | tb bits (segment, weights eqB).
+// Inner sums are unreduced 160-bit accumulations of t * eqA (two per lane, for bit 0 = 0/1);
+// they are reduced once per chunk of tiles and folded into the outer accumulators with
+// eqB; the bit-0 and lane weights are applied once per thread at the end.  This is the
+// streaming form of vsbw_multilinear_from_evaluations' "eq table, then dot product"
+// (multilinear-extensions/src/lib.rs:6-24) without materialising the 2^n eq table.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chunk_log, u64 w_extra, PassOut out,
+                int nt_load) {
+  constexpr int kWaves = kBlock / kWave;
+  __shared__ u64 eqA[1024];  // ta <= 10
+  __shared__ u64 lds[kWaves];
+  __shared__ int lds_flag;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int tb = n - 7 - ta;
+  // every block builds the tile-in-segment weights itself: 2^ta products of ta factors
+  for (int i = threadIdx.x; i < (1 << ta); i += kBlock) {
+    u64 w = f.one();
+    for (int j = 0; j < ta; ++j) {
+      const u64 rj = rv.v[7 + j];
+      w = f.mul(w, ((i >> j) & 1) ? rj : f.sub(f.one(), rj));
+    }
+    eqA[i] = w;
+  }
+  __syncthreads();
+  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+  const size_t n_tiles = (size_t)1 << (n - 7);
+  const size_t n_chunks = n_tiles >> chunk_log;
+  const int C = 1 << chunk_log;
+  typename F::Acc o0, o1;
+  f.acc_zero(o0);
+  f.acc_zero(o1);
+  for (size_t chunk = (size_t)blockIdx.x * kWaves + wave; chunk < n_chunks; chunk += (size_t)gridDim.x * kWaves) {
+    const size_t tile0 = chunk << chunk_log;
+    const size_t seg = tile0 >> ta;
+    const int in_seg = (int)(tile0 & (((size_t)1 << ta) - 1));
+    typename F::Acc a0, a1;
+    f.acc_zero(a0);
+    f.acc_zero(a1);
+#pragma unroll 8
+    for (int i = 0; i < C; ++i) {
+      const size_t q = (tile0 + i) * kWave + lane;
+      const ull2 pc = nt_load ? __builtin_nontemporal_load(Tp + q) : Tp[q];
+      const u64 w = eqA[in_seg + i];
+      f.acc_mac(a0, pc.x, w);
+      f.acc_mac(a1, pc.y, w);
+    }
+    u64 wB = f.one();  // segment weight, wave-uniform: tb factors per chunk of 2*C products
+    for (int j = 0; j < tb; ++j) {
+      const u64 rj = rv.v[7 + ta + j];
+      wB = f.mul(wB, ((seg >> j) & 1) ? rj : f.sub(f.one(), rj));
+    }
+    f.acc_mac(o0, f.acc_get(a0), wB);
+    f.acc_mac(o1, f.acc_get(a1), wB);
+  }
+  // bit 0, lane and (sharded evaluate) rank weights
+  const u64 r0 = rv.v[0];
+  u64 v = f.add(f.mul(f.sub(f.one(), r0), f.acc_get(o0)), f.mul(r0, f.acc_get(o1)));
+  u64 wl = w_extra;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const u64 rj = rv.v[1 + j];
+    wl = f.mul(wl, ((lane >> j) & 1) ? rj : f.sub(f.one(), rj));
+  }
+  u64 res[1] = {f.mul(v, wl)};
+  block_reduce<F, 1>(f, res, lds);
+  finish_pass<F, 1>(f, out, res[0], &lds_flag);
+}
+
+// "Column dot": out[c] = sum_{i in [i0, i1)} w[i] * t[i*M + c]  for one chunk of rows per
+// blockIdx.y; partial[y][c] holds chunk y (reduced by sum_rows_kernel when there are
+// several).  This is fix_variables of the TOP k index bits (BE order), and the f_A half of
+// G::new: f_A[col] = sum_row eq(r1)[row] * A[row][col] (matrix-multiplication/src/lib.rs:81-83,
+// relabel + fold collapsed into one pass).  Lanes own 16-byte pieces of c: coalesced.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+coldot_kernel(F f, const u64* __restrict__ T, const u64* __restrict__ w, size_t rows, size_t rows_per_chunk,
+              size_t M, u64* __restrict__ partial, int nt_load) {
+  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+  ull2* __restrict__ Pp = reinterpret_cast<ull2*>(partial);
+  const size_t mp = M / 2;  // pieces per row
+  const size_t i0 = (size_t)blockIdx.y * rows_per_chunk;
+  const size_t i1 = (i0 + rows_per_chunk < rows) ? i0 + rows_per_chunk : rows;
+  for (size_t pc = (size_t)blockIdx.x * kBlock + threadIdx.x; pc < mp; pc += (size_t)gridDim.x * kBlock) {
+    typename F::Acc a0, a1;
+    f.acc_zero(a0);
+    f.acc_zero(a1);
+#pragma unroll 4
+    for (size_t i = i0; i < i1; ++i) {
+      const ull2 v = nt_load ? __builtin_nontemporal_load(Tp + i * mp + pc) : Tp[i * mp + pc];
+      const u64 wi = w[i];
+      f.acc_mac(a0, v.x, wi);
+      f.acc_mac(a1, v.y, wi);
+    }
+    ull2 o = {f.acc_get(a0), f.acc_get(a1)};
+    Pp[(size_t)blockIdx.y * mp + pc] = o;
+  }
+}
+// out[c] = sum_y partial[y][c]
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+sum_rows_kernel(F f, const u64* __restrict__ partial, size_t chunks, size_t M, u64* __restrict__ out) {
+  for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < M; c += (size_t)gridDim.x * kBlock) {
+    u64 t = 0;
+    for (size_t y = 0; y < chunks; ++y) t = f.add(t, partial[y * M + c]);
+    out[c] = t;
   }
 }
 

@@ -422,14 +422,65 @@ int gather_table(sc_ctx* ctx, const u64* local, size_t len, u64** out_full) {
 // shared helpers for the table API
 // =====================================================================================
 
+sc::RVec make_rvec(const u64* r, size_t n) {
+  sc::RVec rv;
+  memset(&rv, 0, sizeof(rv));
+  for (size_t i = 0; i < n && i < 64; ++i) rv.v[i] = r[i];
+  return rv;
+}
+
+// eq table over `nbits` index bits: out[i] = prod_j (bit_j(i) ? r[j] : 1 - r[j]).
+int build_eq_table(sc_ctx* ctx, const u64* r, int nbits, u64** out) {
+  if (nbits > 40) return fail(ctx, SC_ERR_ARG, "eq table of 2^%d entries", nbits);
+  u64* t = nullptr;
+  SC_TRY(pool_alloc(ctx, (size_t)1 << nbits, &t));
+  sc::RVec rv = make_rvec(r, (size_t)nbits);
+  int grid = grid_for(ctx, (size_t)1 << nbits);
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::eq_table_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                  rv, 0, nbits, t));
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    pool_release(ctx, t);
+    return fail(ctx, SC_ERR_HIP, "eq_table_kernel: %s", hipGetErrorString(e));
+  }
+  *out = t;
+  return SC_OK;
+}
+
+// out[c] = sum_i w[i] * in[i*M + c], i < rows: one streaming pass (plus a small reduce when
+// the rows are split over blockIdx.y for parallelism).  M must be even.
+int coldot(sc_ctx* ctx, const u64* in, const u64* w, size_t rows, size_t M, u64* out) {
+  const size_t mp = M / 2;
+  size_t chunks = 1;
+  if (mp < ((size_t)1 << 16)) {
+    chunks = (((size_t)1 << 16) + mp - 1) / mp;
+    if (chunks > rows) chunks = rows;
+    if (chunks > 256) chunks = 256;
+  }
+  const size_t rows_per_chunk = (rows + chunks - 1) / chunks;
+  chunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+  u64* partial = out;
+  if (chunks > 1) SC_TRY(pool_alloc(ctx, chunks * M, &partial));
+  size_t gx = (mp + sc::kBlock - 1) / sc::kBlock;
+  if (gx > 1024) gx = 1024;
+  const int nt = (rows * M) >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::coldot_kernel<F>), dim3((unsigned)gx, (unsigned)chunks), dim3(sc::kBlock),
+                                                  0, ctx->stream, f, in, w, rows, rows_per_chunk, M, partial, nt));
+  if (chunks > 1) {
+    int grid = grid_for(ctx, M);
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::sum_rows_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                    (const u64*)partial, chunks, M, out));
+    pool_release(ctx, partial);
+  }
+  SC_HIP(ctx, hipGetLastError());
+  return SC_OK;
+}
+
 // Fold k variables of a device table (LE or BE), producing a pool buffer.  `in` is never
-// written.  Uses two variables per launch where the length allows.
+// written.  LE: up to three variables per pass (read N, write N/8).  BE: one "column dot"
+// pass against the eq table of the k leading variables.
 int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, int order, u64** out,
                size_t* out_len) {
-  const u64* cur = in;
-  u64* owned = nullptr;  // intermediate we own (never `in`)
-  size_t cur_len = len;
-  size_t done = 0;
   if (k == 0) {
     u64* cp = nullptr;
     SC_TRY(pool_alloc(ctx, len, &cp));
@@ -438,23 +489,48 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
     *out_len = len;
     return SC_OK;
   }
+  if (order == SC_ORDER_BE && k >= 2 && (len >> k) >= 2) {
+    // eq index i has variable 0 (r[0]) as its MSB: reverse r for the LE-bit table builder
+    std::vector<u64> rr(r, r + k);
+    std::reverse(rr.begin(), rr.end());
+    u64* eq = nullptr;
+    SC_TRY(build_eq_table(ctx, rr.data(), (int)k, &eq));
+    u64* res = nullptr;
+    int rc = pool_alloc(ctx, len >> k, &res);
+    if (rc == SC_OK) rc = coldot(ctx, in, eq, (size_t)1 << k, len >> k, res);
+    pool_release(ctx, eq);
+    if (rc != SC_OK) {
+      pool_release(ctx, res);
+      return rc;
+    }
+    *out = res;
+    *out_len = len >> k;
+    return SC_OK;
+  }
+  const u64* cur = in;
+  u64* owned = nullptr;  // intermediate we own (never `in`)
+  size_t cur_len = len;
+  size_t done = 0;
   while (done < k) {
     int step;
     u64* nxt = nullptr;
     if (order == SC_ORDER_LE) {
-      step = (k - done >= 2 && cur_len >= 8) ? 2 : 1;
+      step = (int)std::min<size_t>(3, k - done);
+      while (step > 1 && (cur_len >> step) < 2) --step;
       size_t nlen = cur_len >> step;
       SC_TRY(pool_alloc(ctx, nlen, &nxt));
-      u64 r0 = r[done], r1 = step == 2 ? r[done + 1] : 0;
+      u64 r0 = r[done], r1 = step >= 2 ? r[done + 1] : 0, r2 = step >= 3 ? r[done + 2] : 0;
       if (nlen >= 2) {
         size_t n_units = nlen / 2;
         int grid = grid_for(ctx, n_units);
-        if (step == 2)
-          SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_le_kernel<F, 2>), dim3(grid), dim3(sc::kBlock), 0,
-                                                          ctx->stream, f, cur, nxt, r0, r1, n_units));
-        else
-          SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_le_kernel<F, 1>), dim3(grid), dim3(sc::kBlock), 0,
-                                                          ctx->stream, f, cur, nxt, r0, r1, n_units));
+        const int nt = cur_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
+#define SC_FOLD(KF)                                                                                                 \
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_kernel<F, KF>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, \
+                                                  f, cur, nxt, r0, r1, r2, n_units, nt))
+        if (step == 3) SC_FOLD(3);
+        else if (step == 2) SC_FOLD(2);
+        else SC_FOLD(1);
+#undef SC_FOLD
       } else {
         SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_le_small_kernel<F>), dim3(1), dim3(64), 0,
                                                         ctx->stream, f, cur, nxt, r0, nlen));
@@ -836,16 +912,45 @@ extern "C" int sc_table_fix_variables(sc_ctx* ctx, const sc_table* in, const uin
   return SC_OK;
 }
 
-// Local evaluate of a device table at a full point (len == 2^n_local); result left in a
-// 1-entry pool buffer.
-static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* r, int order, u64** out1) {
-  int nv = log2_of(len);
-  std::vector<u64> pt(r, r + nv);
-  // BE evaluate == LE evaluate at the reversed point (same multilinear polynomial, the
-  // index bits are just named in the opposite order).
-  if (order == SC_ORDER_BE) std::reverse(pt.begin(), pt.end());
-  size_t out_len = 0;
-  return fold_chain(ctx, d, len, pt.data(), (size_t)nv, SC_ORDER_LE, out1, &out_len);
+// Local evaluate of a device table at a full LE point, times `w_extra`; leaves the split limbs
+// of the result in the mailbox (*from_mailbox) or in ctx->d_sums.
+static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_le, u64 w_extra, bool across,
+                          bool* from_mailbox) {
+  const int nv = log2_of(len);
+  *from_mailbox = false;
+  if (nv < 8) {
+    // tiny table: fold chain, then scale into d_sums
+    u64* v1 = nullptr;
+    size_t out_len = 0;
+    SC_TRY(fold_chain(ctx, d, len, pt_le, (size_t)nv, SC_ORDER_LE, &v1, &out_len));
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::scale_split_kernel<F>), dim3(1), dim3(64), 0, ctx->stream, f,
+                                                    (const u64*)v1, w_extra, ctx->d_sums));
+    pool_release(ctx, v1);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+  }
+  const int ta = std::min(nv - 7, 10);
+  const int chunk_log = std::min(ta, 4);
+  sc::RVec rv = make_rvec(pt_le, (size_t)nv);
+  const size_t n_chunks = ((size_t)1 << (nv - 7)) >> chunk_log;
+  int grid = (int)std::min<size_t>((n_chunks + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
+  if (grid < 1) grid = 1;
+  const bool mailbox = ctx->use_mailbox && !(across && ctx->transport == Transport::kRccl);
+  sc::PassOut out;
+  out.partials = ctx->d_partials;
+  out.n_rows = (int)ctx->partial_rows;
+  out.ticket = ctx->d_ticket;
+  out.ticket_base = ctx->ticket_base;
+  out.sums_dev = ctx->d_sums;
+  out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
+  out.seq = mailbox ? ++ctx->mailbox_seq : 0;
+  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  const int nt = nv >= ctx->nt_load_log ? 1 : 0;
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::evaluate_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, d,
+                                                  nv, rv, ta, chunk_log, w_extra, out, nt));
+  SC_HIP(ctx, hipGetLastError());
+  *from_mailbox = mailbox;
+  return SC_OK;
 }
 
 extern "C" int sc_table_evaluate(sc_ctx* ctx, const sc_table* t, const uint64_t* r, size_t n, int order,
@@ -858,11 +963,15 @@ extern "C" int sc_table_evaluate(sc_ctx* ctx, const sc_table* t, const uint64_t*
     return fail(ctx, SC_ERR_ARG, "evaluate: point has %zu entries, table has %d variables", n, nl + ctx->log_world);
   SC_TRY(set_device(ctx));
   const int g = ctx->log_world;
-  // local part: LE -> low nl variables are r[0..nl); BE -> the shard index is the leading
-  // variables r[0..g), the local ones are r[g..n).
-  const u64* r_local = (order == SC_ORDER_LE) ? r : r + g;
-  u64* v1 = nullptr;
-  SC_TRY(evaluate_local(ctx, t->d, t->len, r_local, order, &v1));
+  // local part: LE -> the low nl variables are r[0..nl); BE -> the shard index is the leading
+  // variables r[0..g), the local ones are r[g..n).  A BE evaluate is the LE evaluate at the
+  // reversed point (same multilinear polynomial, index bits named in the opposite order).
+  std::vector<u64> pt;
+  if (order == SC_ORDER_LE) pt.assign(r, r + nl);
+  else {
+    pt.assign(r + g, r + n);
+    std::reverse(pt.begin(), pt.end());
+  }
   HostField hf(ctx->fp);
   u64 w = hf.one();
   for (int i = 0; i < g; ++i) {
@@ -871,12 +980,10 @@ extern "C" int sc_table_evaluate(sc_ctx* ctx, const sc_table* t, const uint64_t*
     bool bit = (ctx->rank >> i) & 1;
     w = hf.mul(w, bit ? ri : hf.sub(hf.one(), ri));
   }
-  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::scale_split_kernel<F>), dim3(1), dim3(64), 0, ctx->stream, f,
-                                                  (const u64*)v1, w, ctx->d_sums));
-  pool_release(ctx, v1);
-  SC_HIP(ctx, hipGetLastError());
+  bool mb = false;
+  SC_TRY(evaluate_local(ctx, t->d, t->len, pt.data(), w, is_sharded(ctx), &mb));
   u64 res = 0;
-  SC_TRY(collect_sums(ctx, 1, is_sharded(ctx), false, &res));
+  SC_TRY(collect_sums(ctx, 1, is_sharded(ctx), mb, &res));
   *out = res;
   return SC_OK;
 }
@@ -921,18 +1028,37 @@ extern "C" int sc_matmul_g_new(sc_ctx* ctx, const sc_table* A, const sc_table* B
   SC_TRY(check_pair(ctx, A, B, "sc_matmul_g_new"));
   if (ctx->world > 1) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_matmul_g_new on sharded tables");
   if (A->len != ((size_t)1 << (2 * n))) return fail(ctx, SC_ERR_ARG, "sc_matmul_g_new: tables must have 2^(2n) entries");
-  // matrix-multiplication/src/lib.rs:81-86
-  sc_table* At = nullptr;
-  SC_TRY(sc_table_relabel(ctx, A, 0, n, n, &At));
-  int rc = sc_table_fix_variables(ctx, At, point, n, SC_ORDER_LE, a_out);
-  sc_table_free(ctx, At);
-  SC_TRY(rc);
-  rc = sc_table_fix_variables(ctx, B, point + n, n, SC_ORDER_LE, b_out);
-  if (rc != SC_OK) {
-    sc_table_free(ctx, *a_out);
-    *a_out = nullptr;
+  // matrix-multiplication/src/lib.rs:81-86.  relabel(0,n,n) + fix_variables(point[..n]) folds
+  // the ROW index of A with LE weights: f_a[col] = sum_row eq(point[..n])[row] * A[row][col]
+  // - one "column dot" pass over A, no transposed copy.  f_b folds the column index of B.
+  SC_TRY(set_device(ctx));
+  const size_t side = (size_t)1 << n;
+  if (n == 0) {
+    SC_TRY(sc_table_clone(ctx, A, a_out));
+    int rc0 = sc_table_clone(ctx, B, b_out);
+    if (rc0 != SC_OK) { sc_table_free(ctx, *a_out); *a_out = nullptr; }
+    return rc0;
   }
-  return rc;
+  sc_table* ta = nullptr;
+  if (side >= 2) {
+    u64* eq = nullptr;
+    SC_TRY(build_eq_table(ctx, point, (int)n, &eq));
+    int rc1 = new_table(ctx, side, &ta);
+    if (rc1 == SC_OK) rc1 = coldot(ctx, A->d, eq, side, side, ta->d);
+    pool_release(ctx, eq);
+    if (rc1 != SC_OK) {
+      sc_table_free(ctx, ta);
+      return rc1;
+    }
+  }
+  int rc = sc_table_fix_variables(ctx, B, point + n, n, SC_ORDER_LE, b_out);
+  if (rc != SC_OK) {
+    sc_table_free(ctx, ta);
+    return rc;
+  }
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  *a_out = ta;
+  return SC_OK;
 }
 
 extern "C" int sc_prod2_to_evaluations(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_table** out) {

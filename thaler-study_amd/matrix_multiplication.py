@@ -87,6 +87,14 @@ class G(SumCheckPolynomial):
         assert f_a.num_vars() == n and f_b.num_vars() == n                 # :88-89
         return cls(f_a, f_b)
 
+    @classmethod
+    def new_from_tables(cls, ctx, n, A, B, point):
+        """G::new on matrices that already live in HBM (2^(2n)-entry device tables)"""
+        pt = _words(point)
+        ha, hb = voidp(), voidp()
+        ctx.check(ctx.lib.sc_matmul_g_new(ctx.h, A.h, B.h, n, _u64p(pt), ctypes.byref(ha), ctypes.byref(hb)))
+        return cls(DenseMultilinearExtension(ctx, ha), DenseMultilinearExtension(ctx, hb))
+
     def clone(self):
         """#[derive(Clone)] :11 - tables are never written by the prover, so share them"""
         return G(self.f_a, self.f_b)
