@@ -251,18 +251,31 @@ def mle_fix_variables_be(t, r, p):
 # ---- two-variables-per-pass identities (checker for the GPU schedule) ---------------
 
 def g_grid_sums(a, b, p):
-    """S[u][v] = sum over quads of a(u,v)*b(u,v), (u,v) in {0,1,2}^2 on index bits (0,1)."""
+    """S[u][v] = sum over quads of a(u,v)*b(u,v), (u,v) in {0,1,inf}^2 on index bits (0,1);
+    'inf' is the leading coefficient t1 - t0 of the (bi)linear extension."""
     S = [[0] * 3 for _ in range(3)]
     for q in range(len(a) // 4):
         def ext(t):
             g = [[t[4 * q + 2 * h], t[4 * q + 2 * h + 1],
-                  2 * t[4 * q + 2 * h + 1] - t[4 * q + 2 * h]] for h in range(2)]
-            return [[g[0][u], g[1][u], 2 * g[1][u] - g[0][u]] for u in range(3)]
+                  t[4 * q + 2 * h + 1] - t[4 * q + 2 * h]] for h in range(2)]
+            return [[g[0][u], g[1][u], g[1][u] - g[0][u]] for u in range(3)]
         ea, eb = ext(a), ext(b)
         for u in range(3):
             for v in range(3):
                 S[u][v] += ea[u][v] * eb[u][v]
     return [[x % p for x in row] for row in S]
+
+
+def evals_from_inf(h0, h1, hinf, p):
+    """(H(0), H(1), H(inf)) -> (H(0), H(1), H(2)) for a quadratic H"""
+    return [h0 % p, h1 % p, (2 * h1 - h0 + 2 * hinf) % p]
+
+
+def grid_round_evals(S, r, p):
+    """the two rounds one grid serves: round j, and round j+1 once r_j = r is known"""
+    first = evals_from_inf(S[0][0] + S[0][1], S[1][0] + S[1][1], S[2][0] + S[2][1], p)
+    q = [(S[0][v] + r * (S[1][v] - S[0][v] - S[2][v]) + r * r * S[2][v]) % p for v in range(3)]
+    return first, evals_from_inf(q[0], q[1], q[2], p)
 
 
 # ---- other reference call sites that pin the LE index convention --------------------

@@ -404,10 +404,13 @@ void sco_mle_fix_variables_be(const sco_field* f, const u64* t, size_t nv, const
 
 /* ---- sharded partial sums (checker for the multi-GPU path) ------------------------ */
 
-/* 3x3 grid of sums used by the two-variables-per-pass schedule:
+/* 3x3 grid of sums used by the two-variables-per-pass schedule, in the evaluation basis
+ * {0, 1, inf} per variable (inf = leading coefficient, t1 - t0):
  * S[3*u+v] = sum over quads q of a(u,v)*b(u,v), where a(u,v) is the bilinear extension
- * of (t[4q], t[4q+1], t[4q+2], t[4q+3]) in (index bit 0, index bit 1) at u,v in {0,1,2}.
- * Round j:   H(u) = S[u][0] + S[u][1].   Round j+1 after challenge r: Lagrange in u. */
+ * of (t[4q], t[4q+1], t[4q+2], t[4q+3]) in (index bit 0, index bit 1).
+ * Round j:   H(u) = S[u][0] + S[u][1], u in {0,1,inf};  H(2) = 2H(1) - H(0) + 2H(inf).
+ * Round j+1 after challenge r: column v is the quadratic
+ *   S[0][v] + r (S[1][v] - S[0][v] - S[inf][v]) + r^2 S[inf][v]. */
 void sco_g_grid_sums(const sco_field* f, const u64* a, const u64* b, size_t nv, u64 S[9]) {
   for (int i = 0; i < 9; ++i) S[i] = 0;
   size_t quads = (size_t)1 << (nv - 2);
@@ -421,12 +424,12 @@ void sco_g_grid_sums(const sco_field* f, const u64* a, const u64* b, size_t nv, 
         u64 t0 = t[4 * q + 2 * h], t1 = t[4 * q + 2 * h + 1];
         g[0][h] = t0;
         g[1][h] = t1;
-        g[2][h] = f_sub(f, f_add(f, t1, t1), t0);
+        g[2][h] = f_sub(f, t1, t0);
       }
       for (int u = 0; u < 3; ++u) {
         o[u][0] = g[u][0];
         o[u][1] = g[u][1];
-        o[u][2] = f_sub(f, f_add(f, g[u][1], g[u][1]), g[u][0]);
+        o[u][2] = f_sub(f, g[u][1], g[u][0]);
       }
     }
     for (int u = 0; u < 3; ++u)

@@ -19,7 +19,6 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 def model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allgather, pyref):
     """Python model of sc_prover_* in sharded mode (thaler-study_amd/csrc/sumcheck_hip.hip,
     prover_pass / prover_answer), with oracle calls in place of kernels."""
-    from util_field import lagrange_weights
     start, length = D.shard_range(n, rank, world)
     a = o.generate_range(pyref.SEED_A, start, length)
     b = o.generate_range(pyref.SEED_B, start, length)
@@ -53,15 +52,25 @@ def model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allga
                 S = D.recombine_limbs(limbs, p)
             cache = (ks, j, [int(x) for x in S])
         ks, j0, S = cache
+        L = o.lib
+
+        def from_inf(h0, h1, hinf):
+            t = L.sco_add(o.fp, h1, hinf)
+            return [h0, h1, L.sco_sub(o.fp, L.sco_add(o.fp, t, t), h0)]
+
         if ks == 1:
-            e = S
+            e = [int(x) for x in S]   # round_evals already is (H(0), H(1), H(2))
         elif j == j0:
-            e = [(S[3 * u] + S[3 * u + 1]) % p for u in range(3)]
+            e = from_inf(L.sco_add(o.fp, S[0], S[1]), L.sco_add(o.fp, S[3], S[4]), L.sco_add(o.fp, S[6], S[7]))
         else:
-            L = lagrange_weights(o, pending[0])
-            e = [o.lib.sco_add(o.fp, o.lib.sco_add(o.fp, o.lib.sco_mul(o.fp, L[0], S[v]),
-                                                   o.lib.sco_mul(o.fp, L[1], S[3 + v])),
-                               o.lib.sco_mul(o.fp, L[2], S[6 + v])) for v in range(3)]
+            r = pending[0]
+            r2 = L.sco_mul(o.fp, r, r)
+            q = []
+            for v in range(3):
+                s0, s1, si = S[v], S[3 + v], S[6 + v]
+                lin = L.sco_sub(o.fp, L.sco_sub(o.fp, s1, s0), si)
+                q.append(L.sco_add(o.fp, L.sco_add(o.fp, s0, L.sco_mul(o.fp, r, lin)), L.sco_mul(o.fp, r2, si)))
+            e = from_inf(q[0], q[1], q[2])
         evals.append([int(x) for x in e])
     return evals, ch, n_allreduce
 

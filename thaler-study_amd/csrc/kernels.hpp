@@ -20,49 +20,78 @@ constexpr int kMaxSums = 9;
 
 typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 
+// Fold weights of one pass: w[c] = eq((r0,..,r_{KF-1}), c) = prod_j (bit_j(c) ? r_j : 1 - r_j),
+// computed exactly on the host (Montgomery words).  KF = 1 uses w[1] = r0.
+struct FoldW {
+  u64 w[8];
+};
+
 // Fold KF variables (LE) of a run of IN entries in registers; the first IN >> KF entries
-// of v hold the result.  new[b] = t[2b] + r*(t[2b+1] - t[2b])  (ark-poly fix_variables).
+// of v hold the result.
+//  KF = 1: new[b] = t[2b] + r*(t[2b+1] - t[2b])                    (ark-poly fix_variables)
+//  KF >= 2: new[b] = sum_c w[c] * t[2^KF b + c] - the same value (folding is linear), but as
+//  2^KF unreduced multiply-accumulates and ONE Montgomery reduction per output instead of
+//  2^KF - 1 dependent (sub, mul, reduce, add) steps: on gfx950 v_mad_u64_u32 issues as fast as
+//  a 64-bit add or compare (tools/instbench.hip), so trading modular adds for multiplies
+//  cuts the VALU work of a two-variable fold by ~40 %.
 template <class F, int KF, int IN>
-__device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], u64 r0, u64 r1, u64 r2 = 0) {
-  if constexpr (KF >= 1) {
+__device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], const FoldW& fw) {
+  if constexpr (KF == 1) {
+    const u64 r0 = fw.w[1];
 #pragma unroll
     for (int b = 0; b < IN / 2; ++b) v[b] = f.add(v[2 * b], f.mul(r0, f.sub(v[2 * b + 1], v[2 * b])));
-  }
-  if constexpr (KF >= 2) {
+  } else if constexpr (KF >= 2) {
+#if defined(SC_FOLD_CLASSIC)  // A/B switch (tools/kbench.hip): dependent one-variable folds
+    static_assert(KF <= 3, "");
 #pragma unroll
-    for (int b = 0; b < IN / 4; ++b) v[b] = f.add(v[2 * b], f.mul(r1, f.sub(v[2 * b + 1], v[2 * b])));
-  }
-  if constexpr (KF >= 3) {
+    for (int lvl = 0; lvl < KF; ++lvl) {
+      const u64 r = fw.w[4 + lvl];  // kbench passes raw challenges in w[4..6]
 #pragma unroll
-    for (int b = 0; b < IN / 8; ++b) v[b] = f.add(v[2 * b], f.mul(r2, f.sub(v[2 * b + 1], v[2 * b])));
+      for (int b = 0; b < (IN >> (lvl + 1)); ++b) v[b] = f.add(v[2 * b], f.mul(r, f.sub(v[2 * b + 1], v[2 * b])));
+    }
+    return;
+#endif
+    constexpr int G = 1 << KF;
+#pragma unroll
+    for (int b = 0; b < IN / G; ++b) {
+      typename F::Acc acc;
+      f.acc_zero(acc);
+#pragma unroll
+      for (int c = 0; c < G; ++c) f.acc_mac(acc, v[G * b + c], fw.w[c]);
+      v[b] = f.acc_get(acc);
+    }
   }
 }
 
-// Round sums of the product of two tables over one run of OUT = 2^KS entries.
-//  KS = 1: acc[0..2] = H(0), H(1), H(2)   (matrix-multiplication/src/lib.rs:116-120)
-//  KS = 2: acc[3u+v] = a(u,v)*b(u,v), (u,v) in {0,1,2}^2, u on index bit 0, v on bit 1
+// Round sums of the product of two tables over one run of OUT = 2^KS entries, in the
+// evaluation basis {0, 1, inf} per variable ("inf" = leading coefficient = t1 - t0): one
+// subtraction per extension value instead of the double-and-subtract of the point 2.  The
+// host converts exactly: H(2) = 2 H(1) - H(0) + 2 H(inf) for a quadratic H
+// (matrix-multiplication/src/lib.rs:116-120 evaluates at 0, 1, 2 directly).
+//  KS = 1: acc[0..2] = H(0), H(1), H(inf)
+//  KS = 2: acc[3u+v] = sum a(u,v)*b(u,v), (u,v) in {0,1,inf}^2, u on index bit 0, v on bit 1
 template <class F, int KS>
 __device__ __forceinline__ void accumulate_run(const F& f, typename F::Acc* acc, const u64* a,
                                                const u64* b) {
   if constexpr (KS == 1) {
     f.acc_mac(acc[0], a[0], b[0]);
     f.acc_mac(acc[1], a[1], b[1]);
-    f.acc_mac(acc[2], f.sub(f.dbl(a[1]), a[0]), f.sub(f.dbl(b[1]), b[0]));
+    f.acc_mac(acc[2], f.sub(a[1], a[0]), f.sub(b[1], b[0]));
   } else {
     u64 ea[3][3], eb[3][3];
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
       ea[0][h] = a[2 * h];
       ea[1][h] = a[2 * h + 1];
-      ea[2][h] = f.sub(f.dbl(a[2 * h + 1]), a[2 * h]);
+      ea[2][h] = f.sub(a[2 * h + 1], a[2 * h]);
       eb[0][h] = b[2 * h];
       eb[1][h] = b[2 * h + 1];
-      eb[2][h] = f.sub(f.dbl(b[2 * h + 1]), b[2 * h]);
+      eb[2][h] = f.sub(b[2 * h + 1], b[2 * h]);
     }
 #pragma unroll
     for (int u = 0; u < 3; ++u) {
-      ea[u][2] = f.sub(f.dbl(ea[u][1]), ea[u][0]);
-      eb[u][2] = f.sub(f.dbl(eb[u][1]), eb[u][0]);
+      ea[u][2] = f.sub(ea[u][1], ea[u][0]);
+      eb[u][2] = f.sub(eb[u][1], eb[u][0]);
     }
 #pragma unroll
     for (int u = 0; u < 3; ++u)
@@ -259,7 +288,7 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
 template <class F, int KF, int KS>
 __global__ void SC_PASS_BOUNDS
 pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
-            u64* __restrict__ B2, u64 r0, u64 r1, size_t n_units, PassOut out, int nt_load, int nt_store) {
+            u64* __restrict__ B2, FoldW fw, size_t n_units, PassOut out, int nt_load, int nt_store) {
   constexpr int IN = 1 << (KF + KS), OUT = 1 << KS, NS = (KS == 1) ? 3 : 9;
   constexpr int NP = IN / 2, NPO = OUT / 2;  // 16-byte pieces per lane, in and out
   constexpr int kWaves = kBlock / kWave;
@@ -284,16 +313,20 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   // larger than the 256 MiB Infinity Cache are read once: stream them (nontemporal).
   auto load_tile = [&](size_t tile, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
     const size_t q0 = tile * kWave * NP;
+    if (q0 + (size_t)kWave * NP <= in_pieces) {  // full tile (wave-uniform): no per-piece test
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const size_t q = q0 + (size_t)k * kWave + lane;
-      const ull2 zero = {0, 0};
-      if (q < in_pieces) {
+      for (int k = 0; k < NP; ++k) {
+        const size_t q = q0 + (size_t)k * kWave + lane;
         pa[k] = nt_load ? __builtin_nontemporal_load(Ap + q) : Ap[q];
         pb[k] = nt_load ? __builtin_nontemporal_load(Bp + q) : Bp[q];
-      } else {
-        pa[k] = zero;
-        pb[k] = zero;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const size_t q = q0 + (size_t)k * kWave + lane;
+        const ull2 zero = {0, 0};
+        pa[k] = (q < in_pieces) ? Ap[q] : zero;
+        pb[k] = (q < in_pieces) ? Bp[q] : zero;
       }
     }
   };
@@ -306,8 +339,8 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
       a[2 * k] = pa[k].x; a[2 * k + 1] = pa[k].y;
       b[2 * k] = pb[k].x; b[2 * k + 1] = pb[k].y;
     }
-    fold_run<F, KF, IN>(f, a, r0, r1);
-    fold_run<F, KF, IN>(f, b, r0, r1);
+    fold_run<F, KF, IN>(f, a, fw);
+    fold_run<F, KF, IN>(f, b, fw);
     if constexpr (KF > 0) {
       ull2 oa[NPO], ob[NPO];
 #pragma unroll
@@ -378,8 +411,7 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
 // per lane.  n_units = number of output pieces (pairs of output entries).
 template <class F, int KF>
 __global__ void __launch_bounds__(kBlock)
-fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, u64 r0, u64 r1, u64 r2, size_t n_units,
-            int nt_load) {
+fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, FoldW fw, size_t n_units, int nt_load) {
   constexpr int IN = 2 << KF, NP = IN / 2;
   constexpr int kWaves = kBlock / kWave;
   __shared__ ull2 lds_t[kWaves * kWave * NP];
@@ -400,7 +432,7 @@ fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, u64 r0, u64 r1
     u64 v[IN];
 #pragma unroll
     for (int k = 0; k < NP; ++k) { v[2 * k] = pv[k].x; v[2 * k + 1] = pv[k].y; }
-    fold_run<F, KF, IN>(f, v, r0, r1, r2);
+    fold_run<F, KF, IN>(f, v, fw);
     const size_t qo = tile * kWave + lane;
     if (qo < n_units) {
       ull2 o = {v[0], v[1]};

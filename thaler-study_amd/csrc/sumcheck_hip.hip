@@ -273,15 +273,38 @@ int grid_for(const sc_ctx* ctx, size_t n_threads_needed) {
     }                                          \
   } while (0)
 
+// w[c] = prod_j (bit_j(c) ? r[j] : 1 - r[j]), c < 2^kf   (kernels.hpp: FoldW)
+sc::FoldW make_fold_weights(const sc_ctx* ctx, const u64* r, int kf) {
+  HostField hf(ctx->fp);
+  sc::FoldW fw;
+  for (int c = 0; c < 8; ++c) fw.w[c] = 0;
+  fw.w[0] = hf.one();
+  for (int j = 0; j < kf; ++j) {
+    const int half = 1 << j;
+    for (int c = half - 1; c >= 0; --c) {
+      const u64 base = fw.w[c];
+      fw.w[c + half] = hf.mul(base, r[j]);
+      fw.w[c] = hf.mul(base, hf.sub(hf.one(), r[j]));
+    }
+  }
+  return fw;
+}
+
+// (H(0), H(1), H(inf)) -> H(2) = 2 H(1) - H(0) + 2 H(inf)   (H quadratic, inf = leading coefficient)
+u64 eval2_from_inf(const HostField& hf, u64 e0, u64 e1, u64 einf) {
+  u64 t = hf.add(e1, einf);
+  return hf.sub(hf.add(t, t), e0);
+}
+
 template <class F>
 void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const u64* B, u64* A2,
-                   u64* B2, u64 r0, u64 r1, size_t n_units, int grid, int log_in, const sc::PassOut& out) {
+                   u64* B2, const sc::FoldW& fw, size_t n_units, int grid, int log_in, const sc::PassOut& out) {
   dim3 g(grid), b(sc::kBlock);
   hipStream_t s = ctx->stream;
   const int nt_ld = log_in >= ctx->nt_load_log ? 1 : 0;
   const int nt_st = (log_in - kf) >= ctx->nt_store_log ? 1 : 0;
 #define SC_PASS(KF, KS) \
-  hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS>), g, b, 0, s, f, A, B, A2, B2, r0, r1, n_units, out, nt_ld, nt_st)
+  hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS>), g, b, 0, s, f, A, B, A2, B2, fw, n_units, out, nt_ld, nt_st)
   switch (kf * 4 + ks) {
     case 0 * 4 + 1: SC_PASS(0, 1); break;
     case 0 * 4 + 2: SC_PASS(0, 2); break;
@@ -297,10 +320,11 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
 // Launch one pass over tables of 2^log_in entries.  The 2*NS split limbs end up in the
 // host mailbox (*from_mailbox = true; wait with collect_sums) or in ctx->d_sums when they
 // still have to be all-reduced on the device (RCCL transport).
-int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, u64 r0,
-                u64 r1, int log_in, bool across_ranks, bool* from_mailbox) {
+int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, const u64* r,
+                int log_in, bool across_ranks, bool* from_mailbox) {
   if (kf < 0 || kf > 2 || ks < 1 || ks > 2 || log_in < kf + ks)
     return fail(ctx, SC_ERR_ARG, "launch_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
+  const sc::FoldW fw = make_fold_weights(ctx, r, kf);
   size_t n_units = (size_t)1 << (log_in - kf - ks);
   int grid = grid_for(ctx, n_units);
   const bool mailbox = ctx->use_mailbox && !(across_ranks && ctx->transport == Transport::kRccl);
@@ -314,7 +338,7 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   out.seq = mailbox ? ++ctx->mailbox_seq : 0;
   if (grid > 1) ctx->ticket_base += (unsigned)grid;
   if (ctx->time_kernels) SC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-  SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, r0, r1, n_units, grid, log_in, out));
+  SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, fw, n_units, grid, log_in, out));
   SC_HIP(ctx, hipGetLastError());
   if (ctx->time_kernels) {
     SC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
@@ -519,21 +543,21 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
       while (step > 1 && (cur_len >> step) < 2) --step;
       size_t nlen = cur_len >> step;
       SC_TRY(pool_alloc(ctx, nlen, &nxt));
-      u64 r0 = r[done], r1 = step >= 2 ? r[done + 1] : 0, r2 = step >= 3 ? r[done + 2] : 0;
+      const sc::FoldW fw = make_fold_weights(ctx, r + done, step);
       if (nlen >= 2) {
         size_t n_units = nlen / 2;
         int grid = grid_for(ctx, n_units);
         const int nt = cur_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
 #define SC_FOLD(KF)                                                                                                 \
   SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_kernel<F, KF>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, \
-                                                  f, cur, nxt, r0, r1, r2, n_units, nt))
+                                                  f, cur, nxt, fw, n_units, nt))
         if (step == 3) SC_FOLD(3);
         else if (step == 2) SC_FOLD(2);
         else SC_FOLD(1);
 #undef SC_FOLD
       } else {
         SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_le_small_kernel<F>), dim3(1), dim3(64), 0,
-                                                        ctx->stream, f, cur, nxt, r0, nlen));
+                                                        ctx->stream, f, cur, nxt, r[done], nlen));
       }
       cur_len = nlen;
     } else {
@@ -1084,8 +1108,11 @@ extern "C" int sc_prod2_to_evaluations(sc_ctx* ctx, const sc_table* a, const sc_
 static int round_sums_now(sc_ctx* ctx, const u64* a, const u64* b, int log_len, bool across, u64 e[3]) {
   if (log_len < 1) return fail(ctx, SC_ERR_ARG, "round sums need at least one variable");
   bool mb = false;
-  SC_TRY(launch_pass(ctx, 0, 1, a, b, nullptr, nullptr, 0, 0, log_len, across, &mb));
-  return collect_sums(ctx, 3, across, mb, e);
+  SC_TRY(launch_pass(ctx, 0, 1, a, b, nullptr, nullptr, nullptr, log_len, across, &mb));
+  SC_TRY(collect_sums(ctx, 3, across, mb, e));
+  HostField hf(ctx->fp);
+  e[2] = eval2_from_inf(hf, e[0], e[1], e[2]);  // the kernel sums H(0), H(1), H(inf)
+  return SC_OK;
 }
 
 extern "C" int sc_prod2_round_sums(sc_ctx* ctx, const sc_table* a, const sc_table* b, uint64_t out_e[3]) {
@@ -1130,8 +1157,12 @@ extern "C" int sc_prod2_fold_and_sums(sc_ctx* ctx, const sc_table* a, const sc_t
   SC_TRY(new_table(ctx, a->len / 2, &ta));
   int rc = new_table(ctx, a->len / 2, &tb);
   bool mb = false;
-  if (rc == SC_OK) rc = launch_pass(ctx, 1, 1, a->d, b->d, ta->d, tb->d, r[0], 0, nv, is_sharded(ctx), &mb);
+  if (rc == SC_OK) rc = launch_pass(ctx, 1, 1, a->d, b->d, ta->d, tb->d, r, nv, is_sharded(ctx), &mb);
   if (rc == SC_OK) rc = collect_sums(ctx, 3, is_sharded(ctx), mb, out_e);
+  if (rc == SC_OK) {
+    HostField hf(ctx->fp);
+    out_e[2] = eval2_from_inf(hf, out_e[0], out_e[1], out_e[2]);
+  }
   if (rc != SC_OK) {
     sc_table_free(ctx, ta);
     sc_table_free(ctx, tb);
@@ -1227,9 +1258,8 @@ int prover_pass(sc_prover* pr, size_t j) {
       return rc;
     }
   }
-  u64 r0 = kf > 0 ? pr->pending[0] : 0, r1 = kf > 1 ? pr->pending[1] : 0;
   bool mb = false;
-  int rc = launch_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, r0, r1, pr->cur_log, pr->sharded, &mb);
+  int rc = launch_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, pr->pending.data(), pr->cur_log, pr->sharded, &mb);
   if (rc == SC_OK) rc = collect_sums(ctx, ks == 1 ? 3 : 9, pr->sharded, mb, pr->S);
   if (rc != SC_OK) {
     pool_release(ctx, na);
@@ -1251,27 +1281,37 @@ int prover_pass(sc_prover* pr, size_t j) {
   return SC_OK;
 }
 
-// answer round j from the cache (which must cover it)
+// answer round j from the cache (which must cover it).  The cache is in the {0,1,inf} basis.
 void prover_answer(const sc_prover* pr, size_t j, u64 e[3]) {
   HostField hf(pr->ctx->fp);
+  u64 h0, h1, hinf;
   if (pr->cache_ks == 1) {
-    e[0] = pr->S[0];
-    e[1] = pr->S[1];
-    e[2] = pr->S[2];
+    h0 = pr->S[0];
+    h1 = pr->S[1];
+    hinf = pr->S[2];
   } else if (j == pr->cache_round) {
-    for (int u = 0; u < 3; ++u) e[u] = hf.add(pr->S[3 * u], pr->S[3 * u + 1]);
+    // first round of the pass: sum the second variable over {0,1}
+    h0 = hf.add(pr->S[0], pr->S[1]);
+    h1 = hf.add(pr->S[3], pr->S[4]);
+    hinf = hf.add(pr->S[6], pr->S[7]);
   } else {
-    // second round of the pass: interpolate the grid in u at r = pending[0]
-    u64 r = pr->pending[0];
-    u64 one = hf.one(), two = hf.add(one, one);
-    u64 inv2 = hf.inv(two);
-    u64 rm1 = hf.sub(r, one), rm2 = hf.sub(r, two);
-    u64 L0 = hf.mul(hf.mul(rm1, rm2), inv2);       // (r-1)(r-2)/2
-    u64 L1 = hf.neg(hf.mul(r, rm2));               // -r(r-2)
-    u64 L2 = hf.mul(hf.mul(r, rm1), inv2);         // r(r-1)/2
-    for (int v = 0; v < 3; ++v)
-      e[v] = hf.add(hf.add(hf.mul(L0, pr->S[v]), hf.mul(L1, pr->S[3 + v])), hf.mul(L2, pr->S[6 + v]));
+    // second round: for each v the grid column is a quadratic in the first variable,
+    // q_v(X) = S[0][v] + X (S[1][v] - S[0][v] - S[inf][v]) + X^2 S[inf][v]; evaluate at r
+    const u64 r = pr->pending[0];
+    const u64 r2 = hf.mul(r, r);
+    u64 q[3];
+    for (int v = 0; v < 3; ++v) {
+      const u64 s0 = pr->S[v], s1 = pr->S[3 + v], si = pr->S[6 + v];
+      const u64 lin = hf.sub(hf.sub(s1, s0), si);
+      q[v] = hf.add(hf.add(s0, hf.mul(r, lin)), hf.mul(r2, si));
+    }
+    h0 = q[0];
+    h1 = q[1];
+    hinf = q[2];
   }
+  e[0] = h0;
+  e[1] = h1;
+  e[2] = eval2_from_inf(hf, h0, h1, hinf);
 }
 
 bool cache_covers(const sc_prover* pr, size_t j) {

@@ -20,11 +20,12 @@ double run(const char* tag, u64* A, u64* B, u64* A2, u64* B2, u64* P, u64* S, in
   std::vector<float> ts;
   for (int r = 0; r < reps + 2; ++r) {
     CK(hipEventRecord(e0));
+    FoldW fw; for (int c = 0; c < 8; ++c) fw.w[c] = 0x1234567ull * (c + 3);
     PassOut out; out.partials = P; out.n_rows = 4096; out.ticket = (unsigned*)(S + 40); out.ticket_base = g_ticket_base;
     out.sums_dev = S; out.mailbox = nullptr; out.seq = 0;
     if (grid > 1) g_ticket_base += grid;
     hipLaunchKernelGGL((pass_kernel<GoldilocksMont, KF, KS>), dim3(grid), dim3(kBlock), 0, 0, f, A, B, A2, B2,
-                       (u64)0x1234567, (u64)0x7654321, n_units, out, nt_ld, nt_st);
+                       fw, n_units, out, nt_ld, nt_st);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (r >= 2) ts.push_back(ms);
