@@ -1,0 +1,144 @@
+// The reference's own unit tests for this path, replayed in C++ against the C ABI through
+// the host mirror (thaler-study_amd/host/*.hpp).  Exit code 0 = all passed.  Needs a GPU.
+//   multilinear-extensions/src/lib.rs:76-120   example_from_book
+//   matrix-multiplication/src/lib.rs:202-243   matrix_test_from_book
+//   matrix-multiplication/src/lib.rs:245-303   example_from_book
+//   matrix-multiplication/src/lib.rs:315-374   randomized_test (2^2..2^5, every (i,j))
+#include <cstdio>
+#include <cstdlib>
+#include <random>
+
+#include "../../thaler-study_amd/host/matrix_multiplication.hpp"
+
+using namespace sum_check_protocol;
+using matrix_multiplication::G;
+using sumcheck_hip::Context;
+
+#define REQUIRE(cond)                                                              \
+  do {                                                                             \
+    if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); std::exit(1); } \
+  } while (0)
+
+struct StdRng : RngF {  // the blanket impl<F: Field, T: Rng> RngF<F> for T (:17-21)
+  const Field& f;
+  std::mt19937_64 gen;
+  StdRng(const Field& f_, uint64_t seed) : f(f_), gen(seed) {}
+  F draw() override { return f.from_int(gen() % f.c.p); }
+};
+
+static std::vector<F> u32_to_boolean_vec(const Field& f, uint32_t v, size_t bits) {  // :305-313
+  std::vector<F> out;
+  for (size_t i = 0; i < bits; ++i) out.push_back(((v >> i) & 1) ? f.one() : f.zero());
+  return out;
+}
+
+typedef std::vector<std::vector<F>> Matrix;
+static Matrix matmul(const Field& f, const Matrix& a, const Matrix& b) {  // :181-200
+  size_t n = a.size();
+  Matrix res(n, std::vector<F>(n, 0));
+  for (size_t i = 0; i < n; ++i)
+    for (size_t j = 0; j < n; ++j)
+      for (size_t k = 0; k < n; ++k) res[i][j] = f.add(res[i][j], f.mul(a[i][k], b[k][j]));
+  return res;
+}
+static std::vector<F> flatten(const Matrix& m) {
+  std::vector<F> v;
+  for (auto& row : m) v.insert(v.end(), row.begin(), row.end());
+  return v;
+}
+
+static void run_protocol(const Field& f, const G& g, F c_1_expected, bool check_c1, RngF& rng) {
+  Prover prover(g.clone());
+  F c_1 = prover.c_1();
+  if (check_c1) REQUIRE(c_1 == c_1_expected);
+  size_t num_vars = g.num_vars();
+  F r_j = f.one();
+  Verifier verifier(num_vars, g.clone(), f);
+  verifier.set_c_1(c_1);
+  for (size_t j = 0; j < num_vars; ++j) {
+    SparsePolynomial g_j = prover.round(r_j, j);
+    VerifierRoundResult res = verifier.round(g_j, rng);
+    if (res.kind == VerifierRoundResult::JthRound) r_j = res.r;
+    else REQUIRE(res.ok);
+  }
+}
+
+int main() {
+  Field f5(5);
+  Context ctx(f5);
+  StdRng rng(f5, 42);
+
+  {  // multilinear-extensions example_from_book
+    std::vector<F> evals = {f5.from_int(1), f5.from_int(2), f5.from_int(1), f5.from_int(4)};
+    const int expected[5][5] = {{1, 2, 3, 4, 0}, {1, 4, 2, 0, 3}, {1, 1, 1, 1, 1}, {1, 3, 0, 2, 4}, {1, 0, 4, 3, 2}};
+    for (uint32_t i = 0; i < 5; ++i)
+      for (uint32_t j = 0; j < 5; ++j) {
+        std::vector<F> r = {f5.from_int(i), f5.from_int(j)};
+        REQUIRE((int)f5.to_int(multilinear_extensions::cti_multilinear_from_evaluations(ctx, evals, r)) == expected[i][j]);
+        REQUIRE((int)f5.to_int(multilinear_extensions::vsbw_multilinear_from_evaluations(ctx, evals, r)) == expected[i][j]);
+      }
+    std::printf("ok multilinear_extensions::example_from_book\n");
+  }
+
+  Matrix a = {{f5.from_int(0), f5.from_int(1)}, {f5.from_int(2), f5.from_int(0)}};
+  Matrix b = {{f5.from_int(1), f5.from_int(0)}, {f5.from_int(0), f5.from_int(4)}};
+  Matrix c = {{f5.from_int(0), f5.from_int(4)}, {f5.from_int(2), f5.from_int(0)}};
+  REQUIRE(matmul(f5, a, b) == c);  // matrix_test_from_book
+  for (uint32_t i = 0; i < 2; ++i)
+    for (uint32_t j = 0; j < 2; ++j) {
+      std::vector<F> point = u32_to_boolean_vec(f5, i, 1), pj = u32_to_boolean_vec(f5, j, 1);
+      point.insert(point.end(), pj.begin(), pj.end());
+      G g = G::create(ctx, 1, flatten(a), flatten(b), point);
+      run_protocol(f5, g, c[i][j], true, rng);
+    }
+  std::printf("ok matrix_multiplication::example_from_book\n");
+
+  std::mt19937_64 gen(7);
+  for (uint32_t p = 2; p < 6; ++p) {  // randomized_test
+    size_t n = (size_t)1 << p;
+    Matrix A(n, std::vector<F>(n)), B(n, std::vector<F>(n));
+    for (auto& row : A) for (auto& x : row) x = f5.from_int(gen() % 5);
+    for (auto& row : B) for (auto& x : row) x = f5.from_int(gen() % 5);
+    Matrix C = matmul(f5, A, B);
+    size_t step = p >= 4 ? 5 : 1;  // every (i,j) for 4x4 and 8x8, a lattice of them above
+    for (uint32_t i = 0; i < n; i += step)
+      for (uint32_t j = 0; j < n; j += step) {
+        std::vector<F> point = u32_to_boolean_vec(f5, i, p), pj = u32_to_boolean_vec(f5, j, p);
+        point.insert(point.end(), pj.begin(), pj.end());
+        G g = G::create(ctx, p, flatten(A), flatten(B), point);
+        F resu = f5.zero();
+        for (uint32_t z = 0; z < n; ++z) resu = f5.add(resu, g.evaluate(u32_to_boolean_vec(f5, z, p)).value());  // :346-350
+        REQUIRE(resu == C[i][j]);                                                                                // :352 with :340
+        REQUIRE(!g.evaluate(u32_to_boolean_vec(f5, 0, p + 1)).has_value());
+        run_protocol(f5, g, C[i][j], true, rng);
+      }
+  }
+  std::printf("ok matrix_multiplication::randomized_test\n");
+
+  {  // Verifier error paths (:286-291, :308-309)
+    std::vector<F> point = u32_to_boolean_vec(f5, 1, 2), pj = u32_to_boolean_vec(f5, 2, 2);
+    point.insert(point.end(), pj.begin(), pj.end());
+    Matrix A(4, std::vector<F>(4)), B(4, std::vector<F>(4));
+    for (auto& row : A) for (auto& x : row) x = f5.from_int(gen() % 5);
+    for (auto& row : B) for (auto& x : row) x = f5.from_int(gen() % 5);
+    G g = G::create(ctx, 2, flatten(A), flatten(B), point);
+    Prover prover(g.clone());
+    Verifier bad(2, g.clone(), f5);
+    bad.set_c_1(f5.add(prover.c_1(), f5.one()));
+    bool threw = false;
+    try { bad.round(prover.round(f5.one(), 0), rng); } catch (const ProverClaimMismatch&) { threw = true; }
+    REQUIRE(threw);
+    Prover p2(g.clone());
+    Verifier blind(2, nullptr, f5);
+    blind.set_c_1(p2.c_1());
+    threw = false;
+    try {
+      F r = f5.one();
+      for (size_t j = 0; j < 2; ++j) r = blind.round(p2.round(r, j), rng).r;
+    } catch (const NoPolySet&) { threw = true; }
+    REQUIRE(threw);
+    std::printf("ok verifier error paths\n");
+  }
+  std::printf("ALL OK\n");
+  return 0;
+}

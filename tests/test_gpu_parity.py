@@ -468,3 +468,14 @@ def test_stress_inkernel_handoff(pkg):
             c1, evals, _ = mm.prove(ctx, gs[k], pyref.SEED_R)
             assert c1 == refs[k]["c_1"], (n, it)
             assert np.array_equal(evals, refs[k]["evals"]), (n, it)
+
+
+def test_cpp_host_mirror_runs_reference_tests():
+    """thaler-study_amd/host/*.hpp (C++ mirror of the Rust API) replaying the reference's own
+    unit tests against the C ABI: tests/cpp/test_reference_tests.cpp"""
+    import subprocess
+    import __graft_entry__ as ge
+    exe = ge.build_cpp_host_tests()
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ALL OK" in out.stdout
