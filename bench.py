@@ -25,6 +25,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the pool's driver only supports dmabuf IPC (RCCL)
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -58,8 +60,8 @@ def main():
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--num-vars", type=int, default=int(os.environ.get("SC_BENCH_N", "28")))
-    ap.add_argument("--cpu-num-vars", type=int, default=int(os.environ.get("SC_BENCH_CPU_N", "26")),
-                    help="size of the bounded CPU-baseline sample (0 disables)")
+    ap.add_argument("--cpu-num-vars", type=int, default=int(os.environ.get("SC_BENCH_CPU_N", "-1")),
+                    help="size of the bounded CPU-baseline sample (0 disables; -1 = as large as host memory allows, <= 28)")
     ap.add_argument("--vars-per-pass", type=int, default=2)
     args = ap.parse_args()
 
@@ -94,8 +96,34 @@ def main():
 
     ctx = pkg.Context(F, device=local_rank)
     ctx.set_option("vars_per_pass", args.vars_per_pass)
+    transport = "none"
+    if world == 1 and os.environ.get("SC_BENCH_FORCE_RCCL") == "1":
+        # diagnostic: one-rank RCCL communicator, so that the collective code path (all-reduce
+        # per pass, tail gather) runs on a single-GPU box
+        D.attach_rccl(ctx, 0, 1)
+        transport = "rccl(world=1, diagnostic)"
     if world > 1:
-        D.attach_rccl(ctx, rank, world)  # data plane: RCCL all-reduce / all-gather inside the library
+        # data plane: RCCL all-reduce / all-gather issued by the library on its own stream.
+        # If the communicator cannot be created on some rank, every rank falls back to the
+        # host transport (torch.distributed/gloo callbacks) so that the run still completes.
+        ok = 1
+        try:
+            D.attach_rccl(ctx, rank, world)
+        except Exception as e:  # pragma: no cover - depends on the node
+            sys.stderr.write("rank %d: RCCL init failed (%s)\n" % (rank, e))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 1:
+            transport = "rccl"
+        else:
+            if ok:
+                ctx.close()
+                ctx = pkg.Context(F, device=local_rank)
+                ctx.set_option("vars_per_pass", args.vars_per_pass)
+            ar, ag = D.torch_collectives()
+            ctx.comm_init_host(rank, world, ar, ag)
+            transport = "host(gloo)"
     start, length = D.shard_range(n, rank, world)
     nl = length.bit_length() - 1
     a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, nl, start=start)
@@ -161,13 +189,14 @@ def main():
             "config": {
                 "workload": "full sumcheck prover, g=a*b, n=%d, Goldilocks p=2^64-2^32+1, hypercube sharded by top "
                             "index bits over %d GPU(s), %s" % (
-                                n, world, "RCCL all-reduce per pass" if world > 1 else "no collective"),
+                                n, world, ("%s all-reduce per pass" % transport) if world > 1 else "no collective"),
                 "num_vars": n,
                 "field_mul_adds_per_step": muladds,
                 "algorithmic_bytes_per_step": alg_bytes,
                 "vars_per_pass": args.vars_per_pass,
                 "parallelism": "hypercube-shard x%d" % world,
                 "parity_gate": "verifier identities at n=%d ok" % n,
+                "transport": transport,
             },
             "roofline": {
                 "bound": "hbm",
@@ -186,6 +215,17 @@ def main():
         }
 
     # ---- CPU baseline: the reference-shaped port, 1 core, bounded sample (N = 1 only) -------
+    if args.cpu_num_vars < 0:
+        # ~10-30 s of single-core work: n = 28 needs ~14 GiB of host memory, n = 27 ~7 GiB
+        avail_gib = 0.0
+        try:
+            with open("/proc/meminfo") as f:
+                for line in f:
+                    if line.startswith("MemAvailable:"):
+                        avail_gib = int(line.split()[1]) / 2**20
+        except OSError:
+            pass
+        args.cpu_num_vars = 28 if avail_gib > 48 else (27 if avail_gib > 20 else 26)
     if rank == 0 and world == 1 and args.cpu_num_vars > 0:
         from oracle import Oracle
         nc = args.cpu_num_vars

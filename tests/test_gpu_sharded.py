@@ -131,3 +131,54 @@ def test_rccl_world1():
         assert g.evaluate([int(x) for x in ch]) == ref["final_eval"]
         del a, b, g
         ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_virtual_ranks_g_new(world):
+    """sharded G::new (row-block shards of A and B; SURVEY 8e) + proof on the result, against
+    the oracle's G::new + prover on the whole matrices (BASELINE config 5 shape)"""
+    pkg = load_package()
+    p = GOLD
+    o = oracle(p)
+    for n in (3, 5, 7):
+        A = o.generate(11, 2 * n)
+        B = o.generate(12, 2 * n)
+        pt = np.array([o.challenge(pyref.SEED_PT, j) for j in range(2 * n)], dtype=np.uint64)
+        fa, fb = o.g_new(n, A, B, pt)
+        ch = challenges(o, n)
+        ref = o.prove(fa, fb, ch)
+        lb = Loopback(world)
+        results, errors = [None] * world, []
+
+        def body(rank):
+            try:
+                ctx = pkg.Context(pkg.Field(p))
+                ctx.set_option("tail_log", 0)
+                ar, ag = lb.collectives(rank)
+                ctx.comm_init_host(rank, world, ar, ag)
+                start, length = pkg.distributed.shard_range(2 * n, rank, world)
+                nl = length.bit_length() - 1
+                At = pkg.DenseMultilinearExtension.generate(ctx, 11, nl, start=start)
+                Bt = pkg.DenseMultilinearExtension.generate(ctx, 12, nl, start=start)
+                g = pkg.matrix_multiplication.G.new_from_tables(ctx, n, At, Bt, [int(x) for x in pt])
+                assert g.num_vars() == n
+                s0, l0 = pkg.distributed.shard_range(n, rank, world)
+                assert np.array_equal(g.f_a.to_evaluations(), fa[s0:s0 + l0])
+                assert np.array_equal(g.f_b.to_evaluations(), fb[s0:s0 + l0])
+                c1, evals, _ = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+                results[rank] = (c1, evals)
+                ctx.close()
+            except Exception as e:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                errors.append(e)
+                lb.barrier.abort()
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+        for c1, evals in results:
+            assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])

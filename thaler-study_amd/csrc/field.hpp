@@ -77,6 +77,7 @@ struct MontGeneric {
 
   SC_HD u64 modulus() const { return p; }
   SC_HD u64 one() const { return r1; }
+  SC_HD u64 r_squared() const { return r2; }
 
   SC_HD u64 add(u64 a, u64 b) const {
     u64 s = a + b;
@@ -130,6 +131,7 @@ struct GoldilocksMont {
 
   SC_HD u64 modulus() const { return P; }
   SC_HD u64 one() const { return R1; }
+  SC_HD u64 r_squared() const { return R2; }
 
   // a + b >= p  <=>  a + b + (2^64 - p) carries out of 64 bits, and 2^64 - p = EPS:
   // two add-with-carry pairs and a select, no 64-bit compare against p.

@@ -642,4 +642,37 @@ __global__ void scale_split_kernel(F f, const u64* __restrict__ v, u64 w, u64* _
   if (threadIdx.x == 0 && blockIdx.x == 0) write_split(out, 0, f.mul(w, v[0]));
 }
 
+// Vector form of the split-limb exchange (sharded G::new: the f_A half is a sum over the
+// row blocks the ranks own).  limbs[2i], limbs[2i+1] = low / high 32 bits of v[i].
+__global__ void __launch_bounds__(kBlock)
+split_limbs_kernel(const u64* __restrict__ v, size_t n, u64* __restrict__ limbs) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    ull2 o = {v[i] & 0xFFFFFFFFull, v[i] >> 32};
+    reinterpret_cast<ull2*>(limbs)[i] = o;
+  }
+}
+// out[i] = (LO + 2^32 * HI) mod p for the limb sums LO, HI (< 2^63) of word i.  The words are
+// plain integers here (sums of Montgomery words), so the product with 2^32 is an ordinary
+// modular product: mont_mul(mont_mul(x, y), R^2) = x*y mod p.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+recombine_limbs_kernel(F f, const u64* __restrict__ limbs, size_t n, u64* __restrict__ out) {
+  const u64 c32 = f.reduce_word((u64)1 << 32);
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    const ull2 l = reinterpret_cast<const ull2*>(limbs)[i];
+    const u64 lo = f.reduce_word(l.x), hi = f.reduce_word(l.y);
+    out[i] = f.add(lo, f.mul(f.mul(hi, c32), f.r_squared()));
+  }
+}
+
+// After a device-side all-reduce: hand the summed limbs to the host mailbox (one wave).
+__global__ void mailbox_copy_kernel(const u64* __restrict__ sums, int count, u64* __restrict__ mailbox, u64 seq) {
+  if (blockIdx.x == 0 && threadIdx.x < kWave) {
+    if ((int)threadIdx.x < count)
+      __hip_atomic_store(mailbox + threadIdx.x, sums[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0)  // same wave: the release orders it behind the data stores above
+      __hip_atomic_store(mailbox + kMailboxSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 }  // namespace sc

@@ -399,9 +399,21 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
       if (r != ncclSuccess)
         return fail(ctx, SC_ERR_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     }
-    SC_HIP(ctx, hipMemcpyAsync(ctx->h_sums, ctx->d_sums, count * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    src = ctx->h_sums;
+    if (ctx->use_mailbox && count <= (size_t)sc::kMailboxSeq) {
+      // device -> pinned mailbox by a one-wave kernel; the host spins instead of a
+      // memcpy + stream synchronise (about 8 us less per pass)
+      const u64 seq = ++ctx->mailbox_seq;
+      hipLaunchKernelGGL(sc::mailbox_copy_kernel, dim3(1), dim3(sc::kWave), 0, ctx->stream, (const u64*)ctx->d_sums,
+                         (int)count, ctx->d_mailbox, seq);
+      SC_HIP(ctx, hipGetLastError());
+      SC_TRY(wait_mailbox(ctx, seq));
+      if (ctx->time_kernels) SC_HIP(ctx, hipEventSynchronize(ctx->ev1));
+      src = ctx->h_mailbox;
+    } else {
+      SC_HIP(ctx, hipMemcpyAsync(ctx->h_sums, ctx->d_sums, count * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+      SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+      src = ctx->h_sums;
+    }
   }
   account_kernel_time(ctx);
   if (across_ranks && ctx->transport == Transport::kHost) {
@@ -439,6 +451,24 @@ int gather_table(sc_ctx* ctx, const u64* local, size_t len, u64** out_full) {
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   }
   *out_full = full;
+  return SC_OK;
+}
+
+// Sum `count` u64 words of a device buffer across ranks, in place (values are 32-bit limbs).
+int allreduce_device(sc_ctx* ctx, u64* buf, size_t count) {
+  if (ctx->transport == Transport::kRccl) {
+    ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclUint64, ncclSum, ctx->comm, ctx->stream);
+    if (r != ncclSuccess)
+      return fail(ctx, SC_ERR_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
+    return SC_OK;
+  }
+  std::vector<u64> host(count);
+  SC_HIP(ctx, hipMemcpyAsync(host.data(), buf, count * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  if (ctx->host_allreduce(ctx->host_user, host.data(), count) != 0)
+    return fail(ctx, SC_ERR_RCCL, "host all-reduce callback failed");
+  SC_HIP(ctx, hipMemcpyAsync(buf, host.data(), count * sizeof(u64), hipMemcpyHostToDevice, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SC_OK;
 }
 
@@ -1050,7 +1080,54 @@ extern "C" int sc_matmul_g_new(sc_ctx* ctx, const sc_table* A, const sc_table* B
                                sc_table** a_out, sc_table** b_out) {
   if (!ctx || !point || !a_out || !b_out) return SC_ERR_ARG;
   SC_TRY(check_pair(ctx, A, B, "sc_matmul_g_new"));
-  if (ctx->world > 1) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_matmul_g_new on sharded tables");
+  if (is_sharded(ctx)) {
+    // Row-block shards (top log2(world) bits of the row index = rank).  f_b = B~(z, r2) has
+    // z = row, so the local rows ARE this rank's shard of f_b: no exchange.  f_a = A~(r1, z)
+    // has z = column and sums over rows: every rank holds a partial vector over all columns;
+    // they are summed as 32-bit limbs (one all-reduce of 2*2^n words) and each rank keeps
+    // its own column range.  ("G::new".)
+    SC_TRY(set_device(ctx));
+    const int g = ctx->log_world;
+    if (n < (size_t)g) return fail(ctx, SC_ERR_ARG, "sc_matmul_g_new: 2^%zu rows cannot be split over %d ranks", n, ctx->world);
+    const size_t side = (size_t)1 << n, rows_local = side >> g;
+    if (A->len != rows_local * side) return fail(ctx, SC_ERR_ARG, "sc_matmul_g_new: shard must hold 2^(2n)/world entries");
+    if (side < 2) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_matmul_g_new: sharded 1x1 matrices");
+    u64 *eq = nullptr, *partial = nullptr, *limbs = nullptr;
+    sc_table *ta = nullptr, *tb = nullptr;
+    int rc = build_eq_table(ctx, point, (int)n, &eq);
+    if (rc == SC_OK) rc = pool_alloc(ctx, side, &partial);
+    if (rc == SC_OK) rc = pool_alloc(ctx, 2 * side, &limbs);
+    if (rc == SC_OK) rc = coldot(ctx, A->d, eq + (size_t)ctx->rank * rows_local, rows_local, side, partial);
+    if (rc == SC_OK) {
+      hipLaunchKernelGGL(sc::split_limbs_kernel, dim3(grid_for(ctx, side)), dim3(sc::kBlock), 0, ctx->stream,
+                         (const u64*)partial, side, limbs);
+      rc = allreduce_device(ctx, limbs, 2 * side);
+    }
+    if (rc == SC_OK) rc = new_table(ctx, rows_local, &ta);
+    if (rc == SC_OK) {
+      const u64* mine = limbs + 2 * (size_t)ctx->rank * rows_local;
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::recombine_limbs_kernel<F>), dim3(grid_for(ctx, rows_local)),
+                                                      dim3(sc::kBlock), 0, ctx->stream, f, mine, rows_local, ta->d));
+      if (hipGetLastError() != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "recombine_limbs_kernel launch failed");
+    }
+    if (rc == SC_OK) {
+      tb = new (std::nothrow) sc_table;
+      if (!tb) rc = fail(ctx, SC_ERR_OOM, "host allocation failed");
+      else rc = fold_chain(ctx, B->d, B->len, point + n, n, SC_ORDER_LE, &tb->d, &tb->len);
+    }
+    if (rc == SC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "g_new: sync failed");
+    pool_release(ctx, eq);
+    pool_release(ctx, partial);
+    pool_release(ctx, limbs);
+    if (rc != SC_OK) {
+      sc_table_free(ctx, ta);
+      if (tb) { pool_release(ctx, tb->d); delete tb; }
+      return rc;
+    }
+    *a_out = ta;
+    *b_out = tb;
+    return SC_OK;
+  }
   if (A->len != ((size_t)1 << (2 * n))) return fail(ctx, SC_ERR_ARG, "sc_matmul_g_new: tables must have 2^(2n) entries");
   // matrix-multiplication/src/lib.rs:81-86.  relabel(0,n,n) + fix_variables(point[..n]) folds
   // the ROW index of A with LE weights: f_a[col] = sum_row eq(point[..n])[row] * A[row][col]
