@@ -76,8 +76,11 @@ int sc_ctx_create(const sc_field* f, int device, sc_ctx** out);
 int sc_ctx_destroy(sc_ctx* ctx);
 /* message of the last failing call on ctx (ctx == NULL: last failing sc_ctx_create) */
 const char* sc_last_error(const sc_ctx* ctx);
-/* Tunables: "vars_per_pass" (1|2), "tail_log" (shard log-size at which a sharded prover
- * gathers), "max_blocks", "final_mode" (0 second kernel, 1 in-kernel last-block). */
+/* Tunables: "vars_per_pass" (1|2, default 2), "tail_log" (shard log-size at which a sharded
+ * prover gathers, default 12), "max_blocks" (grid cap, default 2048), "use_mailbox" (kernels
+ * publish sums to pinned host memory the host spins on, default 1), "time_kernels" (HIP-event
+ * timing of pass kernels), "nt_load_log" / "nt_store_log" (table log-size from which loads /
+ * stores are nontemporal). */
 int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value);
 int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* value);
 int sc_ctx_synchronize(sc_ctx* ctx);
@@ -179,6 +182,43 @@ int sc_prover_destroy(sc_prover* pr);
 typedef uint64_t (*sc_draw_fn)(void* user, size_t round, const uint64_t evals[3]);
 int sc_prove(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_draw_fn draw, void* user,
              uint64_t seed_r, uint64_t* c1, uint64_t* evals, uint64_t* challenges);
+
+/* ---- gkr_protocol::round_polynomial::W -----------------------
+ *   f(b,c) = add_i(r_i,b,c) (W(b) + W(c)) + mul_i(r_i,b,c) W(b) W(c)
+ * (gkr-protocol/src/round_polynomial.rs:13-44).  add/mul: tables of kb+kc variables indexed
+ * (c << kb) | b; w_b: kb variables, w_c: kc variables (kb = kc = k_{i+1} when the sumcheck
+ * starts; b variables are fixed first).  Not available on sharded contexts yet. */
+
+/* add_i(r_i,.,.) and mul_i(r_i,.,.) of Prover::start_round (gkr-protocol/src/lib.rs:388-416)
+ * straight from the gate list of layer i (2^k_i gates: type 0 = add, 1 = mul; inputs index
+ * layer i+1, which has 2^k_next values); r_i has k_i entries.  Equals the reference's dense
+ * predicate tables after fix_variables(r_i), without building them. */
+int sc_gkr_wiring(sc_ctx* ctx, const int32_t* gate_type, const uint32_t* in0, const uint32_t* in1, size_t k_i,
+                  size_t k_next, const uint64_t* r_i, sc_table** add_out, sc_table** mul_out);
+/* W::to_evaluations (round_polynomial.rs:96-118): out[b*2^kc + c] = f(b,c) (the reference's order) */
+int sc_gkr_w_to_evaluations(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
+                            const sc_table* w_c, sc_table** out);
+/* W::to_univariate (round_polynomial.rs:78-90) as (H(0), H(1), H(2)): the round polynomial has
+ * degree <= 2, so sc_interpolate_quadratic gives the coefficient vector the reference obtains
+ * from its 4-point roots-of-unity interpolation. */
+int sc_gkr_w_round_sums(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
+                        const sc_table* w_c, uint64_t out_e[3]);
+/* W::fix_variables (round_polynomial.rs:59-76): r goes to add/mul and to w_b's variables first,
+ * the rest to w_c. */
+int sc_gkr_w_fix_variables(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
+                           const sc_table* w_c, const uint64_t* r, size_t k, sc_table** add_out,
+                           sc_table** mul_out, sc_table** w_b_out, sc_table** w_c_out);
+/* W::evaluate (round_polynomial.rs:48-57) */
+int sc_gkr_w_evaluate(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
+                      const sc_table* w_c, const uint64_t* point, size_t n, uint64_t* out);
+/* SumCheckProver<F, W<F>> (gkr-protocol/src/lib.rs:418-456 drives it): same contract as
+ * sc_prover_*: create computes c_1, rounds in order, r_prev ignored at j = 0. */
+typedef struct sc_gkr_prover sc_gkr_prover;
+int sc_gkr_prover_create(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
+                         const sc_table* w_c, sc_gkr_prover** out);
+int sc_gkr_prover_c1(const sc_gkr_prover* pr, uint64_t* out);
+int sc_gkr_prover_round(sc_gkr_prover* pr, uint64_t r_prev, size_t j, uint64_t out_e[3]);
+int sc_gkr_prover_destroy(sc_gkr_prover* pr);
 
 #ifdef __cplusplus
 }

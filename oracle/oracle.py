@@ -72,6 +72,14 @@ class Oracle:
         L.sco_prove.restype = ctypes.c_int
         L.sco_prover_run.argtypes = [FP, u64p, u64p, ctypes.c_size_t, u64p, u64p, u64p]
         L.sco_prover_run.restype = None
+        L.sco_w_to_evaluations.argtypes = [FP, u64p, u64p, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p]
+        L.sco_w_round_evals.argtypes = [FP, u64p, u64p, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p]
+        L.sco_w_evaluate.argtypes = [FP, u64p, u64p, u64p, ctypes.c_size_t, u64p, ctypes.c_size_t, u64p]
+        L.sco_w_evaluate.restype = u64
+        L.sco_w_prove.argtypes = [FP, u64p, u64p, u64p, u64p, ctypes.c_size_t, u64p, u64p, u64p, u64p]
+        L.sco_w_prove.restype = ctypes.c_int
+        L.sco_wiring_fixed.argtypes = [FP, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32),
+                                       ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t, ctypes.c_size_t, u64p, u64p, u64p]
         L.sco_vsbw.argtypes = [FP, u64p, u64p, ctypes.c_size_t]
         L.sco_vsbw.restype = u64
         L.sco_cti.argtypes = [FP, u64p, u64p, ctypes.c_size_t]
@@ -211,3 +219,43 @@ class Oracle:
                                 _ptr(ev), _ptr(co), ctypes.byref(fin))
         return {"status": st, "c_1": int(c1.value), "evals": ev, "coeffs": co,
                 "final_eval": int(fin.value)}
+
+    # -- gkr_protocol::round_polynomial::W -------------------------------------------------
+    def w_to_evaluations(self, add, mul, w_b, w_c):
+        out = np.empty(add.size, dtype=np.uint64)
+        self.lib.sco_w_to_evaluations(self.fp, _ptr(add), _ptr(mul), _ptr(w_b), self._nv(w_b), _ptr(w_c),
+                                      self._nv(w_c), _ptr(out))
+        return out
+
+    def w_round_evals(self, add, mul, w_b, w_c):
+        e = np.empty(3, dtype=np.uint64)
+        self.lib.sco_w_round_evals(self.fp, _ptr(add), _ptr(mul), _ptr(w_b), self._nv(w_b), _ptr(w_c),
+                                   self._nv(w_c), _ptr(e))
+        return e
+
+    def w_evaluate(self, add, mul, w_b, w_c, point):
+        pt = np.ascontiguousarray(np.asarray(point, dtype=np.uint64))
+        return int(self.lib.sco_w_evaluate(self.fp, _ptr(add), _ptr(mul), _ptr(w_b), self._nv(w_b), _ptr(w_c),
+                                           self._nv(w_c), _ptr(pt)))
+
+    def w_prove(self, add, mul, w_b, w_c, challenges):
+        k = self._nv(w_b)
+        ch = np.ascontiguousarray(np.asarray(challenges, dtype=np.uint64))
+        assert ch.size == 2 * k
+        c1, fin = u64(0), u64(0)
+        ev = np.empty((2 * k, 3), dtype=np.uint64)
+        st = self.lib.sco_w_prove(self.fp, _ptr(add), _ptr(mul), _ptr(w_b), _ptr(w_c), k, _ptr(ch),
+                                  ctypes.byref(c1), _ptr(ev), ctypes.byref(fin))
+        return {"status": st, "c_1": int(c1.value), "evals": ev, "final_eval": int(fin.value)}
+
+    def wiring_fixed(self, layer, k_next, r_i):
+        """layer: list of ('add'|'mul', in0, in1); returns add_i(r_i,.,.), mul_i(r_i,.,.)"""
+        k_i = (len(layer) - 1).bit_length()
+        gt = (ctypes.c_int * len(layer))(*[0 if t == "add" else 1 for t, _, _ in layer])
+        i0 = (ctypes.c_uint32 * len(layer))(*[a for _, a, _ in layer])
+        i1 = (ctypes.c_uint32 * len(layer))(*[b for _, _, b in layer])
+        r = np.ascontiguousarray(np.asarray(r_i, dtype=np.uint64))
+        add = np.empty(1 << (2 * k_next), dtype=np.uint64)
+        mul = np.empty(1 << (2 * k_next), dtype=np.uint64)
+        self.lib.sco_wiring_fixed(self.fp, gt, i0, i1, k_i, k_next, _ptr(r), _ptr(add), _ptr(mul))
+        return add, mul

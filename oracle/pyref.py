@@ -327,3 +327,119 @@ def matmul(A, B, p):
 def bits_le(v, nbits):
     """u32_to_boolean_vec, matrix-multiplication/src/lib.rs:305-313."""
     return [(v >> i) & 1 for i in range(nbits)]
+
+
+# ---- gkr_protocol::round_polynomial::W and the wiring predicates ----------------------
+# f(b, c) = add(b,c) (W(b) + W(c)) + mul(b,c) W(b) W(c); tables indexed (c << k) | b.
+
+def w_to_evaluations(add, mul, w_b, w_c, p):
+    """gkr-protocol/src/round_polynomial.rs:96-118 - note the push order: b outer, c inner,
+    while the tables are read at idx(c, b, num_vars(w_b)) = (c << kb) | b."""
+    kb = (len(w_b) - 1).bit_length()
+    res = []
+    for b_idx, wb in enumerate(w_b):
+        for c_idx, wc in enumerate(w_c):
+            bc = (c_idx << kb) | b_idx
+            res.append((add[bc] * (wb + wc) + mul[bc] * (wb * wc)) % p)
+    return res
+
+
+def w_fix_variables(add, mul, w_b, w_c, partial, p):
+    """gkr-protocol/src/round_polynomial.rs:59-76"""
+    kb = (len(w_b) - 1).bit_length()
+    b_part = partial[:min(kb, len(partial))]
+    c_part = partial[kb:]
+    return (mle_fix_variables(add, partial, p), mle_fix_variables(mul, partial, p),
+            mle_fix_variables(w_b, b_part, p), mle_fix_variables(w_c, c_part, p))
+
+
+def w_evaluate(add, mul, w_b, w_c, point, p):
+    """gkr-protocol/src/round_polynomial.rs:48-57"""
+    kb = (len(w_b) - 1).bit_length()
+    b, c = point[:kb], point[kb:]
+    wb, wc = mle_evaluate(w_b, b, p), mle_evaluate(w_c, c, p)
+    return (mle_evaluate(add, point, p) * (wb + wc) + mle_evaluate(mul, point, p) * wb * wc) % p
+
+
+def primitive_root_of_unity(order, p):
+    assert (p - 1) % order == 0
+    for g in range(2, p):
+        w = pow(g, (p - 1) // order, p)
+        if all(pow(w, order // q, p) != 1 for q in (2,) if order % q == 0) and pow(w, order, p) == 1:
+            if len({pow(w, i, p) for i in range(order)}) == order:
+                return w
+    raise ValueError("no root of unity")
+
+
+def w_to_univariate_domain(add, mul, w_b, w_c, p):
+    """gkr-protocol/src/round_polynomial.rs:78-90, literally: sum the polynomial with the
+    first variable fixed at each element of the size-4 radix-2 domain, then interpolate
+    (inverse DFT).  Any primitive 4th root gives the same coefficient vector."""
+    w = primitive_root_of_unity(4, p)
+    dom = [pow(w, i, p) for i in range(4)]
+    evals = [sum(w_to_evaluations(*w_fix_variables(add, mul, w_b, w_c, [e], p), p)) % p for e in dom]
+    inv4 = pow(4, p - 2, p)
+    coeffs = [sum(evals[i] * pow(w, (-i * d) % 4, p) for i in range(4)) * inv4 % p for d in range(4)]
+    while coeffs and coeffs[-1] == 0:
+        coeffs.pop()
+    return coeffs
+
+
+def w_round_evals(add, mul, w_b, w_c, p):
+    """(H(0), H(1), H(2)) of the round polynomial by direct substitution"""
+    return [sum(w_to_evaluations(*w_fix_variables(add, mul, w_b, w_c, [x % p], p), p)) % p for x in (0, 1, 2)]
+
+
+def w_transcript(add, mul, w_b, w_c, challenges, p):
+    """Prover::new + rounds on W with the verifier's identities checked"""
+    n = (len(add) - 1).bit_length()
+    c1 = sum(w_to_evaluations(add, mul, w_b, w_c, p)) % p
+    cur = (list(add), list(mul), list(w_b), list(w_c))
+    evals, coeffs = [], []
+    claim = c1
+    for j in range(n):
+        if j:
+            cur = w_fix_variables(*cur, [challenges[j - 1]], p)
+        e = w_round_evals(*cur, p)
+        c = interpolate_quadratic([(0, e[0]), (1 % p, e[1]), (2 % p, e[2])], p)
+        assert (e[0] + e[1]) % p == claim, "round %d" % j
+        claim = poly_eval(c, challenges[j], p)
+        evals.append(e)
+        coeffs.append(c)
+    final = w_evaluate(add, mul, w_b, w_c, challenges, p)
+    assert claim == final
+    return {"c_1": c1, "evals": evals, "coeffs": coeffs, "final_eval": final}
+
+
+def circuit_evaluate(layers, inputs, p):
+    """gkr-protocol/src/circuit.rs:99-124; layers[0] is the output layer; a gate is
+    ('add'|'mul', in0, in1).  Returns the per-layer values, outputs first."""
+    vals = [[x % p for x in inputs]]
+    cur = vals[0]
+    for layer in reversed(layers):
+        cur = [(cur[i0] + cur[i1]) % p if t == "add" else (cur[i0] * cur[i1]) % p for (t, i0, i1) in layer]
+        vals.append(cur)
+    vals.reverse()
+    return vals
+
+
+def wiring_tables(layer, k_next, p):
+    """the dense add_i / mul_i tables of start_round, gkr-protocol/src/lib.rs:388-404:
+    index ((c << k_next) | b) << k_i | a"""
+    k_i = (len(layer) - 1).bit_length()
+    n = 1 << k_next
+    add_t, mul_t = [], []
+    for c in range(n):
+        for b in range(n):
+            for a in range(1 << k_i):
+                t, i0, i1 = layer[a]
+                add_t.append(1 if (t == "add" and i0 == b and i1 == c) else 0)
+                mul_t.append(1 if (t == "mul" and i0 == b and i1 == c) else 0)
+    return add_t, mul_t
+
+
+def wiring_fixed(layer, k_next, r_i, p):
+    """add_i(r_i, ., .), mul_i(r_i, ., .): the tables above with the a-variables fixed at r_i
+    (gkr-protocol/src/lib.rs:406-416)"""
+    add_t, mul_t = wiring_tables(layer, k_next, p)
+    return mle_fix_variables(add_t, r_i, p), mle_fix_variables(mul_t, r_i, p)

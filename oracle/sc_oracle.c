@@ -437,3 +437,143 @@ void sco_g_grid_sums(const sco_field* f, const u64* a, const u64* b, size_t nv, 
         S[3 * u + v] = f_add(f, S[3 * u + v], f_mul(f, av[u][v], bv[u][v]));
   }
 }
+
+/* ---- gkr_protocol::round_polynomial::W ----------------
+ * f(b,c) = add(b,c) (W(b) + W(c)) + mul(b,c) W(b) W(c); add/mul have 2k variables and are
+ * indexed (c << k) | b; w_b, w_c have k variables.  kb = current number of variables of
+ * w_b, kc of w_c (they shrink as the sumcheck fixes variables, b first). */
+
+/* W::to_evaluations, gkr-protocol/src/round_polynomial.rs:96-118 (push order b outer, c inner) */
+void sco_w_to_evaluations(const sco_field* f, const u64* add, const u64* mul, const u64* w_b,
+                          size_t kb, const u64* w_c, size_t kc, u64* out) {
+  size_t nb = (size_t)1 << kb, nc = (size_t)1 << kc, o = 0;
+  for (size_t b = 0; b < nb; ++b)
+    for (size_t c = 0; c < nc; ++c) {
+      size_t bc = (c << kb) | b;
+      u64 s = f_add(f, w_b[b], w_c[c]), pr = f_mul(f, w_b[b], w_c[c]);
+      out[o++] = f_add(f, f_mul(f, add[bc], s), f_mul(f, mul[bc], pr));
+    }
+}
+
+/* W::fix_variables for ONE variable, gkr-protocol/src/round_polynomial.rs:59-76: the point goes
+ * to add/mul and to w_b while it still has variables, else to w_c.  Outputs are malloc'ed. */
+static void w_fix_one(const sco_field* f, u64** add, u64** mul, u64** w_b, size_t* kb, u64** w_c,
+                      size_t* kc, u64 r) {
+  size_t nv = *kb + *kc;
+  u64* na = (u64*)malloc((((size_t)1) << (nv - 1)) * sizeof(u64));
+  u64* nm = (u64*)malloc((((size_t)1) << (nv - 1)) * sizeof(u64));
+  sco_mle_fix_variables(f, *add, nv, &r, 1, na);
+  sco_mle_fix_variables(f, *mul, nv, &r, 1, nm);
+  free(*add);
+  free(*mul);
+  *add = na;
+  *mul = nm;
+  if (*kb > 0) {
+    u64* nw = (u64*)malloc((((size_t)1) << (*kb - 1)) * sizeof(u64));
+    sco_mle_fix_variables(f, *w_b, *kb, &r, 1, nw);
+    free(*w_b);
+    *w_b = nw;
+    *kb -= 1;
+  } else {
+    u64* nw = (u64*)malloc((((size_t)1) << (*kc - 1)) * sizeof(u64));
+    sco_mle_fix_variables(f, *w_c, *kc, &r, 1, nw);
+    free(*w_c);
+    *w_c = nw;
+    *kc -= 1;
+  }
+}
+
+static u64* dup_words(const u64* src, size_t n) {
+  u64* d = (u64*)malloc(n * sizeof(u64));
+  memcpy(d, src, n * sizeof(u64));
+  return d;
+}
+
+/* H(0), H(1), H(2) of W::to_univariate (gkr-protocol/src/round_polynomial.rs:78-90).  The
+ * reference evaluates on the size-4 roots-of-unity domain and interpolates; the round
+ * polynomial has degree <= 2, so the integer points 0, 1, 2 determine the same coefficient
+ * vector (oracle/pyref.py w_to_univariate_domain restates the domain form and checks this). */
+void sco_w_round_evals(const sco_field* f, const u64* add, const u64* mul, const u64* w_b, size_t kb,
+                       const u64* w_c, size_t kc, u64 e[3]) {
+  u64 xs[3];
+  xs[0] = 0;
+  xs[1] = f->r_mod_p;
+  xs[2] = f_add(f, f->r_mod_p, f->r_mod_p);
+  size_t nv = kb + kc;
+  for (int i = 0; i < 3; ++i) {
+    u64 *a = dup_words(add, (size_t)1 << nv), *m = dup_words(mul, (size_t)1 << nv);
+    u64 *wb = dup_words(w_b, (size_t)1 << kb), *wc = dup_words(w_c, (size_t)1 << kc);
+    size_t b = kb, c = kc;
+    w_fix_one(f, &a, &m, &wb, &b, &wc, &c, xs[i]);
+    size_t len = (size_t)1 << (b + c);
+    u64* ev = (u64*)malloc(len * sizeof(u64));
+    sco_w_to_evaluations(f, a, m, wb, b, wc, c, ev);
+    u64 s = 0;
+    for (size_t t = 0; t < len; ++t) s = f_add(f, s, ev[t]);
+    e[i] = s;
+    free(ev); free(a); free(m); free(wb); free(wc);
+  }
+}
+
+/* W::evaluate, gkr-protocol/src/round_polynomial.rs:48-57 */
+u64 sco_w_evaluate(const sco_field* f, const u64* add, const u64* mul, const u64* w_b, size_t kb,
+                   const u64* w_c, size_t kc, const u64* point) {
+  u64 ae = sco_mle_evaluate(f, add, kb + kc, point), me = sco_mle_evaluate(f, mul, kb + kc, point);
+  u64 wb = sco_mle_evaluate(f, w_b, kb, point), wc = sco_mle_evaluate(f, w_c, kc, point + kb);
+  return f_add(f, f_mul(f, ae, f_add(f, wb, wc)), f_mul(f, me, f_mul(f, wb, wc)));
+}
+
+/* Prover::new + all rounds on W (sum-check-protocol/src/lib.rs:88-112) with the verifier's
+ * identities; k = variables of w_b = w_c at the start.  evals: 3*(2k) words. */
+int sco_w_prove(const sco_field* f, const u64* add, const u64* mul, const u64* w_b, const u64* w_c,
+                size_t k, const u64* challenges, u64* c1_out, u64* evals, u64* final_eval) {
+  size_t nv = 2 * k, len = (size_t)1 << nv;
+  u64* ev = (u64*)malloc(len * sizeof(u64));
+  sco_w_to_evaluations(f, add, mul, w_b, k, w_c, k, ev);
+  u64 c1 = 0;
+  for (size_t t = 0; t < len; ++t) c1 = f_add(f, c1, ev[t]);
+  free(ev);
+  if (c1_out) *c1_out = c1;
+  u64 *a = dup_words(add, len), *m = dup_words(mul, len);
+  u64 *wb = dup_words(w_b, (size_t)1 << k), *wc = dup_words(w_c, (size_t)1 << k);
+  size_t kb = k, kc = k;
+  int status = 0;
+  u64 claim = c1;
+  for (size_t j = 0; j < nv; ++j) {
+    if (j) w_fix_one(f, &a, &m, &wb, &kb, &wc, &kc, challenges[j - 1]);
+    u64 e[3], c[3];
+    sco_w_round_evals(f, a, m, wb, kb, wc, kc, e);
+    sco_interpolate_quadratic(f, e, c);
+    if (evals) memcpy(evals + 3 * j, e, sizeof(e));
+    if (f_add(f, e[0], e[1]) != claim && !status) status = 1 + (int)j;
+    claim = sco_poly2_eval(f, c, challenges[j]);
+  }
+  u64 fin = sco_w_evaluate(f, add, mul, w_b, k, w_c, k, challenges);
+  if (final_eval) *final_eval = fin;
+  if (claim != fin && !status) status = 1 + (int)nv;
+  free(a); free(m); free(wb); free(wc);
+  return status;
+}
+
+/* add_i(r_i, b, c), mul_i(r_i, b, c) of Prover::start_round, gkr-protocol/src/lib.rs:388-416:
+ * dense 0/1 tables over (a, b, c) with index ((c << k_next) | b) << k_i | a, then
+ * fix_variables(r_i) over the k_i low variables.  gate_type[a]: 0 add, 1 mul. */
+void sco_wiring_fixed(const sco_field* f, const int* gate_type, const uint32_t* in0, const uint32_t* in1,
+                      size_t k_i, size_t k_next, const u64* r_i, u64* add_out, u64* mul_out) {
+  size_t na = (size_t)1 << k_i, nn = (size_t)1 << k_next, len = na * nn * nn;
+  u64* add_t = (u64*)calloc(len, sizeof(u64));
+  u64* mul_t = (u64*)calloc(len, sizeof(u64));
+  for (size_t c = 0; c < nn; ++c)
+    for (size_t b = 0; b < nn; ++b)
+      for (size_t a = 0; a < na; ++a) {
+        size_t idx = (((c << k_next) | b) << k_i) | a;
+        if (in0[a] == b && in1[a] == c) {
+          if (gate_type[a] == 0) add_t[idx] = f->r_mod_p;
+          else mul_t[idx] = f->r_mod_p;
+        }
+      }
+  sco_mle_fix_variables(f, add_t, k_i + 2 * k_next, r_i, k_i, add_out);
+  sco_mle_fix_variables(f, mul_t, k_i + 2 * k_next, r_i, k_i, mul_out);
+  free(add_t);
+  free(mul_t);
+}

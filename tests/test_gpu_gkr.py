@@ -1,0 +1,155 @@
+"""GKR round polynomial W on the GPU against the oracle restatement of
+gkr-protocol/src/round_polynomial.rs and the reference's circuit known answers."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_package
+from util import GOLD, oracle, pid, pyref
+
+pytestmark = pytest.mark.gpu
+
+BOOK = [[("mul", 0, 1), ("mul", 2, 3)], [("mul", 0, 0), ("mul", 1, 1), ("mul", 1, 2), ("mul", 3, 3)]]
+
+
+def make_circuit(pkg, layers, num_inputs):
+    gp = pkg.gkr_protocol
+    return gp.Circuit([gp.CircuitLayer([gp.Gate(t, [a, b]) for (t, a, b) in layer]) for layer in layers], num_inputs)
+
+
+def random_circuit(rng, ks):
+    """layers[i] has 2^ks[i] gates reading layer i+1 (2^ks[i+1] values); last entry = inputs"""
+    layers = []
+    for i in range(len(ks) - 1):
+        n_next = 1 << ks[i + 1]
+        layers.append([(rng.choice(["add", "mul"]), rng.randrange(n_next), rng.randrange(n_next))
+                       for _ in range(1 << ks[i])])
+    return layers
+
+
+def test_circuit_from_book():
+    """gkr-protocol/src/circuit.rs:259-284"""
+    pkg = load_package()
+    F = pkg.Field(389)
+    c = make_circuit(pkg, BOOK, 4)
+    layers = c.evaluate(F, F.from_ints([3, 2, 3, 1]).tolist())
+    assert [F.to_ints(l) for l in layers] == [[36, 6], [9, 4, 6, 1], [3, 2, 3, 1]]
+    for a in range(4):
+        for b in range(4):
+            for cc in range(4):
+                expected = ((a in (0, 1)) and a == b and a == cc) or (a == 2 and b == 1 and cc == 2) or (a == b == cc == 3)
+                assert c.mul_i(1, a, b, cc) == expected
+    assert c.num_vars_at(0) == 1 and c.num_vars_at(1) == 2 and c.num_vars_at(2) == 2 and c.num_vars_at(3) is None
+
+
+@pytest.mark.parametrize("p", [389, GOLD], ids=pid)
+def test_w_book_circuit_layers(p):
+    """every layer of the book circuit: wiring tables, c_1 = W_i(r_i), all rounds, final evaluation"""
+    pkg = load_package()
+    ctx = pkg.Context(pkg.Field(p))
+    F = ctx.field
+    o = oracle(p)
+    scp, gp = pkg.sum_check_protocol, pkg.gkr_protocol
+    circuit = make_circuit(pkg, BOOK, 4)
+    evaluation = circuit.evaluate(F, F.from_ints([3, 2, 3, 1]).tolist())
+    rng = random.Random(5)
+    for i in (0, 1):
+        k_i, k_next = circuit.num_vars_at(i), circuit.num_vars_at(i + 1)
+        r_i = [F.from_int(rng.randrange(p)) for _ in range(k_i)]
+        w = gp.start_round_w(ctx, circuit, evaluation, i, r_i)
+        oadd, omul = o.wiring_fixed(BOOK[i], k_next, r_i)
+        assert np.array_equal(w.add_i.to_evaluations(), oadd) and np.array_equal(w.mul_i.to_evaluations(), omul)
+        ow = np.array(evaluation[i + 1], dtype=np.uint64)
+        ch = [F.from_int(rng.randrange(p)) for _ in range(2 * k_next)]
+        ref = o.w_prove(oadd, omul, ow, ow, ch)
+        assert ref["status"] == 0
+        # c_1 of the layer sumcheck is W_i~(r_i) (Thaler, GKR)
+        wi = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, k_i, np.array(evaluation[i], dtype=np.uint64))
+        assert ref["c_1"] == wi.evaluate(r_i)
+        # trait methods
+        assert w.num_vars() == 2 * k_next
+        assert np.array_equal(w.to_evaluations(), o.w_to_evaluations(oadd, omul, ow, ow))
+        assert w.hypercube_sum(F) == ref["c_1"]
+        assert w.round_evals() == [int(x) for x in ref["evals"][0]]
+        assert w.evaluate(ch) == ref["final_eval"] and w.evaluate(ch[:-1]) is None
+        # Prover / Verifier loop (the verifier has oracle access here, unlike full GKR)
+        class Scripted(scp.RngF):
+            def __init__(self, vals):
+                self.vals = list(vals)
+
+            def draw(self):
+                return self.vals.pop(0)
+
+        for use_engine in (True, False):
+            g = w.clone()
+            if not use_engine:
+                g.native_prover = lambda: None     # generic fix_variables -> to_univariate path
+            prover = scp.Prover.new(g)
+            assert prover.c_1() == ref["c_1"]
+            verifier = scp.Verifier.new(w.num_vars(), w)
+            verifier.set_c_1(prover.c_1())
+            rr = Scripted(ch)
+            r_j, final = F.one, None
+            for j in range(w.num_vars()):
+                g_j = prover.round(r_j, j)
+                co = o.interpolate(ref["evals"][j])
+                dense = [0, 0, 0]
+                for d, cf in g_j.coeffs:
+                    dense[d] = cf
+                assert dense == [int(x) for x in co], (i, j, use_engine)
+                res = verifier.round(g_j, rr)
+                if res.is_final():
+                    final = res.value
+                else:
+                    r_j = res.value
+            assert final is True
+
+
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+def test_w_random_circuits_vs_oracle(p):
+    pkg = load_package()
+    ctx = pkg.Context(pkg.Field(p))
+    F = ctx.field
+    o = oracle(p)
+    gp = pkg.gkr_protocol
+    rng = random.Random(p % 97)
+    for ks in ([1, 1], [2, 3], [3, 2], [4, 4], [6, 5], [5, 6], [8, 7]):
+        layers = random_circuit(rng, ks)
+        circuit = make_circuit(pkg, layers, 1 << ks[-1])
+        inputs = [F.from_int(rng.randrange(p)) for _ in range(1 << ks[-1])]
+        evaluation = circuit.evaluate(F, inputs)
+        i = 0
+        k_i, k_next = ks[0], ks[1]
+        r_i = [F.from_int(rng.randrange(p)) for _ in range(k_i)]
+        w = gp.start_round_w(ctx, circuit, evaluation, i, r_i)
+        oadd, omul = o.wiring_fixed(layers[0], k_next, r_i)
+        assert np.array_equal(w.add_i.to_evaluations(), oadd) and np.array_equal(w.mul_i.to_evaluations(), omul)
+        ow = np.array(evaluation[1], dtype=np.uint64)
+        ch = [F.from_int(rng.randrange(p)) for _ in range(2 * k_next)]
+        if 2 * k_next <= 12:
+            ref = o.w_prove(oadd, omul, ow, ow, ch)
+            assert ref["status"] == 0
+            eng = w.native_prover()
+            assert eng.c1() == ref["c_1"]
+            for j in range(2 * k_next):
+                assert eng.round_evals(ch[j - 1] if j else F.one, j) == [int(x) for x in ref["evals"][j]], (ks, j)
+            assert w.evaluate(ch) == ref["final_eval"]
+            # fix_variables across the b/c boundary
+            for k in (1, k_next, k_next + 1, 2 * k_next):
+                w2 = w.fix_variables(ch[:k])
+                assert w2.num_vars() == 2 * k_next - k
+                if k < 2 * k_next:
+                    assert w2.evaluate(ch[k:]) == ref["final_eval"]
+        else:
+            # larger: identities only (the oracle is reference-shaped and slow)
+            eng = w.native_prover()
+            wi = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, k_i, np.array(evaluation[0], dtype=np.uint64))
+            assert eng.c1() == wi.evaluate(r_i)
+            claim = eng.c1()
+            for j in range(2 * k_next):
+                e = eng.round_evals(ch[j - 1] if j else F.one, j)
+                assert F.add(e[0], e[1]) == claim
+                c = o.interpolate(np.array(e, dtype=np.uint64))
+                claim = o.poly2_eval(c, ch[j])
+            assert claim == w.evaluate(ch)

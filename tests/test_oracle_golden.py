@@ -183,3 +183,46 @@ def test_prover_rejects_tampering():
     v.set_c_1((pr.c_1 + 1) % p)
     with pytest.raises(ValueError):
         v.round(pr.round(1, 0), 5)
+
+
+def test_kat_gkr_circuit_and_w():
+    """gkr-protocol/src/circuit.rs:259-284 (layer values, mul_1), and the W polynomial of
+    gkr-protocol/src/round_polynomial.rs: C oracle == pyref, c_1 == W_i~(r_i), and the reference's
+    4-point roots-of-unity interpolation (:78-90) gives the coefficients of the direct form"""
+    k = KATS["gkr_circuit_book"]
+    p = k["p"]
+    layers = [[tuple(g) for g in layer] for layer in k["layers"]]
+    vals = pyref.circuit_evaluate(layers, k["inputs"], p)
+    assert vals == k["expected_layers"]
+    _, mul_t = pyref.wiring_tables(layers[1], 2, p)
+    truth = sorted([a, b, c] for a in range(4) for b in range(4) for c in range(4) if mul_t[(((c << 2) | b) << 2) | a])
+    assert truth == k["mul_1_true"]
+    rng = random.Random(9)
+    for q in (p, GOLD):
+        o = Oracle(q)
+        for li in (0, 1):
+            layer = layers[li]
+            k_i = (len(layer) - 1).bit_length()
+            k_next = (len(vals[li + 1]) - 1).bit_length()
+            r_i = [rng.randrange(q) for _ in range(k_i)]
+            add, mul = pyref.wiring_fixed(layer, k_next, r_i, q)
+            oa, om = o.wiring_fixed(layer, k_next, o.to_mont(r_i))
+            assert o.from_mont(oa) == add and o.from_mont(om) == mul
+            w_c = [v % q for v in vals[li + 1]]
+            ch = [rng.randrange(q) for _ in range(2 * k_next)]
+            t = pyref.w_transcript(add, mul, w_c, w_c, ch, q)
+            assert t["c_1"] == pyref.mle_evaluate([v % q for v in vals[li]], r_i, q)
+            ow = o.to_mont(w_c)
+            res = o.w_prove(oa, om, ow, ow, o.to_mont(ch))
+            assert res["status"] == 0 and o.from_mont1(res["c_1"]) == t["c_1"]
+            assert [o.from_mont(r) for r in res["evals"]] == t["evals"]
+            assert o.from_mont1(res["final_eval"]) == t["final_eval"]
+            cur = (add, mul, w_c, w_c)
+            for j in range(2 * k_next):
+                if j:
+                    cur = pyref.w_fix_variables(*cur, [ch[j - 1]], q)
+                dom = pyref.w_to_univariate_domain(*cur, q)
+                mine = list(t["coeffs"][j])
+                while mine and mine[-1] == 0:
+                    mine.pop()
+                assert dom == mine

@@ -70,6 +70,17 @@ SIGNATURES = {
     "sc_prover_round": (ctypes.c_int, [voidp, u64, size_t, u64p]),
     "sc_prover_destroy": (ctypes.c_int, [voidp]),
     "sc_prove": (ctypes.c_int, [voidp, voidp, voidp, DRAW_FN, voidp, u64, u64p, u64p, u64p]),
+    "sc_gkr_wiring": (ctypes.c_int, [voidp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint32),
+                                      ctypes.POINTER(ctypes.c_uint32), size_t, size_t, u64p, ctypes.POINTER(voidp),
+                                      ctypes.POINTER(voidp)]),
+    "sc_gkr_w_to_evaluations": (ctypes.c_int, [voidp, voidp, voidp, voidp, voidp, ctypes.POINTER(voidp)]),
+    "sc_gkr_w_round_sums": (ctypes.c_int, [voidp, voidp, voidp, voidp, voidp, u64p]),
+    "sc_gkr_w_fix_variables": (ctypes.c_int, [voidp, voidp, voidp, voidp, voidp, u64p, size_t] + [ctypes.POINTER(voidp)] * 4),
+    "sc_gkr_w_evaluate": (ctypes.c_int, [voidp, voidp, voidp, voidp, voidp, u64p, size_t, u64p]),
+    "sc_gkr_prover_create": (ctypes.c_int, [voidp, voidp, voidp, voidp, voidp, ctypes.POINTER(voidp)]),
+    "sc_gkr_prover_c1": (ctypes.c_int, [voidp, u64p]),
+    "sc_gkr_prover_round": (ctypes.c_int, [voidp, u64, size_t, u64p]),
+    "sc_gkr_prover_destroy": (ctypes.c_int, [voidp]),
 }
 
 

@@ -642,6 +642,88 @@ __global__ void scale_split_kernel(F f, const u64* __restrict__ v, u64 w, u64* _
   if (threadIdx.x == 0 && blockIdx.x == 0) write_split(out, 0, f.mul(w, v[0]));
 }
 
+// ------------------------------------------------------------------------------------
+// gkr_protocol::round_polynomial::W (gkr-protocol/src/round_polynomial.rs:23-119):
+//   f(b,c) = add(b,c) (W(b) + W(c)) + mul(b,c) W(b) W(c),  add/mul indexed (c << kb) | b.
+// The variable being summed lives in ONE of the two small tables: `V` (w_b while it still
+// has variables, else w_c); the other contributes one value `y` per pair, taken from `Fx`
+// (w_c indexed by the high bits, or the single remaining entry of w_b).  The formula is
+// symmetric in the two small tables, so one kernel serves both phases.
+
+// Round sums H(0), H(1), H(inf) over pairs (2q, 2q+1) of add/mul.  Streams add and mul
+// (coalesced 16-byte pieces), gathers the matching piece of V (index = low bits: also
+// coalesced) and one word of Fx per pair (broadcast within a row).  Wiring tables are mostly
+// zero: pairs whose four add/mul words are all zero are skipped.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+gkr_sums_kernel(F f, const u64* __restrict__ add, const u64* __restrict__ mul, const u64* __restrict__ V, int logV,
+                const u64* __restrict__ Fx, size_t n_pieces, PassOut out) {
+  __shared__ u64 lds[(kBlock / kWave) * 3];
+  __shared__ int lds_flag;
+  const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(add);
+  const ull2* __restrict__ Mp = reinterpret_cast<const ull2*>(mul);
+  const ull2* __restrict__ Vp = reinterpret_cast<const ull2*>(V);
+  const size_t vmask = (((size_t)1 << logV) >> 1) - 1;  // pieces of V minus one
+  typename F::Acc acc[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) f.acc_zero(acc[s]);
+  for (size_t q = (size_t)blockIdx.x * kBlock + threadIdx.x; q < n_pieces; q += (size_t)gridDim.x * kBlock) {
+    const ull2 a = Ap[q], m = Mp[q];
+    if ((a.x | a.y | m.x | m.y) == 0) continue;
+    const ull2 x = Vp[q & vmask];
+    const u64 y = Fx[(2 * q) >> logV];
+    const u64 dx = f.sub(x.y, x.x);
+    f.acc_mac(acc[0], a.x, f.add(x.x, y));
+    f.acc_mac(acc[0], m.x, f.mul(x.x, y));
+    f.acc_mac(acc[1], a.y, f.add(x.y, y));
+    f.acc_mac(acc[1], m.y, f.mul(x.y, y));
+    f.acc_mac(acc[2], f.sub(a.y, a.x), dx);
+    f.acc_mac(acc[2], f.sub(m.y, m.x), f.mul(dx, y));
+  }
+  u64 res[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) res[s] = f.acc_get(acc[s]);
+  block_reduce<F, 3>(f, res, lds);
+  finish_pass<F, 3>(f, out, res[0], &lds_flag);
+}
+
+// W::to_evaluations (round_polynomial.rs:96-118): out[b * 2^kc + c] = f(b, c) - the
+// reference pushes with b outer and c inner while it READS the tables at (c << kb) | b.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+gkr_to_evaluations_kernel(F f, const u64* __restrict__ add, const u64* __restrict__ mul, const u64* __restrict__ w_b,
+                          int kb, const u64* __restrict__ w_c, int kc, u64* __restrict__ out) {
+  const size_t n = (size_t)1 << (kb + kc);
+  for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (size_t)gridDim.x * kBlock) {
+    const size_t b = o >> kc, c = o & (((size_t)1 << kc) - 1);
+    const size_t bc = (c << kb) | b;
+    const u64 wb = w_b[b], wc = w_c[c];
+    out[o] = f.add(f.mul(add[bc], f.add(wb, wc)), f.mul(mul[bc], f.mul(wb, wc)));
+  }
+}
+
+// add_i(r_i, b, c) / mul_i(r_i, b, c) without the dense 2^(k_i + 2 k_next) predicate table of
+// Prover::start_round (gkr-protocol/src/lib.rs:388-416): gate a contributes eq(r_i, a) at
+// (in1[a] << k_next) | in0[a] of the table of its type.  Gates sharing a target are summed
+// with a compare-and-swap loop (there is no modular atomic add).  Outputs start zeroed.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+gkr_wiring_scatter_kernel(F f, const u64* __restrict__ eq, const int* __restrict__ gate_type,
+                          const unsigned* __restrict__ in0, const unsigned* __restrict__ in1, size_t n_gates, int k_next,
+                          u64* __restrict__ add_out, u64* __restrict__ mul_out) {
+  for (size_t a = (size_t)blockIdx.x * kBlock + threadIdx.x; a < n_gates; a += (size_t)gridDim.x * kBlock) {
+    u64* slot = (gate_type[a] == 0 ? add_out : mul_out) + (((size_t)in1[a] << k_next) | in0[a]);
+    const u64 w = eq[a];
+    unsigned long long old = __hip_atomic_load((unsigned long long*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    while (true) {
+      const unsigned long long want = f.add((u64)old, w);
+      if (__hip_atomic_compare_exchange_strong((unsigned long long*)slot, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT))
+        break;
+    }
+  }
+}
+
 // Vector form of the split-limb exchange (sharded G::new: the f_A half is a sum over the
 // row blocks the ranks own).  limbs[2i], limbs[2i+1] = low / high 32 bits of v[i].
 __global__ void __launch_bounds__(kBlock)

@@ -1495,3 +1495,287 @@ extern "C" int sc_prove(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_dr
   sc_prover_destroy(pr);
   return rc;
 }
+
+// =====================================================================================
+// C ABI: gkr_protocol::round_polynomial::W
+// =====================================================================================
+
+namespace {
+
+struct WView {
+  const u64 *add, *mul, *w_b, *w_c;
+  int kb, kc;
+};
+
+int check_w(const sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b, const sc_table* w_c,
+            WView* v) {
+  SC_TRY(check_table(ctx, add, "gkr W"));
+  SC_TRY(check_table(ctx, mul, "gkr W"));
+  SC_TRY(check_table(ctx, w_b, "gkr W"));
+  SC_TRY(check_table(ctx, w_c, "gkr W"));
+  if (is_sharded(ctx)) return fail(ctx, SC_ERR_UNSUPPORTED, "gkr W on a sharded context");
+  v->kb = log2_of(w_b->len);
+  v->kc = log2_of(w_c->len);
+  if (add->len != mul->len || add->len != ((size_t)1 << (v->kb + v->kc)))
+    return fail(ctx, SC_ERR_ARG, "gkr W: add/mul must have num_vars(w_b) + num_vars(w_c) variables");
+  v->add = add->d;
+  v->mul = mul->d;
+  v->w_b = w_b->d;
+  v->w_c = w_c->d;
+  return SC_OK;
+}
+
+// (H(0), H(1), H(2)) of the current round; the summed variable is w_b's while it has any
+int w_round_sums(sc_ctx* ctx, const WView& w, u64 e[3]) {
+  if (w.kb + w.kc < 1) return fail(ctx, SC_ERR_ARG, "gkr W: no variable left");
+  const u64* V = w.kb >= 1 ? w.w_b : w.w_c;
+  const int logV = w.kb >= 1 ? w.kb : w.kc;
+  const u64* Fx = w.kb >= 1 ? w.w_c : w.w_b;
+  const size_t n_pieces = ((size_t)1 << (w.kb + w.kc)) / 2;
+  int grid = grid_for(ctx, n_pieces);
+  sc::PassOut out;
+  out.partials = ctx->d_partials;
+  out.n_rows = (int)ctx->partial_rows;
+  out.ticket = ctx->d_ticket;
+  out.ticket_base = ctx->ticket_base;
+  out.sums_dev = ctx->d_sums;
+  out.mailbox = ctx->use_mailbox ? ctx->d_mailbox : nullptr;
+  out.seq = ctx->use_mailbox ? ++ctx->mailbox_seq : 0;
+  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_sums_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                  w.add, w.mul, V, logV, Fx, n_pieces, out));
+  SC_HIP(ctx, hipGetLastError());
+  SC_TRY(collect_sums(ctx, 3, false, ctx->use_mailbox != 0, e));
+  HostField hf(ctx->fp);
+  e[2] = eval2_from_inf(hf, e[0], e[1], e[2]);
+  return SC_OK;
+}
+
+}  // namespace
+
+extern "C" int sc_gkr_wiring(sc_ctx* ctx, const int32_t* gate_type, const uint32_t* in0, const uint32_t* in1, size_t k_i,
+                             size_t k_next, const uint64_t* r_i, sc_table** add_out, sc_table** mul_out) {
+  if (!ctx || !gate_type || !in0 || !in1 || (k_i && !r_i) || !add_out || !mul_out) return SC_ERR_ARG;
+  if (is_sharded(ctx)) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_gkr_wiring on a sharded context");
+  if (k_i > 30 || k_next > 15) return fail(ctx, SC_ERR_ARG, "sc_gkr_wiring: layer too large");
+  SC_TRY(set_device(ctx));
+  const size_t n_gates = (size_t)1 << k_i, n_next = (size_t)1 << k_next, len = n_next * n_next;
+  for (size_t a = 0; a < n_gates; ++a) {
+    if ((gate_type[a] != 0 && gate_type[a] != 1) || in0[a] >= n_next || in1[a] >= n_next)
+      return fail(ctx, SC_ERR_ARG, "sc_gkr_wiring: gate %zu is malformed", a);
+  }
+  u64* eq = nullptr;
+  u64* gates = nullptr;  // [type | in0 | in1] as 32-bit words
+  sc_table *ta = nullptr, *tm = nullptr;
+  int rc = build_eq_table(ctx, r_i, (int)k_i, &eq);
+  if (rc == SC_OK) rc = pool_alloc(ctx, (3 * n_gates * 4 + 7) / 8 + 1, &gates);
+  if (rc == SC_OK) rc = new_table(ctx, len, &ta);
+  if (rc == SC_OK) rc = new_table(ctx, len, &tm);
+  if (rc == SC_OK) {
+    int* d_type = (int*)gates;
+    unsigned* d_in0 = (unsigned*)gates + n_gates;
+    unsigned* d_in1 = (unsigned*)gates + 2 * n_gates;
+    hipError_t e = hipMemcpyAsync(d_type, gate_type, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in0, in0, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in1, in1, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(ta->d, 0, len * sizeof(u64), ctx->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(tm->d, 0, len * sizeof(u64), ctx->stream);
+    if (e == hipSuccess) {
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_wiring_scatter_kernel<F>), dim3(grid_for(ctx, n_gates)),
+                                                      dim3(sc::kBlock), 0, ctx->stream, f, (const u64*)eq, (const int*)d_type,
+                                                      (const unsigned*)d_in0, (const unsigned*)d_in1, n_gates, (int)k_next,
+                                                      ta->d, tm->d));
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "sc_gkr_wiring: %s", hipGetErrorString(e));
+  }
+  pool_release(ctx, eq);
+  pool_release(ctx, gates);
+  if (rc != SC_OK) {
+    sc_table_free(ctx, ta);
+    sc_table_free(ctx, tm);
+    return rc;
+  }
+  *add_out = ta;
+  *mul_out = tm;
+  return SC_OK;
+}
+
+extern "C" int sc_gkr_w_to_evaluations(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
+                                       const sc_table* w_c, sc_table** out) {
+  if (!ctx || !out) return SC_ERR_ARG;
+  WView w;
+  SC_TRY(check_w(ctx, add, mul, w_b, w_c, &w));
+  SC_TRY(set_device(ctx));
+  sc_table* t = nullptr;
+  SC_TRY(new_table(ctx, add->len, &t));
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_to_evaluations_kernel<F>), dim3(grid_for(ctx, add->len)),
+                                                  dim3(sc::kBlock), 0, ctx->stream, f, w.add, w.mul, w.w_b, w.kb, w.w_c, w.kc,
+                                                  t->d));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    sc_table_free(ctx, t);
+    return fail(ctx, SC_ERR_HIP, "gkr to_evaluations: %s", hipGetErrorString(e));
+  }
+  *out = t;
+  return SC_OK;
+}
+
+extern "C" int sc_gkr_w_round_sums(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
+                                   const sc_table* w_c, uint64_t out_e[3]) {
+  if (!ctx || !out_e) return SC_ERR_ARG;
+  WView w;
+  SC_TRY(check_w(ctx, add, mul, w_b, w_c, &w));
+  SC_TRY(set_device(ctx));
+  return w_round_sums(ctx, w, out_e);
+}
+
+extern "C" int sc_gkr_w_fix_variables(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
+                                      const sc_table* w_c, const uint64_t* r, size_t k, sc_table** add_out,
+                                      sc_table** mul_out, sc_table** w_b_out, sc_table** w_c_out) {
+  if (!ctx || (k && !r) || !add_out || !mul_out || !w_b_out || !w_c_out) return SC_ERR_ARG;
+  WView w;
+  SC_TRY(check_w(ctx, add, mul, w_b, w_c, &w));
+  if (k > (size_t)(w.kb + w.kc)) return fail(ctx, SC_ERR_ARG, "gkr fix_variables: k=%zu > num_vars=%d", k, w.kb + w.kc);
+  const size_t k_b = std::min<size_t>(k, (size_t)w.kb), k_c = k - k_b;   // round_polynomial.rs:60-63
+  sc_table *oa = nullptr, *om = nullptr, *ob = nullptr, *oc = nullptr;
+  int rc = sc_table_fix_variables(ctx, add, r, k, SC_ORDER_LE, &oa);
+  if (rc == SC_OK) rc = sc_table_fix_variables(ctx, mul, r, k, SC_ORDER_LE, &om);
+  if (rc == SC_OK) rc = sc_table_fix_variables(ctx, w_b, r, k_b, SC_ORDER_LE, &ob);
+  if (rc == SC_OK) rc = sc_table_fix_variables(ctx, w_c, r + k_b, k_c, SC_ORDER_LE, &oc);
+  if (rc != SC_OK) {
+    sc_table_free(ctx, oa);
+    sc_table_free(ctx, om);
+    sc_table_free(ctx, ob);
+    sc_table_free(ctx, oc);
+    return rc;
+  }
+  *add_out = oa;
+  *mul_out = om;
+  *w_b_out = ob;
+  *w_c_out = oc;
+  return SC_OK;
+}
+
+extern "C" int sc_gkr_w_evaluate(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
+                                 const sc_table* w_c, const uint64_t* point, size_t n, uint64_t* out) {
+  if (!ctx || !out || (n && !point)) return SC_ERR_ARG;
+  WView w;
+  SC_TRY(check_w(ctx, add, mul, w_b, w_c, &w));
+  if (n != (size_t)(w.kb + w.kc)) return fail(ctx, SC_ERR_ARG, "gkr evaluate: point has %zu entries, W has %d variables", n, w.kb + w.kc);
+  u64 ae = 0, me = 0, wb = 0, wc = 0;
+  SC_TRY(sc_table_evaluate(ctx, add, point, n, SC_ORDER_LE, &ae));
+  SC_TRY(sc_table_evaluate(ctx, mul, point, n, SC_ORDER_LE, &me));
+  SC_TRY(sc_table_evaluate(ctx, w_b, point, (size_t)w.kb, SC_ORDER_LE, &wb));
+  SC_TRY(sc_table_evaluate(ctx, w_c, point + w.kb, (size_t)w.kc, SC_ORDER_LE, &wc));
+  HostField hf(ctx->fp);
+  *out = hf.add(hf.mul(ae, hf.add(wb, wc)), hf.mul(me, hf.mul(wb, wc)));   // round_polynomial.rs:56
+  return SC_OK;
+}
+
+// One variable per pass: fold add, mul and the small table that owns the variable, then sum.
+struct sc_gkr_prover {
+  sc_ctx* ctx = nullptr;
+  const u64 *add = nullptr, *mul = nullptr, *w_b = nullptr, *w_c = nullptr;  // current views
+  u64 *own_add = nullptr, *own_mul = nullptr, *own_wb = nullptr, *own_wc = nullptr;
+  int kb = 0, kc = 0;
+  size_t num_vars = 0, next_round = 0;
+  u64 c1 = 0;
+  u64 first[3];
+};
+
+extern "C" int sc_gkr_prover_create(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
+                                    const sc_table* w_c, sc_gkr_prover** out) {
+  if (!ctx || !out) return SC_ERR_ARG;
+  WView w;
+  SC_TRY(check_w(ctx, add, mul, w_b, w_c, &w));
+  SC_TRY(set_device(ctx));
+  if (w.kb + w.kc < 1) return fail(ctx, SC_ERR_ARG, "sc_gkr_prover_create: W has no variables");
+  sc_gkr_prover* pr = new (std::nothrow) sc_gkr_prover;
+  if (!pr) return fail(ctx, SC_ERR_OOM, "host allocation failed");
+  pr->ctx = ctx;
+  pr->add = w.add;
+  pr->mul = w.mul;
+  pr->w_b = w.w_b;
+  pr->w_c = w.w_c;
+  pr->kb = w.kb;
+  pr->kc = w.kc;
+  pr->num_vars = (size_t)(w.kb + w.kc);
+  int rc = w_round_sums(ctx, w, pr->first);   // c_1 = H(0) + H(1) of round 0
+  if (rc != SC_OK) {
+    delete pr;
+    return rc;
+  }
+  HostField hf(ctx->fp);
+  pr->c1 = hf.add(pr->first[0], pr->first[1]);
+  *out = pr;
+  return SC_OK;
+}
+
+extern "C" int sc_gkr_prover_c1(const sc_gkr_prover* pr, uint64_t* out) {
+  if (!pr || !out) return SC_ERR_ARG;
+  *out = pr->c1;
+  return SC_OK;
+}
+
+extern "C" int sc_gkr_prover_round(sc_gkr_prover* pr, uint64_t r_prev, size_t j, uint64_t out_e[3]) {
+  if (!pr || !out_e) return SC_ERR_ARG;
+  sc_ctx* ctx = pr->ctx;
+  if (j != pr->next_round) return fail(ctx, SC_ERR_STATE, "sc_gkr_prover_round: expected round %zu, got %zu", pr->next_round, j);
+  if (j >= pr->num_vars) return fail(ctx, SC_ERR_STATE, "sc_gkr_prover_round: all %zu rounds done", pr->num_vars);
+  SC_TRY(set_device(ctx));
+  if (j == 0) {
+    memcpy(out_e, pr->first, sizeof(pr->first));
+    pr->next_round = 1;
+    return SC_OK;
+  }
+  if (r_prev >= ctx->fp.p) return fail(ctx, SC_ERR_ARG, "sc_gkr_prover_round: challenge is not reduced");
+  // W::fix_variables(&[r_prev]) (round_polynomial.rs:59-76)
+  const size_t len = (size_t)1 << (pr->kb + pr->kc);
+  u64 *na = nullptr, *nm = nullptr, *nw = nullptr;
+  size_t l1 = 0, l2 = 0, l3 = 0;
+  int rc = fold_chain(ctx, pr->add, len, &r_prev, 1, SC_ORDER_LE, &na, &l1);
+  if (rc == SC_OK) rc = fold_chain(ctx, pr->mul, len, &r_prev, 1, SC_ORDER_LE, &nm, &l2);
+  const bool in_b = pr->kb >= 1;
+  if (rc == SC_OK)
+    rc = fold_chain(ctx, in_b ? pr->w_b : pr->w_c, (size_t)1 << (in_b ? pr->kb : pr->kc), &r_prev, 1, SC_ORDER_LE, &nw, &l3);
+  if (rc != SC_OK) {
+    pool_release(ctx, na);
+    pool_release(ctx, nm);
+    pool_release(ctx, nw);
+    return rc;
+  }
+  pool_release(ctx, pr->own_add);
+  pool_release(ctx, pr->own_mul);
+  pr->own_add = na;
+  pr->own_mul = nm;
+  pr->add = na;
+  pr->mul = nm;
+  if (in_b) {
+    pool_release(ctx, pr->own_wb);
+    pr->own_wb = nw;
+    pr->w_b = nw;
+    pr->kb -= 1;
+  } else {
+    pool_release(ctx, pr->own_wc);
+    pr->own_wc = nw;
+    pr->w_c = nw;
+    pr->kc -= 1;
+  }
+  WView w{pr->add, pr->mul, pr->w_b, pr->w_c, pr->kb, pr->kc};
+  SC_TRY(w_round_sums(ctx, w, out_e));
+  pr->next_round = j + 1;
+  return SC_OK;
+}
+
+extern "C" int sc_gkr_prover_destroy(sc_gkr_prover* pr) {
+  if (!pr) return SC_OK;
+  pool_release(pr->ctx, pr->own_add);
+  pool_release(pr->ctx, pr->own_mul);
+  pool_release(pr->ctx, pr->own_wb);
+  pool_release(pr->ctx, pr->own_wc);
+  delete pr;
+  return SC_OK;
+}
