@@ -220,6 +220,35 @@ int sc_gkr_prover_c1(const sc_gkr_prover* pr, uint64_t* out);
 int sc_gkr_prover_round(sc_gkr_prover* pr, uint64_t r_prev, size_t j, uint64_t out_e[3]);
 int sc_gkr_prover_destroy(sc_gkr_prover* pr);
 
+/* ---- triangle_counting::G -------------------------------------
+ *   g(X,Y,Z) = f(X,Y) f(Y,Z) f(X,Z)   (triangle-counting/src/lib.rs:10-27)
+ * three copies f1, f2, f3 of the adjacency MLE (2*var_len variables each before any fixing,
+ * idx(i,j,nv) = (i << nv) | j, :168-172).  Variable counts of a partially fixed G follow
+ * :53-67.  Not available on sharded contexts yet. */
+
+/* G::to_evaluations (:138-165), order x outer, z inner */
+int sc_tri_to_evaluations(sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const sc_table* f3, size_t var_len,
+                          sc_table** out);
+/* G::to_univariate (:120-132) as (H(0), H(1), H(2)) of the degree-2 round polynomial, for G in
+ * any state, by walking all remaining evaluations like the reference */
+int sc_tri_round_sums(sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const sc_table* f3, size_t var_len,
+                      uint64_t out_e[3]);
+/* G::fix_variables (:89-118) */
+int sc_tri_fix_variables(sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const sc_table* f3, size_t var_len,
+                         const uint64_t* r, size_t k, sc_table** f1_out, sc_table** f2_out, sc_table** f3_out);
+/* G::evaluate (:71-87) */
+int sc_tri_evaluate(sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const sc_table* f3, size_t var_len,
+                    const uint64_t* point, size_t n, uint64_t* out);
+/* Prover<F, G> for G::new_adj_matrix(adj) (:32-51): all 3*var_len rounds.  One n^3 pass
+ * (P = adj-matrix squared) turns the x rounds into a product-of-two-tables sumcheck on (P, f3);
+ * the y rounds run on (f1(r_x,.), Q) with Q[y] = sum_z f2(y,z) f3(r_x,z); the z rounds on
+ * (f2(r_y,.), f3(r_x,.)) scaled by f1(r_x,r_y).  Same contract as sc_prover_*. */
+typedef struct sc_tri_prover sc_tri_prover;
+int sc_tri_prover_create(sc_ctx* ctx, const sc_table* adj, size_t var_len, sc_tri_prover** out);
+int sc_tri_prover_c1(const sc_tri_prover* pr, uint64_t* out);
+int sc_tri_prover_round(sc_tri_prover* pr, uint64_t r_prev, size_t j, uint64_t out_e[3]);
+int sc_tri_prover_destroy(sc_tri_prover* pr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -80,6 +80,13 @@ class Oracle:
         L.sco_w_prove.restype = ctypes.c_int
         L.sco_wiring_fixed.argtypes = [FP, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_uint32),
                                        ctypes.POINTER(ctypes.c_uint32), ctypes.c_size_t, ctypes.c_size_t, u64p, u64p, u64p]
+        sz = ctypes.c_size_t
+        L.sco_tri_to_evaluations.argtypes = [FP, u64p, sz, u64p, sz, u64p, sz, sz, u64p]
+        L.sco_tri_round_evals.argtypes = [FP, u64p, sz, u64p, sz, u64p, sz, sz, u64p]
+        L.sco_tri_evaluate.argtypes = [FP, u64p, sz, u64p]
+        L.sco_tri_evaluate.restype = u64
+        L.sco_tri_prove.argtypes = [FP, u64p, sz, u64p, u64p, u64p, u64p]
+        L.sco_tri_prove.restype = ctypes.c_int
         L.sco_vsbw.argtypes = [FP, u64p, u64p, ctypes.c_size_t]
         L.sco_vsbw.restype = u64
         L.sco_cti.argtypes = [FP, u64p, u64p, ctypes.c_size_t]
@@ -259,3 +266,29 @@ class Oracle:
         mul = np.empty(1 << (2 * k_next), dtype=np.uint64)
         self.lib.sco_wiring_fixed(self.fp, gt, i0, i1, k_i, k_next, _ptr(r), _ptr(add), _ptr(mul))
         return add, mul
+
+    # -- triangle_counting::G -------------------------------------------------------------------
+    def tri_to_evaluations(self, f1, f2, f3, k):
+        n1, n2, n3 = self._nv(f1), self._nv(f2), self._nv(f3)
+        xv, yv, zv = max(n1 - k, 0), max(n2 - k, 0), (n3 if n3 < k else k)
+        out = np.empty(1 << (xv + yv + zv), dtype=np.uint64)
+        self.lib.sco_tri_to_evaluations(self.fp, _ptr(f1), n1, _ptr(f2), n2, _ptr(f3), n3, k, _ptr(out))
+        return out
+
+    def tri_round_evals(self, f1, f2, f3, k):
+        e = np.empty(3, dtype=np.uint64)
+        self.lib.sco_tri_round_evals(self.fp, _ptr(f1), self._nv(f1), _ptr(f2), self._nv(f2), _ptr(f3), self._nv(f3),
+                                     k, _ptr(e))
+        return e
+
+    def tri_evaluate(self, adj, k, point):
+        pt = np.ascontiguousarray(np.asarray(point, dtype=np.uint64))
+        return int(self.lib.sco_tri_evaluate(self.fp, _ptr(adj), k, _ptr(pt)))
+
+    def tri_prove(self, adj, k, challenges):
+        ch = np.ascontiguousarray(np.asarray(challenges, dtype=np.uint64))
+        assert ch.size == 3 * k
+        c1, fin = u64(0), u64(0)
+        ev = np.empty((3 * k, 3), dtype=np.uint64)
+        st = self.lib.sco_tri_prove(self.fp, _ptr(adj), k, _ptr(ch), ctypes.byref(c1), _ptr(ev), ctypes.byref(fin))
+        return {"status": st, "c_1": int(c1.value), "evals": ev, "final_eval": int(fin.value)}

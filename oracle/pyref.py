@@ -443,3 +443,81 @@ def wiring_fixed(layer, k_next, r_i, p):
     (gkr-protocol/src/lib.rs:406-416)"""
     add_t, mul_t = wiring_tables(layer, k_next, p)
     return mle_fix_variables(add_t, r_i, p), mle_fix_variables(mul_t, r_i, p)
+
+
+# ---- triangle_counting::G: g(X,Y,Z) = f(X,Y) f(Y,Z) f(X,Z) --------------------------------
+# three copies of the adjacency MLE; idx(i, j, nv) = (i << nv) | j; variables x, then y, then z.
+
+def tri_var_counts(f1, f2, f3, var_len):
+    """triangle-counting/src/lib.rs:53-67"""
+    nv = lambda t: (len(t) - 1).bit_length()
+    xv = max(nv(f1) - var_len, 0)
+    yv = max(nv(f2) - var_len, 0)
+    zv = nv(f3) if nv(f3) < var_len else var_len
+    return xv, yv, zv
+
+
+def tri_to_evaluations(f1, f2, f3, var_len, p):
+    """triangle-counting/src/lib.rs:138-165"""
+    xv, yv, zv = tri_var_counts(f1, f2, f3, var_len)
+    res = []
+    for x in range(1 << xv):
+        for y in range(1 << yv):
+            for z in range(1 << zv):
+                res.append(f1[(y << xv) | x] * f2[(z << yv) | y] * f3[(z << xv) | x] % p)
+    return res
+
+
+def tri_fix_variables(f1, f2, f3, var_len, pp, p):
+    """triangle-counting/src/lib.rs:89-118"""
+    xv, yv, zv = tri_var_counts(f1, f2, f3, var_len)
+    x_y = pp[:min(xv + yv, len(pp))]
+    y_z = pp[xv:]
+    x_z = pp[:min(xv, len(pp))] + pp[xv + yv:]
+    return mle_fix_variables(f1, x_y, p), mle_fix_variables(f2, y_z, p), mle_fix_variables(f3, x_z, p)
+
+
+def tri_evaluate(f1, f2, f3, var_len, point, p):
+    """triangle-counting/src/lib.rs:71-87"""
+    xv, yv, zv = tri_var_counts(f1, f2, f3, var_len)
+    x_y = point[:xv + yv]
+    y_z = point[xv:]
+    x_z = point[:xv] + point[xv + yv:]
+    return mle_evaluate(f1, x_y, p) * mle_evaluate(f2, y_z, p) * mle_evaluate(f3, x_z, p) % p
+
+
+def tri_round_evals(f1, f2, f3, var_len, p):
+    """(H(0), H(1), H(2)) by direct substitution (the reference uses the 4-point domain, :120-132)"""
+    return [sum(tri_to_evaluations(*tri_fix_variables(f1, f2, f3, var_len, [x % p], p), var_len, p)) % p
+            for x in (0, 1, 2)]
+
+
+def tri_to_univariate_domain(f1, f2, f3, var_len, p):
+    """triangle-counting/src/lib.rs:120-132 literally (size-4 domain + inverse DFT)"""
+    w = primitive_root_of_unity(4, p)
+    dom = [pow(w, i, p) for i in range(4)]
+    evals = [sum(tri_to_evaluations(*tri_fix_variables(f1, f2, f3, var_len, [e], p), var_len, p)) % p for e in dom]
+    inv4 = pow(4, p - 2, p)
+    coeffs = [sum(evals[i] * pow(w, (-i * d) % 4, p) for i in range(4)) * inv4 % p for d in range(4)]
+    while coeffs and coeffs[-1] == 0:
+        coeffs.pop()
+    return coeffs
+
+
+def tri_transcript(adj, var_len, challenges, p):
+    """Prover::new + all 3*var_len rounds on G::new_adj_matrix(adj), verifier identities checked"""
+    cur = (list(adj), list(adj), list(adj))
+    n = 3 * var_len
+    c1 = sum(tri_to_evaluations(*cur, var_len, p)) % p
+    evals, claim = [], c1
+    for j in range(n):
+        if j:
+            cur = tri_fix_variables(*cur, var_len, [challenges[j - 1]], p)
+        e = tri_round_evals(*cur, var_len, p)
+        c = interpolate_quadratic([(0, e[0]), (1 % p, e[1]), (2 % p, e[2])], p)
+        assert (e[0] + e[1]) % p == claim, "round %d" % j
+        claim = poly_eval(c, challenges[j], p)
+        evals.append(e)
+    final = tri_evaluate(adj, adj, adj, var_len, challenges, p)
+    assert claim == final
+    return {"c_1": c1, "evals": evals, "final_eval": final}

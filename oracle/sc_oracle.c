@@ -577,3 +577,106 @@ void sco_wiring_fixed(const sco_field* f, const int* gate_type, const uint32_t* 
   free(add_t);
   free(mul_t);
 }
+
+/* ---- triangle_counting::G ------------------------------------
+ * g(X,Y,Z) = f(X,Y) f(Y,Z) f(X,Z) as three copies of the adjacency MLE; idx(i,j,nv) = (i<<nv)|j
+ * (triangle-counting/src/lib.rs:168-172).  n1, n2, n3 = current variable counts of the copies,
+ * var_len = k. */
+static void tri_counts(size_t n1, size_t n2, size_t n3, size_t k, size_t* xv, size_t* yv, size_t* zv) {
+  *xv = n1 > k ? n1 - k : 0;                                  /* :53-55 */
+  *yv = n2 > k ? n2 - k : 0;                                  /* :57-59 */
+  *zv = n3 < k ? n3 : k;                                      /* :61-67 */
+}
+
+/* G::to_evaluations, triangle-counting/src/lib.rs:138-165 */
+void sco_tri_to_evaluations(const sco_field* f, const u64* f1, size_t n1, const u64* f2, size_t n2,
+                            const u64* f3, size_t n3, size_t k, u64* out) {
+  size_t xv, yv, zv, o = 0;
+  tri_counts(n1, n2, n3, k, &xv, &yv, &zv);
+  for (size_t x = 0; x < ((size_t)1 << xv); ++x)
+    for (size_t y = 0; y < ((size_t)1 << yv); ++y)
+      for (size_t z = 0; z < ((size_t)1 << zv); ++z)
+        out[o++] = f_mul(f, f_mul(f, f1[(y << xv) | x], f2[(z << yv) | y]), f3[(z << xv) | x]);
+}
+
+/* G::fix_variables for ONE variable, triangle-counting/src/lib.rs:89-118 */
+static void tri_fix_one(const sco_field* f, u64** f1, size_t* n1, u64** f2, size_t* n2, u64** f3, size_t* n3,
+                        size_t k, u64 r) {
+  size_t xv, yv, zv;
+  tri_counts(*n1, *n2, *n3, k, &xv, &yv, &zv);
+  /* x_y_point = pp[..min(xv+yv,1)], y_z_point = pp[xv..], x_z_point = pp[..min(xv,1)] ++ pp[xv+yv..] */
+  int to1 = (xv + yv) >= 1, to2 = xv == 0, to3 = (xv >= 1) || (xv + yv == 0);
+  u64** tabs[3] = {f1, f2, f3};
+  size_t* nvs[3] = {n1, n2, n3};
+  int use[3] = {to1, to2, to3};
+  for (int t = 0; t < 3; ++t) {
+    if (!use[t]) continue;
+    u64* nt = (u64*)malloc((((size_t)1) << (*nvs[t] - 1)) * sizeof(u64));
+    sco_mle_fix_variables(f, *tabs[t], *nvs[t], &r, 1, nt);
+    free(*tabs[t]);
+    *tabs[t] = nt;
+    *nvs[t] -= 1;
+  }
+}
+
+void sco_tri_round_evals(const sco_field* f, const u64* f1, size_t n1, const u64* f2, size_t n2, const u64* f3,
+                         size_t n3, size_t k, u64 e[3]) {
+  u64 xs[3];
+  xs[0] = 0;
+  xs[1] = f->r_mod_p;
+  xs[2] = f_add(f, f->r_mod_p, f->r_mod_p);
+  for (int i = 0; i < 3; ++i) {
+    u64 *a = dup_words(f1, (size_t)1 << n1), *b = dup_words(f2, (size_t)1 << n2), *c = dup_words(f3, (size_t)1 << n3);
+    size_t m1 = n1, m2 = n2, m3 = n3, xv, yv, zv;
+    tri_fix_one(f, &a, &m1, &b, &m2, &c, &m3, k, xs[i]);
+    tri_counts(m1, m2, m3, k, &xv, &yv, &zv);
+    size_t len = (size_t)1 << (xv + yv + zv);
+    u64* ev = (u64*)malloc(len * sizeof(u64));
+    sco_tri_to_evaluations(f, a, m1, b, m2, c, m3, k, ev);
+    u64 s = 0;
+    for (size_t t = 0; t < len; ++t) s = f_add(f, s, ev[t]);
+    e[i] = s;
+    free(ev); free(a); free(b); free(c);
+  }
+}
+
+/* G::evaluate, triangle-counting/src/lib.rs:71-87, on the ORIGINAL polynomial (three 2k-variable copies) */
+u64 sco_tri_evaluate(const sco_field* f, const u64* adj, size_t k, const u64* point) {
+  u64* xz = (u64*)malloc(2 * k * sizeof(u64));
+  memcpy(xz, point, k * sizeof(u64));
+  memcpy(xz + k, point + 2 * k, k * sizeof(u64));
+  u64 v = f_mul(f, f_mul(f, sco_mle_evaluate(f, adj, 2 * k, point), sco_mle_evaluate(f, adj, 2 * k, point + k)),
+                sco_mle_evaluate(f, adj, 2 * k, xz));
+  free(xz);
+  return v;
+}
+
+/* Prover::new + all 3k rounds on G::new_adj_matrix (triangle-counting/src/lib.rs:32-51) */
+int sco_tri_prove(const sco_field* f, const u64* adj, size_t k, const u64* challenges, u64* c1_out, u64* evals,
+                  u64* final_eval) {
+  size_t len = (size_t)1 << (2 * k), nv = 3 * k;
+  u64 *a = dup_words(adj, len), *b = dup_words(adj, len), *c = dup_words(adj, len);
+  size_t n1 = 2 * k, n2 = 2 * k, n3 = 2 * k;
+  u64* ev = (u64*)malloc((((size_t)1) << nv) * sizeof(u64));
+  sco_tri_to_evaluations(f, a, n1, b, n2, c, n3, k, ev);
+  u64 c1 = 0;
+  for (size_t t = 0; t < ((size_t)1 << nv); ++t) c1 = f_add(f, c1, ev[t]);
+  free(ev);
+  if (c1_out) *c1_out = c1;
+  int status = 0;
+  u64 claim = c1;
+  for (size_t j = 0; j < nv; ++j) {
+    if (j) tri_fix_one(f, &a, &n1, &b, &n2, &c, &n3, k, challenges[j - 1]);
+    u64 e[3], co[3];
+    sco_tri_round_evals(f, a, n1, b, n2, c, n3, k, e);
+    sco_interpolate_quadratic(f, e, co);
+    if (evals) memcpy(evals + 3 * j, e, sizeof(e));
+    if (f_add(f, e[0], e[1]) != claim && !status) status = 1 + (int)j;
+    claim = sco_poly2_eval(f, co, challenges[j]);
+  }
+  u64 fin = sco_tri_evaluate(f, adj, k, challenges);
+  if (final_eval) *final_eval = fin;
+  if (claim != fin && !status) status = 1 + (int)nv;
+  free(a); free(b); free(c);
+  return status;
+}

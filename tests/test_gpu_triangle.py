@@ -1,0 +1,132 @@
+"""triangle_counting::G on the GPU: the reference's own tests replayed
+(triangle-counting/src/lib.rs:232-317) and parity against the oracle restatement."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import load_package
+from util import GOLD, oracle, pid
+
+pytestmark = pytest.mark.gpu
+
+
+def random_adj(rng, n):
+    """AdjMatrix::new, triangle-counting/src/lib.rs:187-205"""
+    m = [[False] * n for _ in range(n)]
+    for i in range(n):
+        for j in range(i + 1, n):
+            m[i][j] = m[j][i] = rng.random() < 0.5
+    return m
+
+
+def triangle_count(m):
+    n = len(m)
+    return sum(1 for x in range(n) for y in range(n) for z in range(n) if m[x][y] and m[y][z] and m[x][z]) // 6
+
+
+def run_protocol(pkg, g, rng):
+    scp = pkg.sum_check_protocol
+    F = g.field
+    prover = scp.Prover.new(g.clone())
+    c_1 = prover.c_1()
+    num_vars = g.num_vars()
+    verifier = scp.Verifier.new(num_vars, g)
+    verifier.set_c_1(c_1)
+    r_j = F.one
+    for j in range(num_vars):
+        res = verifier.round(prover.round(r_j, j), rng)
+        if res.is_final():
+            assert res.value
+            return c_1
+        r_j = res.value
+    raise AssertionError("should have returned on FinalRound from verifier")
+
+
+def test_simple_matrix():
+    """triangle-counting/src/lib.rs:232-266"""
+    pkg = load_package()
+    ctx = pkg.Context(pkg.Field(389))
+    adj = [[False, True, True, False], [True, False, True, False], [True, True, False, False], [False] * 4]
+    g = pkg.triangle_counting.G.new_adj_matrix(ctx, len(adj), sum(adj, []))
+    rng = pkg.sum_check_protocol.FieldRng(ctx.field, random.Random(1))
+    c_1 = run_protocol(pkg, g, rng)
+    assert ctx.field.to_int(c_1) == 6
+
+
+def test_randomized():
+    """triangle-counting/src/lib.rs:268-317: c_1 == 6 * triangles for n = 2..128, verifier accepts"""
+    pkg = load_package()
+    ctx = pkg.Context(pkg.Field(1572869))
+    rng = pkg.sum_check_protocol.FieldRng(ctx.field, random.Random(2))
+    gen = random.Random(3)
+    for i in range(1, 8):
+        n = 1 << i
+        m = random_adj(gen, n)
+        g = pkg.triangle_counting.G.new_adj_matrix(ctx, 2 * i, sum(m, []))
+        prover = pkg.sum_check_protocol.Prover.new(g.clone())
+        assert ctx.field.to_int(prover.c_1()) == 6 * triangle_count(m), "mismatch for size %d" % n
+        run_protocol(pkg, g, rng)
+
+
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+def test_vs_oracle(p):
+    """engine, generic trait path and every trait method against the oracle, bit for bit"""
+    pkg = load_package()
+    ctx = pkg.Context(pkg.Field(p))
+    F = ctx.field
+    o = oracle(p)
+    gen = random.Random(7)
+    for k in (1, 2, 3, 4):
+        n = 1 << k
+        m = random_adj(gen, n)
+        flat = sum(m, [])
+        g = pkg.triangle_counting.G.new_adj_matrix(ctx, 2 * k, flat)
+        oadj = o.to_mont([1 if b else 0 for b in flat])
+        ch = [F.from_int(gen.randrange(p)) for _ in range(3 * k)]
+        ref = o.tri_prove(oadj, k, ch)
+        assert ref["status"] == 0
+        assert g.num_vars() == 3 * k
+        eng = g.native_prover()
+        assert eng is not None and eng.c1() == ref["c_1"]
+        for j in range(3 * k):
+            assert eng.round_evals(ch[j - 1] if j else F.one, j) == [int(x) for x in ref["evals"][j]], (k, j)
+        assert g.evaluate(ch) == ref["final_eval"] and g.evaluate(ch[:-1]) is None
+        # generic path: fix_variables -> to_univariate, one variable at a time
+        cur = g
+        assert cur.hypercube_sum(F) == ref["c_1"]
+        if k <= 3:
+            assert np.array_equal(cur.to_evaluations(), o.tri_to_evaluations(oadj, oadj, oadj, k))
+        for j in range(3 * k):
+            if j:
+                cur = cur.fix_variables([ch[j - 1]])
+                assert cur.native_prover() is None
+            assert cur.num_vars() == 3 * k - j
+            assert cur.round_evals() == [int(x) for x in ref["evals"][j]], (k, j)
+        # multi-variable fix across the x/y/z boundaries
+        for kk in (1, k, k + 1, 2 * k, 2 * k + 1, 3 * k):
+            g2 = g.fix_variables(ch[:kk])
+            assert g2.num_vars() == 3 * k - kk
+            if kk < 3 * k:
+                assert g2.evaluate(ch[kk:]) == ref["final_eval"]
+
+
+def test_larger_graph_identities():
+    """k = 8 (256 vertices): engine output against the verifier identities and the triangle count"""
+    pkg = load_package()
+    ctx = pkg.Context(pkg.Field(GOLD))
+    F = ctx.field
+    gen = random.Random(11)
+    k = 8
+    n = 1 << k
+    m = np.zeros((n, n), dtype=bool)
+    iu = np.triu_indices(n, 1)
+    bits = np.array([gen.random() < 0.3 for _ in range(len(iu[0]))])
+    m[iu] = bits
+    m = m | m.T
+    a = m.astype(np.int64)
+    tri = int(np.trace(a @ a @ a)) // 6
+    g = pkg.triangle_counting.G.new_adj_matrix(ctx, 2 * k, m.flatten().tolist())
+    rng = pkg.sum_check_protocol.FieldRng(F, random.Random(5))
+    c_1 = run_protocol(pkg, g, rng)
+    assert F.to_int(c_1) == 6 * tri

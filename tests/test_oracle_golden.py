@@ -226,3 +226,41 @@ def test_kat_gkr_circuit_and_w():
                 while mine and mine[-1] == 0:
                     mine.pop()
                 assert dom == mine
+
+
+def test_triangle_restatements():
+    """triangle-counting/src/lib.rs: c_1 == 6 * triangles (:296-300), C oracle == pyref on the whole
+    transcript, and the 4-point-domain interpolation of :120-132 equals the direct form"""
+    rng = random.Random(4)
+    for p in (389, 1572869, GOLD):
+        o = Oracle(p)
+        for k in (1, 2, 3):
+            n = 1 << k
+            adj = [[0] * n for _ in range(n)]
+            for i in range(n):
+                for j in range(i + 1, n):
+                    adj[i][j] = adj[j][i] = rng.randrange(2)
+            flat = sum(adj, [])
+            tri = sum(adj[x][y] & adj[y][z] & adj[x][z] for x in range(n) for y in range(n) for z in range(n)) // 6
+            ch = [rng.randrange(p) for _ in range(3 * k)]
+            t = pyref.tri_transcript(flat, k, ch, p)
+            assert t["c_1"] == 6 * tri % p
+            res = o.tri_prove(o.to_mont(flat), k, o.to_mont(ch))
+            assert res["status"] == 0 and o.from_mont1(res["c_1"]) == t["c_1"]
+            assert [o.from_mont(r) for r in res["evals"]] == t["evals"]
+            assert o.from_mont1(res["final_eval"]) == t["final_eval"]
+            if p == 389 and k <= 2:
+                cur = (flat, flat, flat)
+                for j in range(3 * k):
+                    if j:
+                        cur = pyref.tri_fix_variables(*cur, k, [ch[j - 1]], p)
+                    dom = pyref.tri_to_univariate_domain(*cur, k, p)
+                    e = t["evals"][j]
+                    mine = pyref.interpolate_quadratic([(0, e[0]), (1, e[1]), (2, e[2])], p)
+                    while mine and mine[-1] == 0:
+                        mine.pop()
+                    assert dom == mine
+    k = KATS["triangle_simple_389"]
+    flat = sum(k["adjacency"], [])
+    t = pyref.tri_transcript(flat, k["k"], [3, 5, 7, 11, 13, 17], k["p"])
+    assert t["c_1"] == k["expected_c_1"]

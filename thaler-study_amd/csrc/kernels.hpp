@@ -724,6 +724,77 @@ gkr_wiring_scatter_kernel(F f, const u64* __restrict__ eq, const int* __restrict
   }
 }
 
+// ------------------------------------------------------------------------------------
+// triangle_counting::G (triangle-counting/src/lib.rs:22-166): g(X,Y,Z) = f(X,Y) f(Y,Z) f(X,Z).
+
+// P[(z << k) | x] = sum_y f[(y << k) | x] * f[(z << k) | y]: the square of the adjacency MLE's
+// matrix.  sum_{y} f1(x,y) f2(y,z) is multilinear in x and in z, so the k x-rounds of the
+// sumcheck are a product-of-two-tables sumcheck on (P, f3) - one n^3 pass here instead of an
+// n^3 pass per round (the reference's to_univariate walks all 2^(3k) evaluations, :138-165).
+// Consecutive lanes own consecutive x: the column read is coalesced, the row read a broadcast.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+matsq_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P) {
+  const size_t n = (size_t)1 << k, total = n * n;
+  for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+    const size_t z = o >> k, x = o & (n - 1);
+    typename F::Acc acc;
+    f.acc_zero(acc);
+    for (size_t y = 0; y < n; ++y) f.acc_mac(acc, T[(y << k) | x], T[(z << k) | y]);
+    P[o] = f.acc_get(acc);
+  }
+}
+
+// Round sums H(0), H(1), H(inf) of G in ANY state (xv, yv, zv variables left), by walking every
+// remaining (x, y, z) like the reference does: the generic SumCheckPolynomial::to_univariate.
+// Two of the three copies hold the current variable (pairs p, q), the third a constant c.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+tri_sums_kernel(F f, const u64* __restrict__ f1, const u64* __restrict__ f2, const u64* __restrict__ f3, int xv, int yv,
+                int zv, PassOut out) {
+  __shared__ u64 lds[(kBlock / kWave) * 3];
+  __shared__ int lds_flag;
+  const size_t total = (size_t)1 << (xv + yv + zv - 1);
+  typename F::Acc acc[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) f.acc_zero(acc[s]);
+  for (size_t t = (size_t)blockIdx.x * kBlock + threadIdx.x; t < total; t += (size_t)gridDim.x * kBlock) {
+    u64 p0, p1, q0, q1, c;
+    if (xv > 0) {
+      const size_t xh = t & (((size_t)1 << (xv - 1)) - 1), y = (t >> (xv - 1)) & (((size_t)1 << yv) - 1),
+                   z = t >> (xv - 1 + yv);
+      const size_t i1 = (y << xv) | (2 * xh), i3 = (z << xv) | (2 * xh);
+      p0 = f1[i1]; p1 = f1[i1 + 1]; q0 = f3[i3]; q1 = f3[i3 + 1]; c = f2[(z << yv) | y];
+    } else if (yv > 0) {
+      const size_t yh = t & (((size_t)1 << (yv - 1)) - 1), z = t >> (yv - 1);
+      const size_t i2 = (z << yv) | (2 * yh);
+      p0 = f1[2 * yh]; p1 = f1[2 * yh + 1]; q0 = f2[i2]; q1 = f2[i2 + 1]; c = f3[z];
+    } else {
+      p0 = f2[2 * t]; p1 = f2[2 * t + 1]; q0 = f3[2 * t]; q1 = f3[2 * t + 1]; c = f1[0];
+    }
+    f.acc_mac(acc[0], f.mul(p0, q0), c);
+    f.acc_mac(acc[1], f.mul(p1, q1), c);
+    f.acc_mac(acc[2], f.mul(f.sub(p1, p0), f.sub(q1, q0)), c);
+  }
+  u64 res[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) res[s] = f.acc_get(acc[s]);
+  block_reduce<F, 3>(f, res, lds);
+  finish_pass<F, 3>(f, out, res[0], &lds_flag);
+}
+
+// G::to_evaluations (:138-165): out[((x << yv) | y) << zv | z] = f1[(y<<xv)|x] f2[(z<<yv)|y] f3[(z<<xv)|x]
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+tri_to_evaluations_kernel(F f, const u64* __restrict__ f1, const u64* __restrict__ f2, const u64* __restrict__ f3, int xv,
+                          int yv, int zv, u64* __restrict__ out) {
+  const size_t total = (size_t)1 << (xv + yv + zv);
+  for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+    const size_t z = o & (((size_t)1 << zv) - 1), y = (o >> zv) & (((size_t)1 << yv) - 1), x = o >> (zv + yv);
+    out[o] = f.mul(f.mul(f1[(y << xv) | x], f2[(z << yv) | y]), f3[(z << xv) | x]);
+  }
+}
+
 // Vector form of the split-limb exchange (sharded G::new: the f_A half is a sum over the
 // row blocks the ranks own).  limbs[2i], limbs[2i+1] = low / high 32 bits of v[i].
 __global__ void __launch_bounds__(kBlock)

@@ -1779,3 +1779,277 @@ extern "C" int sc_gkr_prover_destroy(sc_gkr_prover* pr) {
   delete pr;
   return SC_OK;
 }
+
+// =====================================================================================
+// C ABI: triangle_counting::G
+// =====================================================================================
+
+namespace {
+
+struct TriView {
+  const u64 *f1, *f2, *f3;
+  int n1, n2, n3, xv, yv, zv;
+};
+
+int check_tri(const sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const sc_table* f3, size_t var_len, TriView* v) {
+  SC_TRY(check_table(ctx, f1, "triangle G"));
+  SC_TRY(check_table(ctx, f2, "triangle G"));
+  SC_TRY(check_table(ctx, f3, "triangle G"));
+  if (is_sharded(ctx)) return fail(ctx, SC_ERR_UNSUPPORTED, "triangle G on a sharded context");
+  const int k = (int)var_len;
+  v->f1 = f1->d; v->f2 = f2->d; v->f3 = f3->d;
+  v->n1 = log2_of(f1->len); v->n2 = log2_of(f2->len); v->n3 = log2_of(f3->len);
+  v->xv = v->n1 > k ? v->n1 - k : 0;          // triangle-counting/src/lib.rs:53-55
+  v->yv = v->n2 > k ? v->n2 - k : 0;          // :57-59
+  v->zv = v->n3 < k ? v->n3 : k;              // :61-67
+  // the three copies must describe one consistent state (x fixed before y before z)
+  const bool ok = (v->xv > 0) ? (v->n1 == v->xv + k && v->n2 == 2 * k && v->n3 == v->xv + k)
+                : (v->yv > 0) ? (v->n1 == v->yv && v->n2 == v->yv + k && v->n3 == k)
+                              : (v->n1 == 0 && v->n2 == v->zv && v->n3 == v->zv);
+  if (!ok) return fail(ctx, SC_ERR_ARG, "triangle G: inconsistent table sizes (%d,%d,%d) for var_len %d", v->n1, v->n2, v->n3, k);
+  return SC_OK;
+}
+
+sc::PassOut next_pass_out(sc_ctx* ctx, int grid) {
+  sc::PassOut out;
+  out.partials = ctx->d_partials;
+  out.n_rows = (int)ctx->partial_rows;
+  out.ticket = ctx->d_ticket;
+  out.ticket_base = ctx->ticket_base;
+  out.sums_dev = ctx->d_sums;
+  out.mailbox = ctx->use_mailbox ? ctx->d_mailbox : nullptr;
+  out.seq = ctx->use_mailbox ? ++ctx->mailbox_seq : 0;
+  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  return out;
+}
+
+}  // namespace
+
+extern "C" int sc_tri_to_evaluations(sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const sc_table* f3,
+                                     size_t var_len, sc_table** out) {
+  if (!ctx || !out) return SC_ERR_ARG;
+  TriView v;
+  SC_TRY(check_tri(ctx, f1, f2, f3, var_len, &v));
+  SC_TRY(set_device(ctx));
+  if (v.xv + v.yv + v.zv > 34) return fail(ctx, SC_ERR_ARG, "triangle to_evaluations: 2^%d entries", v.xv + v.yv + v.zv);
+  const size_t total = (size_t)1 << (v.xv + v.yv + v.zv);
+  sc_table* t = nullptr;
+  SC_TRY(new_table(ctx, total, &t));
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::tri_to_evaluations_kernel<F>), dim3(grid_for(ctx, total)),
+                                                  dim3(sc::kBlock), 0, ctx->stream, f, v.f1, v.f2, v.f3, v.xv, v.yv, v.zv, t->d));
+  hipError_t e = hipGetLastError();
+  if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) {
+    sc_table_free(ctx, t);
+    return fail(ctx, SC_ERR_HIP, "triangle to_evaluations: %s", hipGetErrorString(e));
+  }
+  *out = t;
+  return SC_OK;
+}
+
+extern "C" int sc_tri_round_sums(sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const sc_table* f3, size_t var_len,
+                                 uint64_t out_e[3]) {
+  if (!ctx || !out_e) return SC_ERR_ARG;
+  TriView v;
+  SC_TRY(check_tri(ctx, f1, f2, f3, var_len, &v));
+  SC_TRY(set_device(ctx));
+  if (v.xv + v.yv + v.zv < 1) return fail(ctx, SC_ERR_ARG, "triangle G: no variable left");
+  const size_t total = (size_t)1 << (v.xv + v.yv + v.zv - 1);
+  const int grid = grid_for(ctx, total);
+  sc::PassOut out = next_pass_out(ctx, grid);
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::tri_sums_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                  v.f1, v.f2, v.f3, v.xv, v.yv, v.zv, out));
+  SC_HIP(ctx, hipGetLastError());
+  SC_TRY(collect_sums(ctx, 3, false, ctx->use_mailbox != 0, out_e));
+  HostField hf(ctx->fp);
+  out_e[2] = eval2_from_inf(hf, out_e[0], out_e[1], out_e[2]);
+  return SC_OK;
+}
+
+extern "C" int sc_tri_fix_variables(sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const sc_table* f3,
+                                    size_t var_len, const uint64_t* r, size_t k, sc_table** f1_out, sc_table** f2_out,
+                                    sc_table** f3_out) {
+  if (!ctx || (k && !r) || !f1_out || !f2_out || !f3_out) return SC_ERR_ARG;
+  TriView v;
+  SC_TRY(check_tri(ctx, f1, f2, f3, var_len, &v));
+  const size_t xv = v.xv, yv = v.yv;
+  if (k > (size_t)(v.xv + v.yv + v.zv)) return fail(ctx, SC_ERR_ARG, "triangle fix_variables: k=%zu > num_vars", k);
+  // triangle-counting/src/lib.rs:90-105
+  const size_t n_xy = std::min(xv + yv, k);
+  const size_t n_yz = k > xv ? k - xv : 0;
+  std::vector<u64> xz(r, r + std::min(xv, k));
+  if (k > xv + yv) xz.insert(xz.end(), r + xv + yv, r + k);
+  sc_table *o1 = nullptr, *o2 = nullptr, *o3 = nullptr;
+  int rc = sc_table_fix_variables(ctx, f1, r, n_xy, SC_ORDER_LE, &o1);
+  if (rc == SC_OK) rc = sc_table_fix_variables(ctx, f2, r + std::min(xv, k), n_yz, SC_ORDER_LE, &o2);
+  if (rc == SC_OK) rc = sc_table_fix_variables(ctx, f3, xz.data(), xz.size(), SC_ORDER_LE, &o3);
+  if (rc != SC_OK) {
+    sc_table_free(ctx, o1);
+    sc_table_free(ctx, o2);
+    sc_table_free(ctx, o3);
+    return rc;
+  }
+  *f1_out = o1;
+  *f2_out = o2;
+  *f3_out = o3;
+  return SC_OK;
+}
+
+extern "C" int sc_tri_evaluate(sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const sc_table* f3, size_t var_len,
+                               const uint64_t* point, size_t n, uint64_t* out) {
+  if (!ctx || !out || (n && !point)) return SC_ERR_ARG;
+  TriView v;
+  SC_TRY(check_tri(ctx, f1, f2, f3, var_len, &v));
+  if (n != (size_t)(v.xv + v.yv + v.zv)) return fail(ctx, SC_ERR_ARG, "triangle evaluate: point has %zu entries, G has %d variables", n, v.xv + v.yv + v.zv);
+  // :72-84
+  std::vector<u64> xz(point, point + v.xv);
+  xz.insert(xz.end(), point + v.xv + v.yv, point + n);
+  u64 e1 = 0, e2 = 0, e3 = 0;
+  SC_TRY(sc_table_evaluate(ctx, f1, point, (size_t)(v.xv + v.yv), SC_ORDER_LE, &e1));
+  SC_TRY(sc_table_evaluate(ctx, f2, point + v.xv, (size_t)(v.yv + v.zv), SC_ORDER_LE, &e2));
+  SC_TRY(sc_table_evaluate(ctx, f3, xz.data(), xz.size(), SC_ORDER_LE, &e3));
+  HostField hf(ctx->fp);
+  *out = hf.mul(hf.mul(e1, e3), e2);   // :86
+  return SC_OK;
+}
+
+// Three product-of-two-tables sumchecks in a row (see include/sumcheck_hip.h).
+struct sc_tri_prover {
+  sc_ctx* ctx = nullptr;
+  const u64* adj = nullptr;  // borrowed 2^(2k) table
+  int k = 0;
+  size_t next_round = 0;
+  std::vector<u64> r;        // every challenge received
+  sc_prover* sub = nullptr;  // current phase's engine
+  sc_table ta, tb;           // views handed to sc_prover_create
+  u64 *P = nullptr, *f3r = nullptr, *f1y = nullptr, *Q = nullptr, *f2r = nullptr;  // pool buffers
+  u64 scale = 0;             // f1(r_x, r_y) in the z phase
+  u64 c1 = 0;
+};
+
+namespace {
+
+// Fold the challenges the sub-prover has not applied yet plus `r_last`; hand back its tables.
+int prover_finish(sc_prover* pr, u64 r_last, u64** a_out, u64** b_out, size_t* len_out) {
+  sc_ctx* ctx = pr->ctx;
+  pr->pending.push_back(r_last);
+  const size_t len = (size_t)1 << pr->cur_log;
+  u64 *na = nullptr, *nb = nullptr;
+  size_t la = 0, lb = 0;
+  SC_TRY(fold_chain(ctx, pr->cur_a, len, pr->pending.data(), pr->pending.size(), SC_ORDER_LE, &na, &la));
+  int rc = fold_chain(ctx, pr->cur_b, len, pr->pending.data(), pr->pending.size(), SC_ORDER_LE, &nb, &lb);
+  if (rc != SC_OK) {
+    pool_release(ctx, na);
+    return rc;
+  }
+  *a_out = na;
+  *b_out = nb;
+  *len_out = la;
+  return SC_OK;
+}
+
+int tri_start_phase(sc_tri_prover* tp, const u64* a, const u64* b, size_t len) {
+  tp->ta.d = const_cast<u64*>(a);
+  tp->ta.len = len;
+  tp->tb.d = const_cast<u64*>(b);
+  tp->tb.len = len;
+  if (tp->sub) sc_prover_destroy(tp->sub);
+  tp->sub = nullptr;
+  return sc_prover_create(tp->ctx, &tp->ta, &tp->tb, &tp->sub);
+}
+
+}  // namespace
+
+extern "C" int sc_tri_prover_create(sc_ctx* ctx, const sc_table* adj, size_t var_len, sc_tri_prover** out) {
+  if (!ctx || !out) return SC_ERR_ARG;
+  SC_TRY(check_table(ctx, adj, "sc_tri_prover_create"));
+  if (is_sharded(ctx)) return fail(ctx, SC_ERR_UNSUPPORTED, "triangle prover on a sharded context");
+  if (var_len < 1 || var_len > 15 || adj->len != ((size_t)1 << (2 * var_len)))
+    return fail(ctx, SC_ERR_ARG, "sc_tri_prover_create: adjacency table must have 2^(2*var_len) entries");
+  SC_TRY(set_device(ctx));
+  sc_tri_prover* tp = new (std::nothrow) sc_tri_prover;
+  if (!tp) return fail(ctx, SC_ERR_OOM, "host allocation failed");
+  tp->ctx = ctx;
+  tp->adj = adj->d;
+  tp->k = (int)var_len;
+  int rc = pool_alloc(ctx, adj->len, &tp->P);
+  if (rc == SC_OK) {
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::matsq_kernel<F>), dim3(grid_for(ctx, adj->len)), dim3(sc::kBlock), 0,
+                                                    ctx->stream, f, (const u64*)adj->d, tp->k, tp->P));
+    if (hipGetLastError() != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "matsq_kernel launch failed");
+  }
+  // x phase: sum_{x,z} P(x,z) f3(x,z), both indexed (z << k) | x
+  if (rc == SC_OK) rc = tri_start_phase(tp, tp->P, tp->adj, adj->len);
+  if (rc != SC_OK) {
+    sc_tri_prover_destroy(tp);
+    return rc;
+  }
+  tp->c1 = tp->sub->c1;
+  *out = tp;
+  return SC_OK;
+}
+
+extern "C" int sc_tri_prover_c1(const sc_tri_prover* pr, uint64_t* out) {
+  if (!pr || !out) return SC_ERR_ARG;
+  *out = pr->c1;
+  return SC_OK;
+}
+
+extern "C" int sc_tri_prover_round(sc_tri_prover* tp, uint64_t r_prev, size_t j, uint64_t out_e[3]) {
+  if (!tp || !out_e) return SC_ERR_ARG;
+  sc_ctx* ctx = tp->ctx;
+  const size_t k = (size_t)tp->k;
+  if (j != tp->next_round) return fail(ctx, SC_ERR_STATE, "sc_tri_prover_round: expected round %zu, got %zu", tp->next_round, j);
+  if (j >= 3 * k) return fail(ctx, SC_ERR_STATE, "sc_tri_prover_round: all %zu rounds done", 3 * k);
+  if (j != 0 && r_prev >= ctx->fp.p) return fail(ctx, SC_ERR_ARG, "sc_tri_prover_round: challenge is not reduced");
+  SC_TRY(set_device(ctx));
+  if (j != 0) tp->r.push_back(r_prev);
+  HostField hf(ctx->fp);
+  const size_t n = (size_t)1 << k;
+  if (j == k) {
+    // x fully fixed at r_x = r[0..k): P(r_x, .) is not needed any more, f3(r_x, .) is
+    u64 *pa = nullptr, *pb = nullptr;
+    size_t len = 0;
+    SC_TRY(prover_finish(tp->sub, r_prev, &pa, &pb, &len));
+    pool_release(ctx, pa);
+    tp->f3r = pb;  // f3(r_x, z), 2^k entries
+    size_t l1 = 0;
+    SC_TRY(fold_chain(ctx, tp->adj, n * n, tp->r.data(), k, SC_ORDER_LE, &tp->f1y, &l1));  // f1(r_x, y)
+    SC_TRY(pool_alloc(ctx, n, &tp->Q));
+    SC_TRY(coldot(ctx, tp->adj, tp->f3r, n, n, tp->Q));  // Q[y] = sum_z f2[(z<<k)|y] f3r[z]
+    SC_TRY(tri_start_phase(tp, tp->f1y, tp->Q, n));
+  } else if (j == 2 * k) {
+    u64 *pa = nullptr, *pb = nullptr;
+    size_t len = 0;
+    SC_TRY(prover_finish(tp->sub, r_prev, &pa, &pb, &len));
+    pool_release(ctx, pb);
+    SC_HIP(ctx, hipMemcpyAsync(&tp->scale, pa, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));  // f1(r_x, r_y)
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    pool_release(ctx, pa);
+    size_t l2 = 0;
+    SC_TRY(fold_chain(ctx, tp->adj, n * n, tp->r.data() + k, k, SC_ORDER_LE, &tp->f2r, &l2));  // f2(r_y, z)
+    SC_TRY(tri_start_phase(tp, tp->f2r, tp->f3r, n));
+  }
+  const size_t local_j = j % k;
+  const bool phase_start = (local_j == 0);
+  u64 e[3];
+  SC_TRY(sc_prover_round(tp->sub, phase_start ? hf.one() : r_prev, local_j, e));
+  if (j >= 2 * k) {
+    for (int i = 0; i < 3; ++i) e[i] = hf.mul(e[i], tp->scale);
+  }
+  memcpy(out_e, e, sizeof(e));
+  tp->next_round = j + 1;
+  return SC_OK;
+}
+
+extern "C" int sc_tri_prover_destroy(sc_tri_prover* tp) {
+  if (!tp) return SC_OK;
+  if (tp->sub) sc_prover_destroy(tp->sub);
+  pool_release(tp->ctx, tp->P);
+  pool_release(tp->ctx, tp->f3r);
+  pool_release(tp->ctx, tp->f1y);
+  pool_release(tp->ctx, tp->Q);
+  pool_release(tp->ctx, tp->f2r);
+  delete tp;
+  return SC_OK;
+}
