@@ -9,7 +9,7 @@ P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
 
 def one(d, pat):
-    return sorted(glob.glob(os.path.join(d, "*", pat)))[-1]
+    return max(glob.glob(os.path.join(d, "*", pat)), key=os.path.getmtime)
 
 def short(name):
     name = re.sub(r"\(.*", "", name)
