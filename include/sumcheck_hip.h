@@ -220,6 +220,14 @@ int sc_gkr_prover_c1(const sc_gkr_prover* pr, uint64_t* out);
 int sc_gkr_prover_round(sc_gkr_prover* pr, uint64_t r_prev, size_t j, uint64_t out_e[3]);
 int sc_gkr_prover_destroy(sc_gkr_prover* pr);
 
+/* restrict_poly (gkr-protocol/src/lib.rs:291-321): the univariate
+ * q(t) = W~(l(t)) for the line l(0) = b, l(1) = c (`line`, :278-289), as dense coefficients
+ * out_coeffs[0..k] (degree <= k = number of variables).  Computed as k+1 streaming evaluations
+ * at t = 0..k plus exact interpolation on the host, instead of the reference's O(k 2^k) product
+ * of linear factors; needs p > k.  The reference returns a SparsePolynomial: drop zero terms. */
+int sc_table_restrict_to_line(sc_ctx* ctx, const sc_table* t, const uint64_t* b, const uint64_t* c, size_t k,
+                              uint64_t* out_coeffs);
+
 /* ---- triangle_counting::G -------------------------------------
  *   g(X,Y,Z) = f(X,Y) f(Y,Z) f(X,Z)   (triangle-counting/src/lib.rs:10-27)
  * three copies f1, f2, f3 of the adjacency MLE (2*var_len variables each before any fixing,

@@ -153,3 +153,38 @@ def test_w_random_circuits_vs_oracle(p):
                 c = o.interpolate(np.array(e, dtype=np.uint64))
                 claim = o.poly2_eval(c, ch[j])
             assert claim == w.evaluate(ch)
+
+
+def test_restrict_poly():
+    """gkr-protocol/src/lib.rs:507-548 ([32, 385, 383] over F_389) and random lines vs pyref"""
+    pkg = load_package()
+    gp = pkg.gkr_protocol
+    kat = __import__("util").load_golden("reference_kats.json")["restrict_poly_389"]
+    p = kat["p"]
+    ctx = pkg.Context(pkg.Field(p))
+    F = ctx.field
+    mle = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2, F.from_ints(kat["evals"]))
+    poly = gp.restrict_poly(F.from_ints(kat["b"]).tolist(), F.from_ints(kat["c"]).tolist(), mle)
+    dense = [0] * 3
+    for d, cf in poly.coeffs:
+        dense[d] = F.to_int(cf)
+    assert dense == kat["expected_coeffs"]                      # -6t^2 - 4t + 32
+    ln = gp.line(F, F.from_ints(kat["b"]).tolist(), F.from_ints(kat["c"]).tolist())
+    assert [F.to_int(l.evaluate(F.zero)) for l in ln] == kat["b"] and [F.to_int(l.evaluate(F.one)) for l in ln] == kat["c"]
+    rng = random.Random(8)
+    for q in (389, GOLD):
+        ctx = pkg.Context(pkg.Field(q))
+        F = ctx.field
+        for k in (1, 3, 6, 9):
+            ev = [rng.randrange(q) for _ in range(1 << k)]
+            b = [rng.randrange(q) for _ in range(k)]
+            c = [rng.randrange(q) for _ in range(k)]
+            mle = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, k, F.from_ints(ev))
+            poly = gp.restrict_poly(F.from_ints(b).tolist(), F.from_ints(c).tolist(), mle)
+            expect = pyref.restrict_poly(b, c, ev, q)
+            got = [0] * (k + 1)
+            for d, cf in poly.coeffs:
+                got[d] = F.to_int(cf)
+            while len(got) > 1 and got[-1] == 0:
+                got.pop()
+            assert got == expect, (q, k)

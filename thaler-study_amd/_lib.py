@@ -81,6 +81,7 @@ SIGNATURES = {
     "sc_gkr_prover_c1": (ctypes.c_int, [voidp, u64p]),
     "sc_gkr_prover_round": (ctypes.c_int, [voidp, u64, size_t, u64p]),
     "sc_gkr_prover_destroy": (ctypes.c_int, [voidp]),
+    "sc_table_restrict_to_line": (ctypes.c_int, [voidp, voidp, u64p, u64p, size_t, u64p]),
     "sc_tri_to_evaluations": (ctypes.c_int, [voidp, voidp, voidp, voidp, size_t, ctypes.POINTER(voidp)]),
     "sc_tri_round_sums": (ctypes.c_int, [voidp, voidp, voidp, voidp, size_t, u64p]),
     "sc_tri_fix_variables": (ctypes.c_int, [voidp, voidp, voidp, voidp, size_t, u64p, size_t] + [ctypes.POINTER(voidp)] * 3),

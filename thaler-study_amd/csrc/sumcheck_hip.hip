@@ -2053,3 +2053,50 @@ extern "C" int sc_tri_prover_destroy(sc_tri_prover* tp) {
   delete tp;
   return SC_OK;
 }
+
+// =====================================================================================
+// C ABI: restrict_poly (gkr-protocol/src/lib.rs:291-321)
+// =====================================================================================
+
+extern "C" int sc_table_restrict_to_line(sc_ctx* ctx, const sc_table* t, const uint64_t* b, const uint64_t* c, size_t k,
+                                         uint64_t* out_coeffs) {
+  if (!ctx || !out_coeffs || (k && (!b || !c))) return SC_ERR_ARG;
+  SC_TRY(check_table(ctx, t, "sc_table_restrict_to_line"));
+  if (is_sharded(ctx)) return fail(ctx, SC_ERR_UNSUPPORTED, "restrict_to_line on a sharded table");
+  if ((size_t)log2_of(t->len) != k) return fail(ctx, SC_ERR_ARG, "restrict_to_line: table has %d variables, k = %zu", log2_of(t->len), k);
+  if (ctx->fp.p <= k) return fail(ctx, SC_ERR_UNSUPPORTED, "restrict_to_line needs k+1 distinct points: p = %llu <= k", (unsigned long long)ctx->fp.p);
+  HostField hf(ctx->fp);
+  // q(j) = W~(b + j (c - b)), j = 0..k
+  std::vector<u64> xs(k + 1), ys(k + 1), pt(k), d(k);
+  for (size_t i = 0; i < k; ++i) d[i] = hf.sub(c[i], b[i]);
+  u64 x = 0;
+  for (size_t j = 0; j <= k; ++j) {
+    xs[j] = x;
+    for (size_t i = 0; i < k; ++i) pt[i] = hf.add(b[i], hf.mul(x, d[i]));
+    SC_TRY(sc_table_evaluate(ctx, t, pt.data(), k, SC_ORDER_LE, &ys[j]));
+    x = hf.add(x, hf.one());
+  }
+  // Lagrange: q(X) = sum_j y_j prod_{m != j} (X - x_m) / (x_j - x_m); master polynomial once,
+  // synthetic division per node.
+  std::vector<u64> master(k + 2, 0);
+  master[0] = hf.one();
+  for (size_t m = 0; m <= k; ++m) {           // multiply by (X - x_m)
+    for (size_t i = m + 1; i > 0; --i) master[i] = hf.sub(master[i - 1], hf.mul(xs[m], master[i]));
+    master[0] = hf.neg(hf.mul(xs[m], master[0]));
+  }
+  std::vector<u64> coeffs(k + 1, 0), quot(k + 1);
+  for (size_t j = 0; j <= k; ++j) {
+    u64 carry = master[k + 1];                // divide master by (X - x_j)
+    for (size_t i = k + 1; i > 0; --i) {
+      quot[i - 1] = carry;
+      carry = hf.add(master[i - 1], hf.mul(carry, xs[j]));
+    }
+    u64 den = hf.one();
+    for (size_t m = 0; m <= k; ++m)
+      if (m != j) den = hf.mul(den, hf.sub(xs[j], xs[m]));
+    const u64 w = hf.mul(ys[j], hf.inv(den));
+    for (size_t i = 0; i <= k; ++i) coeffs[i] = hf.add(coeffs[i], hf.mul(w, quot[i]));
+  }
+  memcpy(out_coeffs, coeffs.data(), (k + 1) * sizeof(u64));
+  return SC_OK;
+}

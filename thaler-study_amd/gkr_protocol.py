@@ -180,3 +180,21 @@ def start_round_w(ctx, circuit, evaluation, i, r_i):
     add_i, mul_i = wiring(ctx, circuit, i, r_i)
     assert add_i.num_vars() == 2 * w_b.num_vars()                        # :419
     return W.new(add_i, mul_i, w_b, w_b)
+
+
+def line(field, b, c):
+    """gkr-protocol/src/lib.rs:278-289: l_i(t) = b_i + t (c_i - b_i)"""
+    from .sum_check_protocol import SparsePolynomial
+    return [SparsePolynomial.from_coefficients_vec(field, [(0, bi), (1, field.sub(ci, bi))]) for bi, ci in zip(b, c)]
+
+
+def restrict_poly(b, c, mle):
+    """gkr-protocol/src/lib.rs:291-321: W~ restricted to the line through b and c"""
+    from .sum_check_protocol import SparsePolynomial
+    ctx = mle.ctx
+    k = mle.num_vars()
+    bb, cc = _words(b), _words(c)
+    assert bb.size == k and cc.size == k
+    out = np.zeros(k + 1, dtype=np.uint64)
+    ctx.check(ctx.lib.sc_table_restrict_to_line(ctx.h, mle.h, _u64p(bb), _u64p(cc), k, _u64p(out)))
+    return SparsePolynomial.from_coefficients_vec(ctx.field, [(d, int(v)) for d, v in enumerate(out)])
