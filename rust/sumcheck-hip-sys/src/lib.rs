@@ -33,6 +33,14 @@ pub struct sc_table {
 pub struct sc_prover {
     _private: [u8; 0],
 }
+#[repr(C)]
+pub struct sc_gkr_prover {
+    _private: [u8; 0],
+}
+#[repr(C)]
+pub struct sc_tri_prover {
+    _private: [u8; 0],
+}
 
 pub type sc_allreduce_fn = Option<unsafe extern "C" fn(user: *mut c_void, buf: *mut u64, count: usize) -> c_int>;
 pub type sc_allgather_fn =
@@ -154,4 +162,124 @@ extern "C" {
         evals: *mut u64,
         challenges: *mut u64,
     ) -> c_int;
+
+    // ---- gkr_protocol::round_polynomial::W ------------------------------------------------
+    pub fn sc_gkr_wiring(
+        ctx: *mut sc_ctx,
+        gate_type: *const i32,
+        in0: *const u32,
+        in1: *const u32,
+        k_i: usize,
+        k_next: usize,
+        r_i: *const u64,
+        add_out: *mut *mut sc_table,
+        mul_out: *mut *mut sc_table,
+    ) -> c_int;
+    pub fn sc_gkr_w_to_evaluations(
+        ctx: *mut sc_ctx,
+        add: *const sc_table,
+        mul: *const sc_table,
+        w_b: *const sc_table,
+        w_c: *const sc_table,
+        out: *mut *mut sc_table,
+    ) -> c_int;
+    pub fn sc_gkr_w_round_sums(
+        ctx: *mut sc_ctx,
+        add: *const sc_table,
+        mul: *const sc_table,
+        w_b: *const sc_table,
+        w_c: *const sc_table,
+        out_e: *mut u64,
+    ) -> c_int;
+    pub fn sc_gkr_w_fix_variables(
+        ctx: *mut sc_ctx,
+        add: *const sc_table,
+        mul: *const sc_table,
+        w_b: *const sc_table,
+        w_c: *const sc_table,
+        r: *const u64,
+        k: usize,
+        add_out: *mut *mut sc_table,
+        mul_out: *mut *mut sc_table,
+        w_b_out: *mut *mut sc_table,
+        w_c_out: *mut *mut sc_table,
+    ) -> c_int;
+    pub fn sc_gkr_w_evaluate(
+        ctx: *mut sc_ctx,
+        add: *const sc_table,
+        mul: *const sc_table,
+        w_b: *const sc_table,
+        w_c: *const sc_table,
+        point: *const u64,
+        n: usize,
+        out: *mut u64,
+    ) -> c_int;
+    pub fn sc_gkr_prover_create(
+        ctx: *mut sc_ctx,
+        add: *const sc_table,
+        mul: *const sc_table,
+        w_b: *const sc_table,
+        w_c: *const sc_table,
+        out: *mut *mut sc_gkr_prover,
+    ) -> c_int;
+    pub fn sc_gkr_prover_c1(pr: *const sc_gkr_prover, out: *mut u64) -> c_int;
+    pub fn sc_gkr_prover_round(pr: *mut sc_gkr_prover, r_prev: u64, j: usize, out_e: *mut u64) -> c_int;
+    pub fn sc_gkr_prover_destroy(pr: *mut sc_gkr_prover) -> c_int;
+    pub fn sc_table_restrict_to_line(
+        ctx: *mut sc_ctx,
+        t: *const sc_table,
+        b: *const u64,
+        c: *const u64,
+        k: usize,
+        out_coeffs: *mut u64,
+    ) -> c_int;
+
+    // ---- triangle_counting::G ----------------------------------------------------------------
+    pub fn sc_tri_to_evaluations(
+        ctx: *mut sc_ctx,
+        f1: *const sc_table,
+        f2: *const sc_table,
+        f3: *const sc_table,
+        var_len: usize,
+        out: *mut *mut sc_table,
+    ) -> c_int;
+    pub fn sc_tri_round_sums(
+        ctx: *mut sc_ctx,
+        f1: *const sc_table,
+        f2: *const sc_table,
+        f3: *const sc_table,
+        var_len: usize,
+        out_e: *mut u64,
+    ) -> c_int;
+    pub fn sc_tri_fix_variables(
+        ctx: *mut sc_ctx,
+        f1: *const sc_table,
+        f2: *const sc_table,
+        f3: *const sc_table,
+        var_len: usize,
+        r: *const u64,
+        k: usize,
+        f1_out: *mut *mut sc_table,
+        f2_out: *mut *mut sc_table,
+        f3_out: *mut *mut sc_table,
+    ) -> c_int;
+    pub fn sc_tri_evaluate(
+        ctx: *mut sc_ctx,
+        f1: *const sc_table,
+        f2: *const sc_table,
+        f3: *const sc_table,
+        var_len: usize,
+        point: *const u64,
+        n: usize,
+        out: *mut u64,
+    ) -> c_int;
+    pub fn sc_tri_prover_create(
+        ctx: *mut sc_ctx,
+        adj: *const sc_table,
+        var_len: usize,
+        out: *mut *mut sc_tri_prover,
+    ) -> c_int;
+    pub fn sc_tri_prover_c1(pr: *const sc_tri_prover, out: *mut u64) -> c_int;
+    pub fn sc_tri_prover_round(pr: *mut sc_tri_prover, r_prev: u64, j: usize, out_e: *mut u64) -> c_int;
+    pub fn sc_tri_prover_destroy(pr: *mut sc_tri_prover) -> c_int;
 }
