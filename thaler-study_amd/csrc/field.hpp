@@ -33,10 +33,7 @@ typedef uint32_t u32;
 // 64 x 64 -> 128 product.  Device: four 32x32+64 multiply-adds (v_mad_u64_u32); asking the
 // compiler for `a*b` and `__umul64hi(a,b)` separately costs seven quarter-rate multiplies.
 SC_HD void mul_wide(u64 a, u64 b, u64& hi, u64& lo) {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(SC_FIELD_V0)
-  lo = a * b;
-  hi = __umul64hi(a, b);
-#elif defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__)
   const u32 a0 = (u32)a, a1 = (u32)(a >> 32), b0 = (u32)b, b1 = (u32)(b >> 32);
   const u64 p00 = (u64)a0 * b0;
   const u64 mid = (u64)a0 * b1 + (p00 >> 32);     // < 2^64: (2^32-1)^2 + 2^32-1

@@ -41,16 +41,6 @@ __device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], const FoldW& 
 #pragma unroll
     for (int b = 0; b < IN / 2; ++b) v[b] = f.add(v[2 * b], f.mul(r0, f.sub(v[2 * b + 1], v[2 * b])));
   } else if constexpr (KF >= 2) {
-#if defined(SC_FOLD_CLASSIC)  // A/B switch (tools/kbench.hip): dependent one-variable folds
-    static_assert(KF <= 3, "");
-#pragma unroll
-    for (int lvl = 0; lvl < KF; ++lvl) {
-      const u64 r = fw.w[4 + lvl];  // kbench passes raw challenges in w[4..6]
-#pragma unroll
-      for (int b = 0; b < (IN >> (lvl + 1)); ++b) v[b] = f.add(v[2 * b], f.mul(r, f.sub(v[2 * b + 1], v[2 * b])));
-    }
-    return;
-#endif
     constexpr int G = 1 << KF;
 #pragma unroll
     for (int b = 0; b < IN / G; ++b) {
@@ -370,30 +360,11 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
 
   const size_t tile_stride = (size_t)gridDim.x * kWaves;
   size_t tile = (size_t)blockIdx.x * kWaves + wave;
-#if defined(SC_PREFETCH)
-  // software pipeline: the next tile's loads are in flight while this one is computed
-  if (tile < n_tiles) {
-    ull2 ca[NP], cb[NP];
-    load_tile(tile, ca, cb);
-    while (true) {
-      const size_t nxt = tile + tile_stride;
-      ull2 na[NP], nb[NP];
-      const bool more = nxt < n_tiles;
-      if (more) load_tile(nxt, na, nb);
-      process_tile(tile, ca, cb);
-      if (!more) break;
-#pragma unroll
-      for (int k = 0; k < NP; ++k) { ca[k] = na[k]; cb[k] = nb[k]; }
-      tile = nxt;
-    }
-  }
-#else
   for (; tile < n_tiles; tile += tile_stride) {
     ull2 pa[NP], pb[NP];
     load_tile(tile, pa, pb);
     process_tile(tile, pa, pb);
   }
-#endif
 
   u64 res[NS];
 #pragma unroll
