@@ -216,6 +216,13 @@ int sc_gkr_w_evaluate(sc_ctx* ctx, const sc_table* add, const sc_table* mul, con
 typedef struct sc_gkr_prover sc_gkr_prover;
 int sc_gkr_prover_create(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
                          const sc_table* w_c, sc_gkr_prover** out);
+/* The same prover straight from the gate list of layer i (arguments as sc_gkr_wiring) and the
+ * 2^k_next values W_{i+1} of the next layer: add_i / mul_i have one non-zero per gate and W is
+ * linear in them, so every round visits the 2^k_i gates instead of the 4^k_next table entries,
+ * and the dense tables are never built.  Round polynomials are identical to the dense prover's. */
+int sc_gkr_prover_create_sparse(sc_ctx* ctx, const int32_t* gate_type, const uint32_t* in0, const uint32_t* in1,
+                                size_t k_i, size_t k_next, const uint64_t* r_i, const sc_table* w_next,
+                                sc_gkr_prover** out);
 int sc_gkr_prover_c1(const sc_gkr_prover* pr, uint64_t* out);
 int sc_gkr_prover_round(sc_gkr_prover* pr, uint64_t r_prev, size_t j, uint64_t out_e[3]);
 int sc_gkr_prover_destroy(sc_gkr_prover* pr);

@@ -127,6 +127,12 @@ def test_w_random_circuits_vs_oracle(p):
         assert np.array_equal(w.add_i.to_evaluations(), oadd) and np.array_equal(w.mul_i.to_evaluations(), omul)
         ow = np.array(evaluation[1], dtype=np.uint64)
         ch = [F.from_int(rng.randrange(p)) for _ in range(2 * k_next)]
+        # the sparse (per-gate) prover gives the dense prover's round polynomials, bit for bit
+        dense_eng, sparse_eng = w.native_prover(), gp.SparseLayerProver(ctx, circuit, evaluation, i, r_i)
+        assert dense_eng.c1() == sparse_eng.c1()
+        for j in range(2 * k_next):
+            rp = ch[j - 1] if j else F.one
+            assert dense_eng.round_evals(rp, j) == sparse_eng.round_evals(rp, j), (ks, j)
         if 2 * k_next <= 12:
             ref = o.w_prove(oadd, omul, ow, ow, ch)
             assert ref["status"] == 0

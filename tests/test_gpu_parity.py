@@ -410,7 +410,7 @@ def _check_round_identities(F, c1, evals, ch, final_eval):
     assert claim == final_eval
 
 
-@pytest.mark.parametrize("n,vpp", [(24, 2), (26, 2), (26, 1), (28, 2)])
+@pytest.mark.parametrize("n,vpp", [(24, 2), (26, 2), (26, 1), (28, 2), (28, 1), (30, 2)])
 def test_full_size_identities(pkg, n, vpp):
     ctx = ctx_for(pkg, GOLD, vars_per_pass=vpp)
     F = ctx.field

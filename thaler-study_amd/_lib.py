@@ -78,6 +78,9 @@ SIGNATURES = {
     "sc_gkr_w_fix_variables": (ctypes.c_int, [voidp, voidp, voidp, voidp, voidp, u64p, size_t] + [ctypes.POINTER(voidp)] * 4),
     "sc_gkr_w_evaluate": (ctypes.c_int, [voidp, voidp, voidp, voidp, voidp, u64p, size_t, u64p]),
     "sc_gkr_prover_create": (ctypes.c_int, [voidp, voidp, voidp, voidp, voidp, ctypes.POINTER(voidp)]),
+    "sc_gkr_prover_create_sparse": (ctypes.c_int, [voidp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint32),
+                                                    ctypes.POINTER(ctypes.c_uint32), size_t, size_t, u64p, voidp,
+                                                    ctypes.POINTER(voidp)]),
     "sc_gkr_prover_c1": (ctypes.c_int, [voidp, u64p]),
     "sc_gkr_prover_round": (ctypes.c_int, [voidp, u64, size_t, u64p]),
     "sc_gkr_prover_destroy": (ctypes.c_int, [voidp]),

@@ -766,6 +766,75 @@ tri_to_evaluations_kernel(F f, const u64* __restrict__ f1, const u64* __restrict
   }
 }
 
+// Sparse form of the W sumcheck.  add_i(r_i,.,.) and mul_i(r_i,.,.) have one non-zero per
+// gate (2^k_i of the 2^(2 k_next) entries), and W is LINEAR in them, so a round only has to
+// visit the gates: entry e carries idx_e = (in1 << k_next) | in0, its type and its current
+// value val_e (eq(r_i, a) times the factors of the challenges folded so far).  Per round:
+//   - apply the previous challenge r: val_e *= (bit ? r : 1 - r), bit = bit (shift-1) of idx_e;
+//   - with cur = idx_e >> shift: the entry sits at position `bit = cur & 1` of pair q = cur >> 1,
+//     S(t) = x(t) + y for an add gate, x(t) * y for a mul gate (x, y as in gkr_sums_kernel);
+//     it adds val*S(0) to H(0) if bit = 0, val*S(1) to H(1) if bit = 1, and -/+ val*(S(1)-S(0)) to
+//     H(inf).  Entries that fall into the same pair need no merging (linearity).
+// O(gates) per round instead of O(4^k_next): the dense tables are never built.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+gkr_sparse_round_kernel(F f, const unsigned* __restrict__ idx, const int* __restrict__ gate_type, u64* __restrict__ val,
+                        size_t n_entries, int shift, u64 r_prev, const u64* __restrict__ V, int logV,
+                        const u64* __restrict__ Fx, PassOut out) {
+  __shared__ u64 lds[(kBlock / kWave) * 3];
+  __shared__ int lds_flag;
+  const ull2* __restrict__ Vp = reinterpret_cast<const ull2*>(V);
+  const size_t vmask = (((size_t)1 << logV) >> 1) - 1;
+  const u64 one_minus_r = f.sub(f.one(), r_prev);
+  typename F::Acc acc[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) f.acc_zero(acc[s]);
+  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < n_entries; e += (size_t)gridDim.x * kBlock) {
+    const unsigned id = idx[e];
+    u64 v = val[e];
+    if (shift > 0) {
+      v = f.mul(v, ((id >> (shift - 1)) & 1) ? r_prev : one_minus_r);
+      val[e] = v;
+    }
+    const size_t cur = (size_t)(id >> shift);
+    const int bit = (int)(cur & 1);
+    const size_t q = cur >> 1;
+    const ull2 x = Vp[q & vmask];
+    const u64 y = Fx[(2 * q) >> logV];
+    u64 s0, s1;
+    if (gate_type[e] == 0) {
+      s0 = f.add(x.x, y);
+      s1 = f.add(x.y, y);
+    } else {
+      s0 = f.mul(x.x, y);
+      s1 = f.mul(x.y, y);
+    }
+    const u64 ds = f.sub(s1, s0);
+    if (bit == 0) {
+      f.acc_mac(acc[0], v, s0);
+      f.acc_mac(acc[2], v, f.sub(0, ds));   // coefficient of t^2 in val (1-t) (s0 + t ds)
+    } else {
+      f.acc_mac(acc[1], v, s1);
+      f.acc_mac(acc[2], v, ds);
+    }
+  }
+  u64 res[3];
+#pragma unroll
+  for (int s = 0; s < 3; ++s) res[s] = f.acc_get(acc[s]);
+  block_reduce<F, 3>(f, res, lds);
+  finish_pass<F, 3>(f, out, res[0], &lds_flag);
+}
+
+// entries of the sparse form from the gate list: idx = (in1 << k_next) | in0, val = eq[a]
+__global__ void __launch_bounds__(kBlock)
+gkr_sparse_init_kernel(const u64* __restrict__ eq, const unsigned* __restrict__ in0, const unsigned* __restrict__ in1,
+                       size_t n_gates, int k_next, unsigned* __restrict__ idx, u64* __restrict__ val) {
+  for (size_t a = (size_t)blockIdx.x * kBlock + threadIdx.x; a < n_gates; a += (size_t)gridDim.x * kBlock) {
+    idx[a] = (in1[a] << k_next) | in0[a];
+    val[a] = eq[a];
+  }
+}
+
 // Vector form of the split-limb exchange (sharded G::new: the f_A half is a sum over the
 // row blocks the ranks own).  limbs[2i], limbs[2i+1] = low / high 32 bits of v[i].
 __global__ void __launch_bounds__(kBlock)

@@ -348,6 +348,20 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   return SC_OK;
 }
 
+// PassOut of the next launch with `grid` blocks that publishes to the mailbox (unsharded paths)
+sc::PassOut next_pass_out(sc_ctx* ctx, int grid) {
+  sc::PassOut out;
+  out.partials = ctx->d_partials;
+  out.n_rows = (int)ctx->partial_rows;
+  out.ticket = ctx->d_ticket;
+  out.ticket_base = ctx->ticket_base;
+  out.sums_dev = ctx->d_sums;
+  out.mailbox = ctx->use_mailbox ? ctx->d_mailbox : nullptr;
+  out.seq = ctx->use_mailbox ? ++ctx->mailbox_seq : 0;
+  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  return out;
+}
+
 void account_kernel_time(sc_ctx* ctx) {
   if (!ctx->time_kernels || !ctx->kt_pending) return;
   ctx->kt_pending = false;
@@ -1684,7 +1698,92 @@ struct sc_gkr_prover {
   size_t num_vars = 0, next_round = 0;
   u64 c1 = 0;
   u64 first[3];
+  // sparse form (sc_gkr_prover_create_sparse): one entry per gate
+  bool sparse = false;
+  size_t n_entries = 0;
+  unsigned* sp_idx = nullptr;
+  int* sp_type = nullptr;
+  u64* sp_val = nullptr;
+  u64* sp_words = nullptr;  // pool block backing sp_idx / sp_type
 };
+
+namespace {
+
+// one round of the sparse prover: folds the gate values with r_prev (shift > 0) and sums
+int gkr_sparse_round(sc_gkr_prover* pr, int shift, u64 r_prev, u64 e[3]) {
+  sc_ctx* ctx = pr->ctx;
+  const u64* V = pr->kb >= 1 ? pr->w_b : pr->w_c;
+  const int logV = pr->kb >= 1 ? pr->kb : pr->kc;
+  const u64* Fx = pr->kb >= 1 ? pr->w_c : pr->w_b;
+  const int grid = grid_for(ctx, pr->n_entries);
+  sc::PassOut out = next_pass_out(ctx, grid);
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_sparse_round_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
+                                                  f, (const unsigned*)pr->sp_idx, (const int*)pr->sp_type, pr->sp_val,
+                                                  pr->n_entries, shift, r_prev, V, logV, Fx, out));
+  SC_HIP(ctx, hipGetLastError());
+  SC_TRY(collect_sums(ctx, 3, false, ctx->use_mailbox != 0, e));
+  HostField hf(ctx->fp);
+  e[2] = eval2_from_inf(hf, e[0], e[1], e[2]);
+  return SC_OK;
+}
+
+}  // namespace
+
+extern "C" int sc_gkr_prover_create_sparse(sc_ctx* ctx, const int32_t* gate_type, const uint32_t* in0, const uint32_t* in1,
+                                           size_t k_i, size_t k_next, const uint64_t* r_i, const sc_table* w_next,
+                                           sc_gkr_prover** out) {
+  if (!ctx || !gate_type || !in0 || !in1 || (k_i && !r_i) || !out) return SC_ERR_ARG;
+  SC_TRY(check_table(ctx, w_next, "sc_gkr_prover_create_sparse"));
+  if (is_sharded(ctx)) return fail(ctx, SC_ERR_UNSUPPORTED, "gkr prover on a sharded context");
+  if (k_i > 30 || k_next < 1 || k_next > 15 || w_next->len != ((size_t)1 << k_next))
+    return fail(ctx, SC_ERR_ARG, "sc_gkr_prover_create_sparse: bad layer sizes");
+  SC_TRY(set_device(ctx));
+  const size_t n_gates = (size_t)1 << k_i, n_next = (size_t)1 << k_next;
+  for (size_t a = 0; a < n_gates; ++a)
+    if ((gate_type[a] != 0 && gate_type[a] != 1) || in0[a] >= n_next || in1[a] >= n_next)
+      return fail(ctx, SC_ERR_ARG, "sc_gkr_prover_create_sparse: gate %zu is malformed", a);
+  sc_gkr_prover* pr = new (std::nothrow) sc_gkr_prover;
+  if (!pr) return fail(ctx, SC_ERR_OOM, "host allocation failed");
+  pr->ctx = ctx;
+  pr->sparse = true;
+  pr->n_entries = n_gates;
+  pr->w_b = pr->w_c = w_next->d;
+  pr->kb = pr->kc = (int)k_next;
+  pr->num_vars = 2 * k_next;
+  u64 *eq = nullptr, *tmp = nullptr;
+  int rc = build_eq_table(ctx, r_i, (int)k_i, &eq);
+  if (rc == SC_OK) rc = pool_alloc(ctx, n_gates + 1, &pr->sp_words);   // idx (u32) | type (i32)
+  if (rc == SC_OK) rc = pool_alloc(ctx, n_gates, &pr->sp_val);
+  if (rc == SC_OK) rc = pool_alloc(ctx, n_gates + 1, &tmp);             // in0 | in1 staging
+  if (rc == SC_OK) {
+    pr->sp_idx = (unsigned*)pr->sp_words;
+    pr->sp_type = (int*)pr->sp_words + n_gates;
+    unsigned* d_in0 = (unsigned*)tmp;
+    unsigned* d_in1 = (unsigned*)tmp + n_gates;
+    hipError_t e = hipMemcpyAsync(pr->sp_type, gate_type, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in0, in0, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in1, in1, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(sc::gkr_sparse_init_kernel, dim3(grid_for(ctx, n_gates)), dim3(sc::kBlock), 0, ctx->stream,
+                         (const u64*)eq, (const unsigned*)d_in0, (const unsigned*)d_in1, n_gates, (int)k_next, pr->sp_idx,
+                         pr->sp_val);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // host arrays may go away after return
+    if (e != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "sc_gkr_prover_create_sparse: %s", hipGetErrorString(e));
+  }
+  pool_release(ctx, eq);
+  pool_release(ctx, tmp);
+  if (rc == SC_OK) rc = gkr_sparse_round(pr, 0, 0, pr->first);
+  if (rc != SC_OK) {
+    sc_gkr_prover_destroy(pr);
+    return rc;
+  }
+  HostField hf(ctx->fp);
+  pr->c1 = hf.add(pr->first[0], pr->first[1]);
+  *out = pr;
+  return SC_OK;
+}
 
 extern "C" int sc_gkr_prover_create(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
                                     const sc_table* w_c, sc_gkr_prover** out) {
@@ -1732,6 +1831,27 @@ extern "C" int sc_gkr_prover_round(sc_gkr_prover* pr, uint64_t r_prev, size_t j,
     return SC_OK;
   }
   if (r_prev >= ctx->fp.p) return fail(ctx, SC_ERR_ARG, "sc_gkr_prover_round: challenge is not reduced");
+  if (pr->sparse) {
+    // fold the small table that owns variable j-1; the gate values are folded inside the kernel
+    const bool in_b = pr->kb >= 1;
+    u64* nw = nullptr;
+    size_t l3 = 0;
+    SC_TRY(fold_chain(ctx, in_b ? pr->w_b : pr->w_c, (size_t)1 << (in_b ? pr->kb : pr->kc), &r_prev, 1, SC_ORDER_LE, &nw, &l3));
+    if (in_b) {
+      pool_release(ctx, pr->own_wb);
+      pr->own_wb = nw;
+      pr->w_b = nw;
+      pr->kb -= 1;
+    } else {
+      pool_release(ctx, pr->own_wc);
+      pr->own_wc = nw;
+      pr->w_c = nw;
+      pr->kc -= 1;
+    }
+    SC_TRY(gkr_sparse_round(pr, (int)j, r_prev, out_e));
+    pr->next_round = j + 1;
+    return SC_OK;
+  }
   // W::fix_variables(&[r_prev]) (round_polynomial.rs:59-76)
   const size_t len = (size_t)1 << (pr->kb + pr->kc);
   u64 *na = nullptr, *nm = nullptr, *nw = nullptr;
@@ -1776,6 +1896,8 @@ extern "C" int sc_gkr_prover_destroy(sc_gkr_prover* pr) {
   pool_release(pr->ctx, pr->own_mul);
   pool_release(pr->ctx, pr->own_wb);
   pool_release(pr->ctx, pr->own_wc);
+  pool_release(pr->ctx, pr->sp_words);
+  pool_release(pr->ctx, pr->sp_val);
   delete pr;
   return SC_OK;
 }
@@ -1810,18 +1932,6 @@ int check_tri(const sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const s
   return SC_OK;
 }
 
-sc::PassOut next_pass_out(sc_ctx* ctx, int grid) {
-  sc::PassOut out;
-  out.partials = ctx->d_partials;
-  out.n_rows = (int)ctx->partial_rows;
-  out.ticket = ctx->d_ticket;
-  out.ticket_base = ctx->ticket_base;
-  out.sums_dev = ctx->d_sums;
-  out.mailbox = ctx->use_mailbox ? ctx->d_mailbox : nullptr;
-  out.seq = ctx->use_mailbox ? ++ctx->mailbox_seq : 0;
-  if (grid > 1) ctx->ticket_base += (unsigned)grid;
-  return out;
-}
 
 }  // namespace
 

@@ -173,6 +173,30 @@ def wiring(ctx, circuit, i, r_i):
     return DenseMultilinearExtension(ctx, ha), DenseMultilinearExtension(ctx, hm)
 
 
+class SparseLayerProver(_NativeWProver):
+    """SumCheckProver<F, W<F>> for layer i built straight from the gate list: every round visits the
+    2^k_i gates instead of the 4^k_{i+1} entries of the dense predicate tables (sc_gkr_prover_create_sparse)"""
+
+    def __init__(self, ctx, circuit, evaluation, i, r_i):
+        self.ctx = ctx
+        layer = circuit.layers[i].layer
+        k_i, k_next = circuit.num_vars_at(i), circuit.num_vars_at(i + 1)
+        gt = (ctypes.c_int32 * len(layer))(*[0 if g.ttype == GateType.Add else 1 for g in layer])
+        i0 = (ctypes.c_uint32 * len(layer))(*[g.inputs[0] for g in layer])
+        i1 = (ctypes.c_uint32 * len(layer))(*[g.inputs[1] for g in layer])
+        r = _words(r_i)
+        assert r.size == k_i
+        self._w_next = DenseMultilinearExtension.from_evaluations_vec(ctx, k_next, np.array(evaluation[i + 1], dtype=np.uint64))
+        self._num_vars = 2 * k_next
+        h = voidp()
+        ctx.check(ctx.lib.sc_gkr_prover_create_sparse(ctx.h, gt, i0, i1, k_i, k_next, _u64p(r), self._w_next.h,
+                                                     ctypes.byref(h)))
+        self.h = h
+
+    def num_vars(self):
+        return self._num_vars
+
+
 def start_round_w(ctx, circuit, evaluation, i, r_i):
     """the W polynomial Prover::start_round builds for layer i (gkr-protocol/src/lib.rs:373-423)"""
     k_next = circuit.num_vars_at(i + 1)
