@@ -235,6 +235,11 @@ def main():
         tc = time.perf_counter()
         c1_cpu, ev_cpu = o.prover_run(oa, ob, och)
         cpu_s = time.perf_counter() - tc
+        tc = time.perf_counter()
+        c1_mt, ev_mt = o.prover_run_mt(oa, ob, och)           # second, clearly labelled row: all host cores
+        cpu_mt_s = time.perf_counter() - tc
+        if c1_mt != c1_cpu or not np.array_equal(ev_mt, ev_cpu):
+            raise SystemExit("oracle: multi-threaded and single-threaded runs disagree")
         # the same sample through the GPU path must agree bit for bit
         del a, b, g
         ga = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, nc)
@@ -253,6 +258,8 @@ def main():
                       "reference-shaped single-thread C restatement (clone + multiply + sum for c_1, copy-fold-copy "
                       "per table per round, separate sum pass); the Rust reference cannot be built here" % (
                           nc, 5 * 2**nc - 7, cpu_s),
+            "all_cores": {"value": (5 * 2**nc - 7) / cpu_mt_s, "cores": os.cpu_count(), "seconds": cpu_mt_s,
+                          "note": "same port with the element loops split over OpenMP threads (BASELINE.md CPU-ref-allT)"},
         }
     elif rank == 0:
         result["cpu_baseline"] = None

@@ -87,6 +87,8 @@ class Oracle:
         L.sco_tri_evaluate.restype = u64
         L.sco_tri_prove.argtypes = [FP, u64p, sz, u64p, u64p, u64p, u64p]
         L.sco_tri_prove.restype = ctypes.c_int
+        L.sco_prover_run_mt.argtypes = [FP, u64p, u64p, ctypes.c_size_t, u64p, u64p, u64p]
+        L.sco_prover_run_mt.restype = None
         L.sco_vsbw.argtypes = [FP, u64p, u64p, ctypes.c_size_t]
         L.sco_vsbw.restype = u64
         L.sco_cti.argtypes = [FP, u64p, u64p, ctypes.c_size_t]
@@ -211,6 +213,15 @@ class Oracle:
         c1 = u64(0)
         ev = np.empty((nv, 3), dtype=np.uint64)
         self.lib.sco_prover_run(self.fp, _ptr(a), _ptr(b), nv, _ptr(ch), ctypes.byref(c1), _ptr(ev))
+        return int(c1.value), ev
+
+    def prover_run_mt(self, a, b, challenges):
+        """all-cores (OpenMP) variant of prover_run; identical outputs"""
+        nv = self._nv(a)
+        ch = np.ascontiguousarray(np.asarray(challenges, dtype=np.uint64))
+        c1 = u64(0)
+        ev = np.empty((nv, 3), dtype=np.uint64)
+        self.lib.sco_prover_run_mt(self.fp, _ptr(a), _ptr(b), nv, _ptr(ch), ctypes.byref(c1), _ptr(ev))
         return int(c1.value), ev
 
     def prove(self, a, b, challenges):

@@ -339,6 +339,87 @@ void sco_prover_run(const sco_field* f, const u64* a, const u64* b, size_t nv, c
   free(gb);
 }
 
+/*
+ * All-cores variant of sco_prover_run for the second, clearly labelled CPU row of BASELINE.md
+ * section 4 ("CPU-ref-allT").  Same passes and copies, the element loops split over OpenMP
+ * threads; modular sums are order-independent, so the outputs are identical.  Built with
+ * -fopenmp; without it the pragmas are ignored and this is sco_prover_run.
+ */
+static void mt_fix_one(const sco_field* f, const u64* t, size_t nv, u64 r, u64* out) {
+  size_t half = (size_t)1 << (nv - 1);
+  long b;
+#pragma omp parallel for schedule(static)
+  for (b = 0; b < (long)half; ++b) {
+    u64 left = t[(size_t)b << 1], right = t[((size_t)b << 1) + 1];
+    out[b] = f_add(f, left, f_mul(f, r, f_sub(f, right, left)));
+  }
+}
+static void mt_round_evals(const sco_field* f, const u64* a, const u64* b, size_t nv, u64 e[3]) {
+  size_t pairs = (size_t)1 << (nv - 1);
+  u64 e0 = 0, e1 = 0, e2 = 0;
+#pragma omp parallel
+  {
+    u64 l0 = 0, l1 = 0, l2 = 0;
+    long q;
+#pragma omp for schedule(static) nowait
+    for (q = 0; q < (long)pairs; ++q) {
+      size_t i = ((size_t)q << 1) + 1;
+      l0 = f_add(f, l0, f_mul(f, a[i - 1], b[i - 1]));
+      l1 = f_add(f, l1, f_mul(f, a[i], b[i]));
+      u64 ax = f_sub(f, f_add(f, a[i], a[i]), a[i - 1]), bx = f_sub(f, f_add(f, b[i], b[i]), b[i - 1]);
+      l2 = f_add(f, l2, f_mul(f, ax, bx));
+    }
+#pragma omp critical
+    {
+      e0 = f_add(f, e0, l0);
+      e1 = f_add(f, e1, l1);
+      e2 = f_add(f, e2, l2);
+    }
+  }
+  e[0] = e0; e[1] = e1; e[2] = e2;
+}
+void sco_prover_run_mt(const sco_field* f, const u64* a, const u64* b, size_t nv, const u64* challenges,
+                       u64* c1_out, u64* evals) {
+  size_t len = (size_t)1 << nv;
+  u64* ga = (u64*)malloc(len * sizeof(u64));
+  u64* gb = (u64*)malloc(len * sizeof(u64));
+  long i;
+  u64 c1 = 0;
+#pragma omp parallel
+  {
+    u64 l = 0;
+#pragma omp for schedule(static) nowait
+    for (i = 0; i < (long)len; ++i) {
+      ga[i] = a[i];
+      gb[i] = b[i];
+      l = f_add(f, l, f_mul(f, a[i], b[i]));
+    }
+#pragma omp critical
+    c1 = f_add(f, c1, l);
+  }
+  if (c1_out) *c1_out = c1;
+  size_t cur = nv;
+  for (size_t j = 0; j < nv; ++j) {
+    if (j != 0) {
+      u64* na = (u64*)malloc((len >> j) * sizeof(u64));
+      u64* nb = (u64*)malloc((len >> j) * sizeof(u64));
+      mt_fix_one(f, ga, cur, challenges[j - 1], na);
+      mt_fix_one(f, gb, cur, challenges[j - 1], nb);
+      free(ga);
+      free(gb);
+      ga = na;
+      gb = nb;
+      cur -= 1;
+    }
+    u64 e[3], c[3];
+    mt_round_evals(f, ga, gb, cur, e);
+    sco_interpolate_quadratic(f, e, c);
+    if (evals) memcpy(evals + 3 * j, e, sizeof(e));
+  }
+  free(ga);
+  free(gb);
+}
+
 /* ---- multilinear-extensions crate (BE: r[0] <-> index MSB) ------------------------ */
 
 /* vsbw_multilinear_from_evaluations, multilinear-extensions/src/lib.rs:6-24. */
