@@ -35,6 +35,6 @@ for vpp in vpps:
         ctx.set_option("time_kernels", 0)
         alg = 64 * 2**n - 96
         print("%s vpp=%d n=%d wall=%.3f ms  muladds/s=%.3e  alg GB/s=%.0f  | pass kernels: %d launches %.3f ms -> alg GB/s=%.0f"
-              % (opts, vpp, n, t * 1e3, (5 * 2**n - 7) / t, alg / t / 1e9, nk, kms, alg / (kms * 1e-3) / 1e9), flush=True)
+              % (opts, vpp, n, t * 1e3, (5 * 2**n - 7) / t, alg / t / 1e9, nk, kms, alg / (max(kms, 1e-9) * 1e-3) / 1e9), flush=True)
         del a, b, g
     ctx.close()
