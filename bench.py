@@ -77,6 +77,8 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if os.environ.get("SC_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0  # diagnostic: several ranks share GPU 0 (only meaningful with SC_BENCH_TRANSPORT=host)
     torch.cuda.set_device(local_rank)
 
     pkg = ge.load_package()
@@ -107,11 +109,14 @@ def main():
         # If the communicator cannot be created on some rank, every rank falls back to the
         # host transport (torch.distributed/gloo callbacks) so that the run still completes.
         ok = 1
-        try:
-            D.attach_rccl(ctx, rank, world)
-        except Exception as e:  # pragma: no cover - depends on the node
-            sys.stderr.write("rank %d: RCCL init failed (%s)\n" % (rank, e))
-            ok = 0
+        if os.environ.get("SC_BENCH_TRANSPORT") == "host":
+            ok = 0  # diagnostic: exercise the multi-process path without RCCL
+        else:
+            try:
+                D.attach_rccl(ctx, rank, world)
+            except Exception as e:  # pragma: no cover - depends on the node
+                sys.stderr.write("rank %d: RCCL init failed (%s)\n" % (rank, e))
+                ok = 0
         flag = torch.tensor([ok], dtype=torch.int64)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 1:
