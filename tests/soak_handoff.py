@@ -1,4 +1,4 @@
-"""soak test of the in-kernel hand-off (finish_pass): many back-to-back proofs over instances whose
+"""(run by hand: python tests/soak_handoff.py [proofs]) soak test of the in-kernel hand-off (finish_pass): many back-to-back proofs over instances whose
 partial sums differ, every transcript compared with a precomputed oracle transcript"""
 import sys, os, time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -4,8 +4,8 @@ import sys, time, os
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import __graft_entry__ as ge
 pkg = ge.load_package()
-sys.path.insert(0, os.path.join(ge.ROOT, "oracle"))
-import pyref
+class pyref:  # seeds of the synthetic instance; tools never load oracle/
+    SEED_A, SEED_B, SEED_R, SEED_PT = 0xA5A5000000000001, 0xB6B6000000000002, 0xC7C7000000000003, 0xD8D8000000000004
 mm = pkg.matrix_multiplication
 ns = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else [20, 24, 26, 28]
 vpps = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [1, 2]
