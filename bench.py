@@ -29,7 +29,6 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the pool's driver on
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 
@@ -68,7 +67,6 @@ def main():
     import numpy as np
     import torch
     import __graft_entry__ as ge
-    import pyref
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -82,7 +80,7 @@ def main():
     torch.cuda.set_device(local_rank)
 
     pkg = ge.load_package()
-    mm, D = pkg.matrix_multiplication, pkg.distributed
+    mm, D, syn = pkg.matrix_multiplication, pkg.distributed, pkg.synthetic
     n = args.num_vars
     F = pkg.Field(pkg.GOLDILOCKS)
 
@@ -131,13 +129,12 @@ def main():
             transport = "host(gloo)"
     start, length = D.shard_range(n, rank, world)
     nl = length.bit_length() - 1
-    a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, nl, start=start)
-    b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, nl, start=start)
+    a, b = syn.tables(ctx, nl, start=start)
     g = mm.G(a, b)
     assert g.num_vars() == n
 
     for _ in range(args.warmup):
-        mm.prove(ctx, g, pyref.SEED_R)
+        mm.prove(ctx, g, syn.SEED_R)
 
     ctx.set_option("time_kernels", 1)  # HIP events around every pass kernel, on the library's stream
     ctx.kernel_time(reset=True)
@@ -145,7 +142,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        c1, evals, ch = mm.prove(ctx, g, pyref.SEED_R)
+        c1, evals, ch = mm.prove(ctx, g, syn.SEED_R)
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -232,7 +229,10 @@ def main():
             pass
         args.cpu_num_vars = 28 if avail_gib > 48 else (27 if avail_gib > 20 else 26)
     if rank == 0 and world == 1 and args.cpu_num_vars > 0:
-        from oracle import Oracle
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        from oracle import Oracle   # the checker / CPU baseline: only this leg touches oracle/
+        import pyref
+        assert (pyref.SEED_A, pyref.SEED_B, pyref.SEED_R) == (syn.SEED_A, syn.SEED_B, syn.SEED_R)
         nc = args.cpu_num_vars
         o = Oracle(pkg.GOLDILOCKS)
         oa, ob = o.generate(pyref.SEED_A, nc), o.generate(pyref.SEED_B, nc)
@@ -247,9 +247,8 @@ def main():
             raise SystemExit("oracle: multi-threaded and single-threaded runs disagree")
         # the same sample through the GPU path must agree bit for bit
         del a, b, g
-        ga = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, nc)
-        gb = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, nc)
-        c1_gpu, ev_gpu, ch_gpu = mm.prove(ctx, mm.G(ga, gb), pyref.SEED_R)
+        ga, gb = syn.tables(ctx, nc)
+        c1_gpu, ev_gpu, ch_gpu = mm.prove(ctx, mm.G(ga, gb), syn.SEED_R)
         if c1_gpu != c1_cpu or not np.array_equal(ev_gpu, ev_cpu) or not np.array_equal(ch_gpu, och):
             raise SystemExit("PARITY FAILURE: GPU and CPU oracle disagree at n=%d" % nc)
         result["config"]["parity_gate"] += "; bit-exact vs CPU oracle at n=%d ok" % nc
