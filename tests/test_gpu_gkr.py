@@ -194,3 +194,50 @@ def test_restrict_poly():
             while len(got) > 1 and got[-1] == 0:
                 got.pop()
             assert got == expect, (q, k)
+
+
+def test_wiring_collisions_and_errors():
+    """many gates wired to the same (b, c): the scatter's compare-and-swap path must sum them;
+    malformed gate lists and inconsistent tables are rejected with SC_ERR_ARG"""
+    pkg = load_package()
+    p = GOLD
+    ctx = pkg.Context(pkg.Field(p))
+    F = ctx.field
+    o = oracle(p)
+    gp = pkg.gkr_protocol
+    rng = random.Random(21)
+    k_i, k_next = 7, 2
+    layers = [[(("add" if a % 3 else "mul"), a % 2, 1) for a in range(1 << k_i)]]   # 2 distinct targets
+    circuit = make_circuit(pkg, layers, 1 << k_next)
+    r_i = [F.from_int(rng.randrange(p)) for _ in range(k_i)]
+    add_d, mul_d = gp.wiring(ctx, circuit, 0, r_i)
+    oadd, omul = o.wiring_fixed(layers[0], k_next, r_i)
+    assert np.array_equal(add_d.to_evaluations(), oadd) and np.array_equal(mul_d.to_evaluations(), omul)
+    assert int(np.count_nonzero(oadd)) <= 2 and int(np.count_nonzero(omul)) <= 2
+    inputs = [F.from_int(rng.randrange(p)) for _ in range(1 << k_next)]
+    evaluation = circuit.evaluate(F, inputs)
+    dense, sparse = gp.start_round_w(ctx, circuit, evaluation, 0, r_i).native_prover(), gp.SparseLayerProver(ctx, circuit, evaluation, 0, r_i)
+    ch = [F.from_int(rng.randrange(p)) for _ in range(2 * k_next)]
+    ref = o.w_prove(oadd, omul, np.array(evaluation[1], dtype=np.uint64), np.array(evaluation[1], dtype=np.uint64), ch)
+    assert dense.c1() == sparse.c1() == ref["c_1"]
+    for j in range(2 * k_next):
+        rp = ch[j - 1] if j else F.one
+        e = [int(x) for x in ref["evals"][j]]
+        assert dense.round_evals(rp, j) == e and sparse.round_evals(rp, j) == e
+    # errors
+    bad = make_circuit(pkg, [[("add", 0, 9)] * 4], 4)           # input index out of range
+    with pytest.raises(pkg.SumcheckHipError) as ei:
+        gp.wiring(ctx, bad, 0, [F.one, F.one])
+    assert ei.value.code == 1
+    t4 = pkg.DenseMultilinearExtension.generate(ctx, 1, 4)
+    t3 = pkg.DenseMultilinearExtension.generate(ctx, 2, 3)
+    with pytest.raises(pkg.SumcheckHipError) as ei:
+        gp.W(t4, t4, t3, t3).round_evals()                       # 4 != 3 + 3 variables
+    assert ei.value.code == 1
+    with pytest.raises(pkg.SumcheckHipError) as ei:
+        pkg.triangle_counting.G(t4, t3, t4, 2).round_evals()     # inconsistent copies
+    assert ei.value.code == 1
+    eng = gp.W(t4, t4, pkg.DenseMultilinearExtension.generate(ctx, 3, 2), pkg.DenseMultilinearExtension.generate(ctx, 4, 2)).native_prover()
+    with pytest.raises(pkg.SumcheckHipError) as ei:
+        eng.round_evals(F.one, 2)                                # out of order
+    assert ei.value.code == 5

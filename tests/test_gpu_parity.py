@@ -479,3 +479,23 @@ def test_cpp_host_mirror_runs_reference_tests():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ALL OK" in out.stdout
+
+
+def test_zero_variable_polynomial(pkg):
+    """tables of a single entry: no variable, c_1 is the product, no rounds
+    (Prover::new on a 0-variable G, sum-check-protocol/src/lib.rs:88-97)"""
+    for p in (GOLD, 5):
+        ctx = ctx_for(pkg, p)
+        F = ctx.field
+        a = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 0, F.from_ints([3]))
+        b = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 0, F.from_ints([4]))
+        g = pkg.matrix_multiplication.G(a, b)
+        assert g.num_vars() == 0
+        assert F.to_int(g.hypercube_sum()) == 12 % p
+        assert F.to_ints(g.to_evaluations()) == [12 % p]
+        assert F.to_int(g.evaluate([])) == 12 % p
+        prover = pkg.sum_check_protocol.Prover.new(g.clone())
+        assert F.to_int(prover.c_1()) == 12 % p and prover.num_vars() == 0
+        c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+        assert F.to_int(c1) == 12 % p and len(evals) == 0 and len(ch) == 0
+        assert F.to_ints(a.fix_variables([]).to_evaluations()) == [3]
