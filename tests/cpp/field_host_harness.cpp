@@ -43,6 +43,13 @@ u64 fh_gold_dot(const u64* a, const u64* b, size_t n) {
   for (size_t i = 0; i < n; ++i) F.acc_mac(acc, a[i], b[i]);
   return F.acc_get(acc);
 }
+u64 fh_gold_dot3(const u64* a, const u64* b, size_t n) {
+  GoldilocksMont F;
+  GoldilocksMont::Acc3 acc;
+  F.acc3_zero(acc);
+  for (size_t i = 0; i < n; ++i) F.acc3_mac(acc, a[i], b[i]);
+  return F.acc3_get(acc);
+}
 u64 fh_gen_dot(u64 p, const u64* a, const u64* b, size_t n) {
   FieldParams fp;
   field_params_from_modulus(p, &fp);

@@ -24,6 +24,8 @@ def fh(tmp_path_factory):
     lib.fh_gen_binop.argtypes = [ctypes.c_uint64, ctypes.c_int, u64p, u64p, u64p, ctypes.c_size_t]
     lib.fh_gold_dot.argtypes = [u64p, u64p, ctypes.c_size_t]
     lib.fh_gold_dot.restype = ctypes.c_uint64
+    lib.fh_gold_dot3.argtypes = [u64p, u64p, ctypes.c_size_t]
+    lib.fh_gold_dot3.restype = ctypes.c_uint64
     lib.fh_gen_dot.argtypes = [ctypes.c_uint64, u64p, u64p, ctypes.c_size_t]
     lib.fh_gen_dot.restype = ctypes.c_uint64
     lib.fh_params.argtypes = [ctypes.c_uint64, u64p]
@@ -108,11 +110,13 @@ def test_lazy_accumulator(fh):
         b = _arr([rng.randrange(GOLD) for _ in range(n)])
         exp = sum(int(x) * int(y) for x, y in zip(a, b)) * rinv % GOLD
         assert int(fh.fh_gold_dot(_p(a), _p(b), n)) == exp
+        assert int(fh.fh_gold_dot3(_p(a), _p(b), n)) == exp
     # worst case: every product is (p-1)^2, enough terms to carry into the third word
     n = 300000
     a = np.full(n, GOLD - 1, dtype=np.uint64)
     exp = n * (GOLD - 1) ** 2 * rinv % GOLD
     assert int(fh.fh_gold_dot(_p(a), _p(a), n)) == exp
+    assert int(fh.fh_gold_dot3(_p(a), _p(a), n)) == exp
     for p in (5, 389, 2**64 - 59):
         a = _arr([rng.randrange(p) for _ in range(5000)])
         b = _arr([rng.randrange(p) for _ in range(5000)])

@@ -113,6 +113,10 @@ struct MontGeneric {
   SC_HD void acc_zero(Acc& a) const { a = 0; }
   SC_HD void acc_mac(Acc& a, u64 x, u64 y) const { a = add(a, mul(x, y)); }
   SC_HD u64 acc_get(const Acc& a) const { return a; }
+  typedef u64 Acc3;  // short sums (folds): same thing for a generic modulus
+  SC_HD void acc3_zero(Acc3& a) const { a = 0; }
+  SC_HD void acc3_mac(Acc3& a, u64 x, u64 y) const { a = add(a, mul(x, y)); }
+  SC_HD u64 acc3_get(const Acc3& a) const { return a; }
 };
 
 // ---------------------------------------------------------------------------------
@@ -187,6 +191,58 @@ struct GoldilocksMont {
     u64 y = mp_high(a.w0);                       // < p
     u64 z = ((u64)a.w2 << 32) - (u64)a.w2;       // w2 * (2^32-1) < p
     return add(sub(x, y), z);
+  }
+
+  // Three-class accumulator for short sums of products (folds): the four 32x32 partial
+  // products of x*y are added into three 64-bit words by v_mad_u64_u32 itself
+  // (value = A00 + A01*2^32 + A11*2^64), each with a carry counter:
+  // 4 multiply-adds + 4 add-with-carry per product, no operand shuffling and no carry
+  // chains.  On the host (tests) the same arithmetic in plain C.
+  struct Acc3 {
+    u64 a00, a01, a11;
+    u32 c00, c01, c11;
+  };
+  SC_HD void acc3_zero(Acc3& A) const { A.a00 = A.a01 = A.a11 = 0; A.c00 = A.c01 = A.c11 = 0; }
+  SC_HD void acc3_mac(Acc3& A, u64 x, u64 y) const {
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 s0, s1, s2, s3;  // SGPR pairs receiving the carries; every reader is >= 2 VALU instructions
+                         // behind its writer (the VALU-writes-SGPR -> VALU-reads-as-carry hazard)
+    asm volatile(
+        "v_mad_u64_u32 %0, %6, %10, %12, %0\n\t"
+        "v_mad_u64_u32 %1, %7, %10, %13, %1\n\t"
+        "v_mad_u64_u32 %2, %8, %11, %13, %2\n\t"
+        "v_addc_co_u32_e64 %3, %6, %3, 0, %6\n\t"
+        "v_mad_u64_u32 %1, %9, %11, %12, %1\n\t"
+        "v_addc_co_u32_e64 %4, %7, %4, 0, %7\n\t"
+        "v_addc_co_u32_e64 %5, %8, %5, 0, %8\n\t"
+        "v_addc_co_u32_e64 %4, %9, %4, 0, %9\n\t"
+        : "+v"(A.a00), "+v"(A.a01), "+v"(A.a11), "+v"(A.c00), "+v"(A.c01), "+v"(A.c11), "=&s"(s0), "=&s"(s1),
+          "=&s"(s2), "=&s"(s3)
+        : "v"(x0), "v"(x1), "v"(y0), "v"(y1));
+#else
+    u64 t;
+    bool c;
+    c = __builtin_add_overflow((u64)x0 * y0, A.a00, &t); A.a00 = t; A.c00 += c ? 1u : 0u;
+    c = __builtin_add_overflow((u64)x0 * y1, A.a01, &t); A.a01 = t; A.c01 += c ? 1u : 0u;
+    c = __builtin_add_overflow((u64)x1 * y1, A.a11, &t); A.a11 = t; A.c11 += c ? 1u : 0u;
+    c = __builtin_add_overflow((u64)x1 * y0, A.a01, &t); A.a01 = t; A.c01 += c ? 1u : 0u;
+#endif
+  }
+  // residue of the accumulated sum of products (same value acc_get returns for the same products)
+  SC_HD u64 acc3_get(const Acc3& A) const {
+    // w0 + w1*2^64 + w2*2^128 = a00 + c00*2^64 + (a01 + c01*2^64)*2^32 + (a11 + c11*2^64)*2^64
+    Acc w;
+    u64 t;
+    bool k = __builtin_add_overflow(A.a00, A.a01 << 32, &w.w0);
+    u32 carry = k ? 1u : 0u;
+    t = (A.a01 >> 32) + ((u64)A.c01 << 32);          // < 2^64: c01 < 2^31 for any sum used here
+    k = __builtin_add_overflow(t, (u64)A.c00 + carry, &t);
+    carry = k ? 1u : 0u;
+    k = __builtin_add_overflow(t, A.a11, &w.w1);
+    carry += k ? 1u : 0u;
+    w.w2 = A.c11 + carry;
+    return acc_get(w);
   }
 };
 

@@ -44,11 +44,11 @@ __device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], const FoldW& 
     constexpr int G = 1 << KF;
 #pragma unroll
     for (int b = 0; b < IN / G; ++b) {
-      typename F::Acc acc;
-      f.acc_zero(acc);
+      typename F::Acc3 acc;
+      f.acc3_zero(acc);
 #pragma unroll
-      for (int c = 0; c < G; ++c) f.acc_mac(acc, v[G * b + c], fw.w[c]);
-      v[b] = f.acc_get(acc);
+      for (int c = 0; c < G; ++c) f.acc3_mac(acc, v[G * b + c], fw.w[c]);
+      v[b] = f.acc3_get(acc);
     }
   }
 }
