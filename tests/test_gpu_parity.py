@@ -22,10 +22,18 @@ def pkg():
 _ctxs = {}
 
 
+def schedule_options(vpp):
+    """test shorthand for the prover schedule: 1 = one round per pass; 2 = two rounds per pass;
+    3 = two rounds per pass and a three-round first pass (the library default)"""
+    return {"vars_per_pass": min(vpp, 2), "first_pass_vars": 3 if vpp == 3 else min(vpp, 2)}
+
+
 def ctx_for(pkg, p, **opts):
     key = (p, tuple(sorted(opts.items())))
     if key not in _ctxs:
         c = pkg.Context(pkg.Field(p))
+        if "vars_per_pass" in opts:
+            opts = dict(opts, **schedule_options(opts["vars_per_pass"]))
         for k, v in opts.items():
             c.set_option(k, v)
         _ctxs[key] = c
@@ -64,7 +72,7 @@ def run_python_protocol(pkg, ctx, g, ch):
 
 # ---- golden transcripts -------------------------------------------------------------------
 
-@pytest.mark.parametrize("vpp", [1, 2])
+@pytest.mark.parametrize("vpp", [1, 2, 3])
 @pytest.mark.parametrize("entry", load_golden("transcripts.json"), ids=lambda e: "%s-n%d" % (pid(e["p"]), e["n"]))
 def test_golden_transcripts(pkg, entry, vpp):
     p, n = entry["p"], entry["n"]
@@ -96,7 +104,7 @@ def test_golden_transcripts(pkg, entry, vpp):
 
 # ---- GPU vs C oracle on seeded inputs -----------------------------------------------------
 
-@pytest.mark.parametrize("vpp", [1, 2])
+@pytest.mark.parametrize("vpp", [1, 2, 3])
 @pytest.mark.parametrize("p", [GOLD] + TOY_MODULI + [2**64 - 59], ids=pid)
 def test_prover_vs_oracle_sizes(pkg, p, vpp):
     ctx = ctx_for(pkg, p, vars_per_pass=vpp)
@@ -410,7 +418,7 @@ def _check_round_identities(F, c1, evals, ch, final_eval):
     assert claim == final_eval
 
 
-@pytest.mark.parametrize("n,vpp", [(24, 2), (26, 2), (26, 1), (28, 2), (28, 1), (30, 2)])
+@pytest.mark.parametrize("n,vpp", [(24, 2), (24, 3), (26, 2), (26, 1), (28, 2), (28, 3), (28, 1), (30, 3)])
 def test_full_size_identities(pkg, n, vpp):
     ctx = ctx_for(pkg, GOLD, vars_per_pass=vpp)
     F = ctx.field
@@ -421,7 +429,7 @@ def test_full_size_identities(pkg, n, vpp):
     final = g.evaluate([int(x) for x in ch])
     _check_round_identities(F, c1, evals, ch, final)
     # the two schedules agree bit for bit
-    other = ctx_for(pkg, GOLD, vars_per_pass=3 - vpp)
+    other = ctx_for(pkg, GOLD, vars_per_pass=1 if vpp > 1 else 3)
     if n <= 26:
         a2 = pkg.DenseMultilinearExtension.generate(other, pyref.SEED_A, n)
         b2 = pkg.DenseMultilinearExtension.generate(other, pyref.SEED_B, n)

@@ -56,7 +56,8 @@ def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove"):
         try:
             ctx = pkg.Context(pkg.Field(p))
             ctx.set_option("tail_log", tail_log)
-            ctx.set_option("vars_per_pass", vpp)
+            ctx.set_option("vars_per_pass", min(vpp, 2))
+            ctx.set_option("first_pass_vars", 3 if vpp == 3 else min(vpp, 2))
             ar, ag = lb.collectives(rank)
             ctx.comm_init_host(rank, world, ar, ag)
             start, length = pkg.distributed.shard_range(n, rank, world)
@@ -86,7 +87,7 @@ def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove"):
     return results, lb
 
 
-@pytest.mark.parametrize("vpp", [1, 2])
+@pytest.mark.parametrize("vpp", [1, 2, 3])
 @pytest.mark.parametrize("world", [2, 4, 8])
 @pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
 def test_virtual_ranks_match_oracle(p, world, vpp):

@@ -7,7 +7,7 @@
 //
 //   GoldilocksMont - p = 2^64 - 2^32 + 1.  p^-1 = 2^32 + 1 (mod 2^64), so the Montgomery
 //                    reduction is shifts/adds only, and sums of products are accumulated
-//                    unreduced in 160 bits (one reduction per thread, not per product).
+//                    unreduced in a signed 128-bit word (2^96 = -1 mod p; one reduction per thread, not per product).
 //   MontGeneric    - any odd p < 2^64 with runtime constants (toy moduli 5 / 389 / 1572869
 //                    used by the reference's tests); every product is reduced.
 //
@@ -168,29 +168,41 @@ struct GoldilocksMont {
   SC_HD u64 from_mont(u64 m) const { return redc(0, m); }
   SC_HD u64 reduce_word(u64 z) const { return z >= P ? z - P : z; }
 
-  // Unreduced sum of up to 2^32 128-bit products: w0 + w1*2^64 + w2*2^128.
+  // (w2*2^128 + w1*2^64 + w0) * 2^-64 mod p  =  w1 - floor(m p / 2^64) + w2 * 2^64  (mod p)
+  SC_HD u64 wide_get(u64 w0, u64 w1, u32 w2) const {
+    u64 x = reduce_word(w1);
+    u64 y = mp_high(w0);                     // < p
+    u64 z = ((u64)w2 << 32) - (u64)w2;       // w2 * (2^32-1) < p
+    return add(sub(x, y), z);
+  }
+
+  // Unreduced sum of up to 2^31 products in FOUR registers.  2^96 == -1 (mod p), so a 128-bit
+  // product x*y = L + H*2^96 (L = its low 96 bits, H < 2^32) is congruent to L - H: a 128-bit
+  // two's-complement accumulator takes 2^31 such terms (|sum| < 2^127) and needs no carry word -
+  // one register and about a third of the add-with-carry work less than a 160-bit sum.
   struct Acc {
-    u64 w0, w1;
-    u32 w2;
+    u64 lo, hi;
   };
-  SC_HD void acc_zero(Acc& a) const { a.w0 = 0; a.w1 = 0; a.w2 = 0; }
+  SC_HD void acc_zero(Acc& a) const { a.lo = 0; a.hi = 0; }
   SC_HD void acc_mac(Acc& a, u64 x, u64 y) const {
     u64 hi, lo;
     mul_wide(x, y, hi, lo);
     typedef unsigned __int128 u128;
-    const u128 prod = ((u128)hi << 64) | lo;
-    u128 sum;
-    const bool c = __builtin_add_overflow(((u128)a.w1 << 64) | a.w0, prod, &sum);
-    a.w0 = (u64)sum;
-    a.w1 = (u64)(sum >> 64);
-    a.w2 += c ? 1u : 0u;
+    u128 s = ((u128)a.hi << 64) | a.lo;
+    s += ((u128)(hi & 0xFFFFFFFFull) << 64) | lo;  // + L
+    s -= (u128)(hi >> 32);                         // - H
+    a.lo = (u64)s;
+    a.hi = (u64)(s >> 64);
   }
-  // (w2*2^128 + w1*2^64 + w0) * 2^-64 mod p  =  w1 - floor(m p / 2^64) + w2 * 2^64  (mod p)
+  // residue of (accumulated value) * 2^-64
   SC_HD u64 acc_get(const Acc& a) const {
-    u64 x = reduce_word(a.w1);
-    u64 y = mp_high(a.w0);                       // < p
-    u64 z = ((u64)a.w2 << 32) - (u64)a.w2;       // w2 * (2^32-1) < p
-    return add(sub(x, y), z);
+    // value = L' + T*2^96 == L' - T, L' = low 96 bits, T = top 32 bits as a signed integer
+    const int64_t T = (int64_t)(int32_t)(u32)(a.hi >> 32);
+    const u64 t = (T > 0) ? P - (u64)T : (u64)(-T);  // -T mod p, in [0, p)
+    u64 w0;
+    const bool c = __builtin_add_overflow(a.lo, t, &w0);
+    const u64 w1 = (a.hi & 0xFFFFFFFFull) + (c ? 1u : 0u);
+    return wide_get(w0, w1, 0);
   }
 
   // Three-class accumulator for short sums of products (folds): the four 32x32 partial
@@ -232,17 +244,16 @@ struct GoldilocksMont {
   // residue of the accumulated sum of products (same value acc_get returns for the same products)
   SC_HD u64 acc3_get(const Acc3& A) const {
     // w0 + w1*2^64 + w2*2^128 = a00 + c00*2^64 + (a01 + c01*2^64)*2^32 + (a11 + c11*2^64)*2^64
-    Acc w;
+    u64 w0, w1;
     u64 t;
-    bool k = __builtin_add_overflow(A.a00, A.a01 << 32, &w.w0);
+    bool k = __builtin_add_overflow(A.a00, A.a01 << 32, &w0);
     u32 carry = k ? 1u : 0u;
     t = (A.a01 >> 32) + ((u64)A.c01 << 32);          // < 2^64: c01 < 2^31 for any sum used here
     k = __builtin_add_overflow(t, (u64)A.c00 + carry, &t);
     carry = k ? 1u : 0u;
-    k = __builtin_add_overflow(t, A.a11, &w.w1);
+    k = __builtin_add_overflow(t, A.a11, &w1);
     carry += k ? 1u : 0u;
-    w.w2 = A.c11 + carry;
-    return acc_get(w);
+    return wide_get(w0, w1, A.c11 + carry);
   }
 };
 

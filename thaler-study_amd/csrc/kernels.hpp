@@ -16,7 +16,7 @@ namespace sc {
 
 constexpr int kBlock = 256;        // 4 waves per workgroup
 constexpr int kWave = 64;
-constexpr int kMaxSums = 9;
+constexpr int kMaxSums = 27;      // 3^3 grid cells of a three-round pass
 
 typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 
@@ -60,6 +60,16 @@ __device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], const FoldW& 
 // (matrix-multiplication/src/lib.rs:116-120 evaluates at 0, 1, 2 directly).
 //  KS = 1: acc[0..2] = H(0), H(1), H(inf)
 //  KS = 2: acc[3u+v] = sum a(u,v)*b(u,v), (u,v) in {0,1,inf}^2, u on index bit 0, v on bit 1
+// one 2x2 slice (index bits u, v) -> its nine extension values in {0,1,inf}^2
+template <class F>
+__device__ __forceinline__ void extend_quad(const F& f, const u64 t0, const u64 t1, const u64 t2, const u64 t3,
+                                            u64 (&e)[3][3]) {
+  e[0][0] = t0; e[1][0] = t1; e[2][0] = f.sub(t1, t0);
+  e[0][1] = t2; e[1][1] = t3; e[2][1] = f.sub(t3, t2);
+#pragma unroll
+  for (int u = 0; u < 3; ++u) e[u][2] = f.sub(e[u][1], e[u][0]);
+}
+
 template <class F, int KS>
 __device__ __forceinline__ void accumulate_run(const F& f, typename F::Acc* acc, const u64* a,
                                                const u64* b) {
@@ -67,26 +77,38 @@ __device__ __forceinline__ void accumulate_run(const F& f, typename F::Acc* acc,
     f.acc_mac(acc[0], a[0], b[0]);
     f.acc_mac(acc[1], a[1], b[1]);
     f.acc_mac(acc[2], f.sub(a[1], a[0]), f.sub(b[1], b[0]));
-  } else {
+  } else if constexpr (KS == 2) {
     u64 ea[3][3], eb[3][3];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      ea[0][h] = a[2 * h];
-      ea[1][h] = a[2 * h + 1];
-      ea[2][h] = f.sub(a[2 * h + 1], a[2 * h]);
-      eb[0][h] = b[2 * h];
-      eb[1][h] = b[2 * h + 1];
-      eb[2][h] = f.sub(b[2 * h + 1], b[2 * h]);
-    }
-#pragma unroll
-    for (int u = 0; u < 3; ++u) {
-      ea[u][2] = f.sub(ea[u][1], ea[u][0]);
-      eb[u][2] = f.sub(eb[u][1], eb[u][0]);
-    }
+    extend_quad(f, a[0], a[1], a[2], a[3], ea);
+    extend_quad(f, b[0], b[1], b[2], b[3], eb);
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
       for (int v = 0; v < 3; ++v) f.acc_mac(acc[3 * u + v], ea[u][v], eb[u][v]);
+  }
+}
+
+// KS = 3: acc[(3u + v)*3 + w] over octets, index bits (u, v, w) = (0, 1, 2), one w-slice at a
+// time: w = 0 (entries 0..3), w = inf (entries 4..7 minus 0..3), w = 1 (entries 4..7), so that
+// only two 3x3 extension blocks are live beside the 27 accumulators.
+template <class F>
+__device__ __forceinline__ void accumulate_octet(const F& f, typename F::Acc* acc, const u64* a, const u64* b) {
+#pragma unroll
+  for (int step = 0; step < 3; ++step) {
+    const int w = (step == 0) ? 0 : (step == 1) ? 2 : 1;
+    u64 sa[4], sb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      sa[i] = (w == 0) ? a[i] : (w == 1) ? a[4 + i] : f.sub(a[4 + i], a[i]);
+      sb[i] = (w == 0) ? b[i] : (w == 1) ? b[4 + i] : f.sub(b[4 + i], b[i]);
+    }
+    u64 ea[3][3], eb[3][3];
+    extend_quad(f, sa[0], sa[1], sa[2], sa[3], ea);
+    extend_quad(f, sb[0], sb[1], sb[2], sb[3], eb);
+#pragma unroll
+    for (int u = 0; u < 3; ++u)
+#pragma unroll
+      for (int v = 0; v < 3; ++v) f.acc_mac(acc[(3 * u + v) * 3 + w], ea[u][v], eb[u][v]);
   }
 }
 
@@ -140,7 +162,8 @@ __device__ __forceinline__ void write_split(u64* out, int s, u64 v) {
 template <int NP>
 __device__ __forceinline__ int swz_slot(int q) {
   if constexpr (NP == 1) return q;
-  constexpr int SH = (NP == 2) ? 3 : (NP == 4) ? 2 : 1;  // log2(16 / NP)
+  static_assert(NP == 2 || NP == 4 || NP == 8 || NP == 16, "pieces per lane");
+  constexpr int SH = (NP == 2) ? 3 : (NP == 4) ? 2 : (NP == 8) ? 1 : 0;  // log2(16 / NP)
   const int l = q / NP;
   return (q & ~(NP - 1)) | ((q ^ (l >> SH)) & (NP - 1));
 }
@@ -196,7 +219,7 @@ __device__ __forceinline__ void transpose_to_pieces(ull2* __restrict__ lds, ull2
 //  * publish target: `mailbox` (pinned host memory the host spins on: 2*NS split limbs, then
 //    the sequence word at index kMailboxSeq) or, for the sharded transports that still have
 //    to all-reduce on the device, `sums_dev`.
-constexpr int kMailboxSeq = 24;
+constexpr int kMailboxSeq = 60;   // 2*27 limbs first, the sequence word after them
 struct PassOut {
   u64* partials;
   int n_rows;
@@ -272,14 +295,13 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
   publish_seq(o);
 }
 
-#ifndef SC_PASS_BOUNDS
-#define SC_PASS_BOUNDS __launch_bounds__(kBlock)
-#endif
+// The 27 lazy accumulators of a three-round pass need ~280 registers if the scheduler is left
+// alone (one wave per SIMD); asking for two waves caps it at 256 (a few values park in AGPRs).
 template <class F, int KF, int KS>
-__global__ void SC_PASS_BOUNDS
+__global__ void __launch_bounds__(kBlock)
 pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
             u64* __restrict__ B2, FoldW fw, size_t n_units, PassOut out, int nt_load, int nt_store) {
-  constexpr int IN = 1 << (KF + KS), OUT = 1 << KS, NS = (KS == 1) ? 3 : 9;
+  constexpr int IN = 1 << (KF + KS), OUT = 1 << KS, NS = (KS == 1) ? 3 : (KS == 2) ? 9 : 27;
   constexpr int NP = IN / 2, NPO = OUT / 2;  // 16-byte pieces per lane, in and out
   constexpr int kWaves = kBlock / kWave;
   __shared__ ull2 lds_t[(NP > 1 || NPO > 1) ? kWaves * kWave * NP : 1];
@@ -320,17 +342,43 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
       }
     }
   };
-  auto process_tile = [&](size_t tile, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
-    transpose_to_runs<NP>(my_lds, pa, lane);
-    transpose_to_runs<NP>(my_lds, pb, lane);
-    u64 a[IN], b[IN];
+  // KF = 3: a run is 2^(3+KS) entries; read it back from LDS one output (8 entries) at a time so
+  // that only the staged pieces and OUT folded values are live, not the whole run twice.
+  auto stage_and_fold3 = [&](ull2 (&p)[NP], u64 (&t)[IN]) {
+    if constexpr (KF == 3) {
 #pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      a[2 * k] = pa[k].x; a[2 * k + 1] = pa[k].y;
-      b[2 * k] = pb[k].x; b[2 * k + 1] = pb[k].y;
+    for (int k = 0; k < NP; ++k) my_lds[swz_slot<NP>(64 * k + lane)] = p[k];
+    wave_lds_fence();
+#pragma unroll
+    for (int o = 0; o < OUT; ++o) {
+      u64 v[8];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        const ull2 x = my_lds[swz_slot<NP>(NP * lane + 4 * o + m)];
+        v[2 * m] = x.x; v[2 * m + 1] = x.y;
+      }
+      fold_run<F, 3, 8>(f, v, fw);
+      t[o] = v[0];
     }
-    fold_run<F, KF, IN>(f, a, fw);
-    fold_run<F, KF, IN>(f, b, fw);
+    wave_lds_fence();
+    }
+  };
+  auto process_tile = [&](size_t tile, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
+    u64 a[IN], b[IN];
+    if constexpr (KF == 3) {
+      stage_and_fold3(pa, a);
+      stage_and_fold3(pb, b);
+    } else {
+      transpose_to_runs<NP>(my_lds, pa, lane);
+      transpose_to_runs<NP>(my_lds, pb, lane);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        a[2 * k] = pa[k].x; a[2 * k + 1] = pa[k].y;
+        b[2 * k] = pb[k].x; b[2 * k + 1] = pb[k].y;
+      }
+      fold_run<F, KF, IN>(f, a, fw);
+      fold_run<F, KF, IN>(f, b, fw);
+    }
     if constexpr (KF > 0) {
       ull2 oa[NPO], ob[NPO];
 #pragma unroll
@@ -355,7 +403,8 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
         }
       }
     }
-    accumulate_run<F, KS>(f, acc, a, b);
+    if constexpr (KS == 3) accumulate_octet<F>(f, acc, a, b);
+    else accumulate_run<F, KS>(f, acc, a, b);
   };
 
   const size_t tile_stride = (size_t)gridDim.x * kWaves;
@@ -366,11 +415,27 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     process_tile(tile, pa, pb);
   }
 
-  u64 res[NS];
+  // reduce nine sums at a time (a 27-cell grid would otherwise hold 27 residues next to the
+  // accumulators they come from); thread s ends up with sum s
+  constexpr int CH = (NS < 9) ? NS : 9;
+  u64 mine = 0;
 #pragma unroll
-  for (int s = 0; s < NS; ++s) res[s] = f.acc_get(acc[s]);
-  block_reduce<F, NS>(f, res, lds);
-  finish_pass<F, NS>(f, out, res[0], &lds_flag);
+  for (int c0 = 0; c0 < NS; c0 += CH) {
+    u64 res[CH];
+#pragma unroll
+    for (int s = 0; s < CH; ++s) res[s] = f.acc_get(acc[c0 + s]);
+    if (c0 > 0) __syncthreads();  // the previous chunk's scratch has been read
+    block_reduce<F, CH>(f, res, lds);
+    if ((int)threadIdx.x >= c0 && (int)threadIdx.x < c0 + CH) mine = res[0];
+    if constexpr (NS > CH) {
+      // block_reduce leaves chunk sum s in thread s; hand it to thread c0 + s
+      __syncthreads();
+      if (threadIdx.x < CH) lds[threadIdx.x] = res[0];
+      __syncthreads();
+      if ((int)threadIdx.x >= c0 && (int)threadIdx.x < c0 + CH) mine = lds[threadIdx.x - c0];
+    }
+  }
+  finish_pass<F, NS>(f, out, mine, &lds_flag);
 }
 
 // ------------------------------------------------------------------------------------

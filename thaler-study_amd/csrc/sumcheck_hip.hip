@@ -92,6 +92,10 @@ struct sc_ctx {
 
   // options
   int vars_per_pass = 2;
+  // rounds served by the first pass (which folds nothing): 1..3, or 0 = by size - three once the
+  // tables outgrow the Infinity Cache (the 27-cell grid costs ALU time, it saves a quarter of the
+  // later traffic), two below
+  int first_pass_vars = 0;
   int tail_log = 12;
   int max_blocks = 2048;
   int time_kernels = 0;
@@ -308,10 +312,13 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
   switch (kf * 4 + ks) {
     case 0 * 4 + 1: SC_PASS(0, 1); break;
     case 0 * 4 + 2: SC_PASS(0, 2); break;
+    case 0 * 4 + 3: SC_PASS(0, 3); break;
     case 1 * 4 + 1: SC_PASS(1, 1); break;
     case 1 * 4 + 2: SC_PASS(1, 2); break;
     case 2 * 4 + 1: SC_PASS(2, 1); break;
     case 2 * 4 + 2: SC_PASS(2, 2); break;
+    case 3 * 4 + 1: SC_PASS(3, 1); break;
+    case 3 * 4 + 2: SC_PASS(3, 2); break;
     default: break;
   }
 #undef SC_PASS
@@ -322,7 +329,7 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
 // still have to be all-reduced on the device (RCCL transport).
 int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, const u64* r,
                 int log_in, bool across_ranks, bool* from_mailbox) {
-  if (kf < 0 || kf > 2 || ks < 1 || ks > 2 || log_in < kf + ks)
+  if (kf < 0 || kf > 3 || ks < 1 || ks > 3 || (ks == 3 && kf != 0) || log_in < kf + ks)
     return fail(ctx, SC_ERR_ARG, "launch_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
   const sc::FoldW fw = make_fold_weights(ctx, r, kf);
   size_t n_units = (size_t)1 << (log_in - kf - ks);
@@ -716,7 +723,7 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
   SC_CREATE_HIP(hipSetDevice(device));
   SC_CREATE_HIP(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking));
   ctx->partial_rows = 4096;
-  SC_CREATE_HIP(hipMalloc(&ctx->d_partials, ctx->partial_rows * 16 * sizeof(u64)));
+  SC_CREATE_HIP(hipMalloc(&ctx->d_partials, ctx->partial_rows * 32 * sizeof(u64)));
   SC_CREATE_HIP(hipMalloc(&ctx->d_sums, 64 * sizeof(u64)));
   SC_CREATE_HIP(hipHostMalloc(&ctx->h_sums, 64 * sizeof(u64), hipHostMallocDefault));
   SC_CREATE_HIP(hipMalloc(&ctx->d_ticket, 64));
@@ -761,6 +768,9 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
   if (k == "vars_per_pass") {
     if (value != 1 && value != 2) return fail(ctx, SC_ERR_ARG, "vars_per_pass must be 1 or 2");
     ctx->vars_per_pass = (int)value;
+  } else if (k == "first_pass_vars") {
+    if (value < 0 || value > 3) return fail(ctx, SC_ERR_ARG, "first_pass_vars must be 0 (auto), 1, 2 or 3");
+    ctx->first_pass_vars = (int)value;
   } else if (k == "tail_log") {
     if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "tail_log out of range");
     ctx->tail_log = (int)value;
@@ -785,6 +795,7 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   if (!ctx || !key || !value) return SC_ERR_ARG;
   std::string k(key);
   if (k == "vars_per_pass") *value = ctx->vars_per_pass;
+  else if (k == "first_pass_vars") *value = ctx->first_pass_vars;
   else if (k == "tail_log") *value = ctx->tail_log;
   else if (k == "max_blocks") *value = ctx->max_blocks;
   else if (k == "time_kernels") *value = ctx->time_kernels;
@@ -1282,8 +1293,8 @@ extern "C" int sc_prod2_evaluate(sc_ctx* ctx, const sc_table* a, const sc_table*
 //
 // Schedule.  The reference folds one variable and re-sums every round
 // (sum-check-protocol/src/lib.rs:105-112).  Here one device pass serves up to two rounds:
-// it folds the (<= 2) challenges received since the previous pass and accumulates the 3x3
-// grid S[u][v] of the folded tables.  Round j is H(u) = S[u][0] + S[u][1]; round j+1,
+// it folds the (<= 3) challenges received since the previous pass and accumulates the 3x3
+// grid S[u][v] of the folded tables (3x3x3 for the first pass, which has nothing to fold).  Round j is H(u) = S[u][0] + S[u][1]; round j+1,
 // once r_j is known, is H'(v) = sum_u L_u(r_j) S[u][v] with the Lagrange basis on {0,1,2}
 // - exact field identities, so every round polynomial equals the reference's bit for bit.
 struct sc_prover {
@@ -1302,18 +1313,25 @@ struct sc_prover {
   // cache of the last pass
   int cache_ks = 0;
   size_t cache_round = 0;
-  u64 S[9];
+  u64 S[27];
   u64 c1 = 0;
 };
 
 namespace {
 
+constexpr int kFirstPass3Log = 27;  // 2 tables x 2^27 x 8 B = 2 GiB, far beyond the 256 MiB MALL
+
 int prover_pass(sc_prover* pr, size_t j) {
   sc_ctx* ctx = pr->ctx;
   const int kf = (int)pr->pending.size();
   const size_t remaining = pr->num_vars - j;  // variables left including round j's
-  const int ks = (ctx->vars_per_pass == 2 && remaining >= 2) ? 2 : 1;
-  if (kf > 2) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges", kf);
+  int ks = (ctx->vars_per_pass == 2 && remaining >= 2) ? 2 : 1;
+  if (j == 0 && kf == 0) {
+    const int first = ctx->first_pass_vars ? ctx->first_pass_vars : (pr->cur_log >= kFirstPass3Log ? 3 : 2);
+    if (ctx->vars_per_pass == 2 && remaining >= 3 && first == 3) ks = 3;
+    if (first < ks) ks = first;
+  }
+  if (kf > 3) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges", kf);
 
   // Sharded: pairs (2b, 2b+1) stay shard-local while the local table still has the kf+ks
   // variables this pass touches; below tail_log the latency of a collective per pass costs
@@ -1351,7 +1369,7 @@ int prover_pass(sc_prover* pr, size_t j) {
   }
   bool mb = false;
   int rc = launch_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, pr->pending.data(), pr->cur_log, pr->sharded, &mb);
-  if (rc == SC_OK) rc = collect_sums(ctx, ks == 1 ? 3 : 9, pr->sharded, mb, pr->S);
+  if (rc == SC_OK) rc = collect_sums(ctx, ks == 1 ? 3 : ks == 2 ? 9 : 27, pr->sharded, mb, pr->S);
   if (rc != SC_OK) {
     pool_release(ctx, na);
     pool_release(ctx, nb);
@@ -1372,43 +1390,50 @@ int prover_pass(sc_prover* pr, size_t j) {
   return SC_OK;
 }
 
-// answer round j from the cache (which must cover it).  The cache is in the {0,1,inf} basis.
+// answer round j from the cache (which must cover it).  The cache is the grid of the last pass
+// in the {0,1,inf} basis, first variable on the slowest axis: S[(3u + v)*3 + w] for a
+// three-round pass.  For each fixed value of the other axes a line along the leading axis is a
+// quadratic q(X) = s0 + X (s1 - s0 - sinf) + X^2 sinf; the challenges received since the pass
+// collapse the leading axes one by one, the round's variable is the next axis, and the axes
+// after it are summed over {0,1}.
 void prover_answer(const sc_prover* pr, size_t j, u64 e[3]) {
   HostField hf(pr->ctx->fp);
-  u64 h0, h1, hinf;
-  if (pr->cache_ks == 1) {
-    h0 = pr->S[0];
-    h1 = pr->S[1];
-    hinf = pr->S[2];
-  } else if (j == pr->cache_round) {
-    // first round of the pass: sum the second variable over {0,1}
-    h0 = hf.add(pr->S[0], pr->S[1]);
-    h1 = hf.add(pr->S[3], pr->S[4]);
-    hinf = hf.add(pr->S[6], pr->S[7]);
-  } else {
-    // second round: for each v the grid column is a quadratic in the first variable,
-    // q_v(X) = S[0][v] + X (S[1][v] - S[0][v] - S[inf][v]) + X^2 S[inf][v]; evaluate at r
-    const u64 r = pr->pending[0];
+  u64 g[27];
+  int cells = 1;
+  for (int i = 0; i < pr->cache_ks; ++i) cells *= 3;
+  for (int i = 0; i < cells; ++i) g[i] = pr->S[i];
+  const int known = (int)(j - pr->cache_round);  // == pr->pending.size()
+  for (int i = 0; i < known; ++i) {
+    const u64 r = pr->pending[i];
     const u64 r2 = hf.mul(r, r);
-    u64 q[3];
-    for (int v = 0; v < 3; ++v) {
-      const u64 s0 = pr->S[v], s1 = pr->S[3 + v], si = pr->S[6 + v];
+    cells /= 3;
+    for (int c = 0; c < cells; ++c) {
+      const u64 s0 = g[c], s1 = g[cells + c], si = g[2 * cells + c];
       const u64 lin = hf.sub(hf.sub(s1, s0), si);
-      q[v] = hf.add(hf.add(s0, hf.mul(r, lin)), hf.mul(r2, si));
+      g[c] = hf.add(hf.add(s0, hf.mul(r, lin)), hf.mul(r2, si));
     }
-    h0 = q[0];
-    h1 = q[1];
-    hinf = q[2];
   }
-  e[0] = h0;
-  e[1] = h1;
-  e[2] = eval2_from_inf(hf, h0, h1, hinf);
+  const int rest = cells / 3;  // cells per value of the round's variable
+  u64 h[3];
+  for (int x = 0; x < 3; ++x) {
+    u64 t = 0;
+    for (int c = 0; c < rest; ++c) {
+      // keep the cells whose remaining axes are all in {0,1}
+      bool boolean = true;
+      for (int d = c; d > 0; d /= 3) boolean = boolean && (d % 3 != 2);
+      if (boolean) t = hf.add(t, g[x * rest + c]);
+    }
+    h[x] = t;
+  }
+  e[0] = h[0];
+  e[1] = h[1];
+  e[2] = eval2_from_inf(hf, h[0], h[1], h[2]);
 }
 
 bool cache_covers(const sc_prover* pr, size_t j) {
-  if (pr->cache_ks == 0) return false;
-  if (j == pr->cache_round) return pr->pending.empty();
-  return pr->cache_ks == 2 && j == pr->cache_round + 1 && pr->pending.size() == 1;
+  if (pr->cache_ks == 0 || j < pr->cache_round) return false;
+  const size_t known = j - pr->cache_round;
+  return known < (size_t)pr->cache_ks && pr->pending.size() == known;
 }
 
 }  // namespace
