@@ -86,6 +86,9 @@ struct MontGeneric {
     return (a < b) ? d + p : d;
   }
   SC_HD u64 dbl(u64 a) const { return add(a, a); }
+  SC_HD void sub4(u64 (&d)[4], const u64 (&a)[4], const u64 (&b)[4]) const {
+    for (int k = 0; k < 4; ++k) d[k] = sub(a[k], b[k]);
+  }
 
   // (hi:lo) < p * 2^64  ->  (hi:lo) * 2^-64 mod p
   SC_HD u64 redc(u64 hi, u64 lo) const {
@@ -149,6 +152,48 @@ struct GoldilocksMont {
     return d - (bw ? EPS : (u64)0);
   }
   SC_HD u64 dbl(u64 a) const { return add(a, a); }
+  // Four independent differences d[k] = a[k] - b[k] (mod p).  On the device the four borrow
+  // chains are interleaved by hand: gfx950 needs two wait states between a VALU that writes a
+  // carry (SGPR pair / VCC) and the VALU that consumes it, so one subtraction on its own is
+  // 6 instructions + ~4 s_nop from the compiler; four together are 20 instructions, no s_nop.
+  // Per chain: d = a - b (borrow bw); on borrow subtract EPS = 2^32 - 1, i.e. d0 += bw (carry c),
+  // d1 -= bw, d1 += c.
+  SC_HD void sub4(u64 (&d)[4], const u64 (&a)[4], const u64 (&b)[4]) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    u32 d0[4], d1[4];
+    asm("v_sub_co_u32_e64 %0, vcc, %8, %16\n\t"
+        "v_sub_co_u32_e64 %1, s[72:73], %9, %17\n\t"
+        "v_sub_co_u32_e64 %2, s[74:75], %10, %18\n\t"
+        "v_sub_co_u32_e64 %3, s[76:77], %11, %19\n\t"
+        "v_subb_co_u32_e64 %4, vcc, %12, %20, vcc\n\t"
+        "v_subb_co_u32_e64 %5, s[72:73], %13, %21, s[72:73]\n\t"
+        "v_subb_co_u32_e64 %6, s[74:75], %14, %22, s[74:75]\n\t"
+        "v_subb_co_u32_e64 %7, s[76:77], %15, %23, s[76:77]\n\t"
+        "v_addc_co_u32_e64 %0, s[78:79], %0, 0, vcc\n\t"
+        "v_addc_co_u32_e64 %1, s[80:81], %1, 0, s[72:73]\n\t"
+        "v_addc_co_u32_e64 %2, s[82:83], %2, 0, s[74:75]\n\t"
+        "v_addc_co_u32_e64 %3, s[84:85], %3, 0, s[76:77]\n\t"
+        "v_subb_co_u32_e64 %4, vcc, %4, 0, vcc\n\t"
+        "v_subb_co_u32_e64 %5, s[72:73], %5, 0, s[72:73]\n\t"
+        "v_subb_co_u32_e64 %6, s[74:75], %6, 0, s[74:75]\n\t"
+        "v_subb_co_u32_e64 %7, s[76:77], %7, 0, s[76:77]\n\t"
+        "v_addc_co_u32_e64 %4, s[78:79], %4, 0, s[78:79]\n\t"
+        "v_addc_co_u32_e64 %5, s[80:81], %5, 0, s[80:81]\n\t"
+        "v_addc_co_u32_e64 %6, s[82:83], %6, 0, s[82:83]\n\t"
+        "v_addc_co_u32_e64 %7, s[84:85], %7, 0, s[84:85]"
+        : "=&v"(d0[0]), "=&v"(d0[1]), "=&v"(d0[2]), "=&v"(d0[3]), "=&v"(d1[0]), "=&v"(d1[1]), "=&v"(d1[2]),
+          "=&v"(d1[3])
+        : "v"((u32)a[0]), "v"((u32)a[1]), "v"((u32)a[2]), "v"((u32)a[3]), "v"((u32)(a[0] >> 32)),
+          "v"((u32)(a[1] >> 32)), "v"((u32)(a[2] >> 32)), "v"((u32)(a[3] >> 32)), "v"((u32)b[0]), "v"((u32)b[1]),
+          "v"((u32)b[2]), "v"((u32)b[3]), "v"((u32)(b[0] >> 32)), "v"((u32)(b[1] >> 32)), "v"((u32)(b[2] >> 32)),
+          "v"((u32)(b[3] >> 32))
+        : "vcc", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85");
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = ((u64)d1[k] << 32) | d0[k];
+#else
+    for (int k = 0; k < 4; ++k) d[k] = sub(a[k], b[k]);
+#endif
+  }
 
   // floor(m * p / 2^64) for the m with m*p == lo (mod 2^64), i.e. m = lo * (2^32+1).
   // m*p = (m - (m>>32)) * 2^64 + (m - (m<<32)); the low word borrows iff m < (m<<32).
@@ -181,27 +226,65 @@ struct GoldilocksMont {
   // two's-complement accumulator takes 2^31 such terms (|sum| < 2^127) and needs no carry word -
   // one register and about a third of the add-with-carry work less than a 160-bit sum.
   struct Acc {
-    u64 lo, hi;
+    u32 l0, l1, l2, l3;  // little-endian 32-bit limbs of the two's-complement sum
   };
-  SC_HD void acc_zero(Acc& a) const { a.lo = 0; a.hi = 0; }
+  SC_HD void acc_zero(Acc& a) const { a.l0 = a.l1 = a.l2 = a.l3 = 0; }
   SC_HD void acc_mac(Acc& a, u64 x, u64 y) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // 4 multiplies + 11 add/subtract-with-carry, scheduled by hand: with x = (x1:x0), y = (y1:y0),
+    //   t = x0*y0 (weight 1), m = x0*y1 + x1*y0 (weight 2^32, carry sC at 2^96), q = x1*y1 (2^64);
+    //   chain A adds t and q0, chain B adds m, chain C subtracts H = q1 + sC at weight 1.
+    // gfx950 wants two wait states between a VALU writing an SGPR/VCC and a VALU reading it; the
+    // three carry chains (each limb update is an independent wrap-around add or subtract, so
+    // they commute) are interleaved so that every consumer sits three slots after its producer:
+    // 15 instructions, no s_nop.  The compiler's own sequence for the same arithmetic is ~17
+    // instructions + ~6 s_nop.
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
+    u64 t, m, q, sC, sB, sD;
+    asm("v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
+        "v_mad_u64_u32 %1, %3, %5, %6, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %6, 0\n\t"
+        "v_mad_u64_u32 %2, vcc, %5, %7, 0"
+        : "=&v"(t), "=&v"(m), "=&v"(q), "=&s"(sC)
+        : "v"(x0), "v"(x1), "v"(y0), "v"(y1)
+        : "vcc");
+    const u32 t0 = (u32)t, t1 = (u32)(t >> 32), m0 = (u32)m, m1 = (u32)(m >> 32), q0 = (u32)q,
+              q1 = (u32)(q >> 32);
+    asm("v_subb_co_u32_e64 %0, %5, %0, %11, %12\n\t"    // C1  l0 -= q1 + sC
+        "v_add_co_u32_e32 %0, vcc, %0, %6\n\t"          // A1  l0 += t0
+        "v_add_co_u32_e64 %1, %4, %1, %8\n\t"           // B1  l1 += m0
+        "v_subb_co_u32_e64 %1, %5, %1, 0, %5\n\t"       // C2  l1 -= b
+        "v_addc_co_u32_e32 %1, vcc, %1, %7, vcc\n\t"    // A2  l1 += t1 + c
+        "v_addc_co_u32_e64 %2, %4, %2, %9, %4\n\t"      // B2  l2 += m1 + c
+        "v_subb_co_u32_e64 %2, %5, %2, 0, %5\n\t"       // C3  l2 -= b
+        "v_addc_co_u32_e32 %2, vcc, %2, %10, vcc\n\t"   // A3  l2 += q0 + c
+        "v_addc_co_u32_e64 %3, %4, %3, 0, %4\n\t"       // B3  l3 += c
+        "v_subb_co_u32_e64 %3, %5, %3, 0, %5\n\t"       // C4  l3 -= b
+        "v_addc_co_u32_e32 %3, vcc, 0, %3, vcc"          // A4  l3 += c
+        : "+v"(a.l0), "+v"(a.l1), "+v"(a.l2), "+v"(a.l3), "=&s"(sB), "=&s"(sD)
+        : "v"(t0), "v"(t1), "v"(m0), "v"(m1), "v"(q0), "v"(q1), "s"(sC)
+        : "vcc");
+#else
     u64 hi, lo;
     mul_wide(x, y, hi, lo);
     typedef unsigned __int128 u128;
-    u128 s = ((u128)a.hi << 64) | a.lo;
+    u128 s = ((u128)a.l3 << 96) | ((u128)a.l2 << 64) | ((u128)a.l1 << 32) | a.l0;
     s += ((u128)(hi & 0xFFFFFFFFull) << 64) | lo;  // + L
     s -= (u128)(hi >> 32);                         // - H
-    a.lo = (u64)s;
-    a.hi = (u64)(s >> 64);
+    a.l0 = (u32)s;
+    a.l1 = (u32)(s >> 32);
+    a.l2 = (u32)(s >> 64);
+    a.l3 = (u32)(s >> 96);
+#endif
   }
   // residue of (accumulated value) * 2^-64
   SC_HD u64 acc_get(const Acc& a) const {
-    // value = L' + T*2^96 == L' - T, L' = low 96 bits, T = top 32 bits as a signed integer
-    const int64_t T = (int64_t)(int32_t)(u32)(a.hi >> 32);
+    // value = L' + T*2^96 == L' - T, L' = low 96 bits, T = top limb as a signed integer
+    const int64_t T = (int64_t)(int32_t)a.l3;
     const u64 t = (T > 0) ? P - (u64)T : (u64)(-T);  // -T mod p, in [0, p)
     u64 w0;
-    const bool c = __builtin_add_overflow(a.lo, t, &w0);
-    const u64 w1 = (a.hi & 0xFFFFFFFFull) + (c ? 1u : 0u);
+    const bool c = __builtin_add_overflow(((u64)a.l1 << 32) | a.l0, t, &w0);
+    const u64 w1 = (u64)a.l2 + (c ? 1u : 0u);
     return wide_get(w0, w1, 0);
   }
 

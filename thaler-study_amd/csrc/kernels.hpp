@@ -64,10 +64,13 @@ __device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], const FoldW& 
 template <class F>
 __device__ __forceinline__ void extend_quad(const F& f, const u64 t0, const u64 t1, const u64 t2, const u64 t3,
                                             u64 (&e)[3][3]) {
-  e[0][0] = t0; e[1][0] = t1; e[2][0] = f.sub(t1, t0);
-  e[0][1] = t2; e[1][1] = t3; e[2][1] = f.sub(t3, t2);
-#pragma unroll
-  for (int u = 0; u < 3; ++u) e[u][2] = f.sub(e[u][1], e[u][0]);
+  // e[u][v], u on index bit 0, v on bit 1; four of the five differences depend on the inputs only
+  const u64 hi[4] = {t1, t3, t2, t3}, lo[4] = {t0, t2, t0, t1};
+  u64 d[4];
+  f.sub4(d, hi, lo);
+  e[0][0] = t0; e[1][0] = t1; e[2][0] = d[0];
+  e[0][1] = t2; e[1][1] = t3; e[2][1] = d[1];
+  e[0][2] = d[2]; e[1][2] = d[3]; e[2][2] = f.sub(d[1], d[0]);
 }
 
 template <class F, int KS>
@@ -97,10 +100,17 @@ __device__ __forceinline__ void accumulate_octet(const F& f, typename F::Acc* ac
   for (int step = 0; step < 3; ++step) {
     const int w = (step == 0) ? 0 : (step == 1) ? 2 : 1;
     u64 sa[4], sb[4];
+    if (w == 2) {
+      const u64 ah[4] = {a[4], a[5], a[6], a[7]}, al[4] = {a[0], a[1], a[2], a[3]};
+      const u64 bh[4] = {b[4], b[5], b[6], b[7]}, bl[4] = {b[0], b[1], b[2], b[3]};
+      f.sub4(sa, ah, al);
+      f.sub4(sb, bh, bl);
+    } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      sa[i] = (w == 0) ? a[i] : (w == 1) ? a[4 + i] : f.sub(a[4 + i], a[i]);
-      sb[i] = (w == 0) ? b[i] : (w == 1) ? b[4 + i] : f.sub(b[4 + i], b[i]);
+      for (int i = 0; i < 4; ++i) {
+        sa[i] = a[4 * w + i];
+        sb[i] = b[4 * w + i];
+      }
     }
     u64 ea[3][3], eb[3][3];
     extend_quad(f, sa[0], sa[1], sa[2], sa[3], ea);
@@ -527,7 +537,7 @@ eq_table_kernel(F f, RVec rv, int off, int nbits, u64* __restrict__ out) {
 //   sum_i t[i] * eq(r, i),  eq factored over the index bits as
 //   bit 0 (inside a 16-byte piece) | bits 1..6 (lane) | ta bits (tile within a segment,
 //   weights eqA) | tb bits (segment, weights eqB).
-// Inner sums are unreduced 160-bit accumulations of t * eqA (two per lane, for bit 0 = 0/1);
+// Inner sums are unreduced (lazy) accumulations of t * eqA (two per lane, for bit 0 = 0/1);
 // they are reduced once per chunk of tiles and folded into the outer accumulators with
 // eqB; the bit-0 and lane weights are applied once per thread at the end.  This is the
 // streaming form of vsbw_multilinear_from_evaluations' "eq table, then dot product"
@@ -567,8 +577,24 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
     typename F::Acc a0, a1;
     f.acc_zero(a0);
     f.acc_zero(a1);
-#pragma unroll 8
-    for (int i = 0; i < C; ++i) {
+    // eight loads in flight per lane; written as a fixed-count inner loop because the runtime
+    // unroller does not touch loops that contain inline assembly (acc_mac)
+    int i = 0;
+    for (; i + 8 <= C; i += 8) {
+      ull2 pc[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const size_t q = (tile0 + i + k) * kWave + lane;
+        pc[k] = nt_load ? __builtin_nontemporal_load(Tp + q) : Tp[q];
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u64 w = eqA[in_seg + i + k];
+        f.acc_mac(a0, pc[k].x, w);
+        f.acc_mac(a1, pc[k].y, w);
+      }
+    }
+    for (; i < C; ++i) {
       const size_t q = (tile0 + i) * kWave + lane;
       const ull2 pc = nt_load ? __builtin_nontemporal_load(Tp + q) : Tp[q];
       const u64 w = eqA[in_seg + i];
@@ -615,8 +641,20 @@ coldot_kernel(F f, const u64* __restrict__ T, const u64* __restrict__ w, size_t 
     typename F::Acc a0, a1;
     f.acc_zero(a0);
     f.acc_zero(a1);
-#pragma unroll 4
-    for (size_t i = i0; i < i1; ++i) {
+    size_t i = i0;
+    for (; i + 4 <= i1; i += 4) {  // fixed-count inner loop: see evaluate_kernel
+      ull2 v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        v[k] = nt_load ? __builtin_nontemporal_load(Tp + (i + k) * mp + pc) : Tp[(i + k) * mp + pc];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const u64 wi = w[i + k];
+        f.acc_mac(a0, v[k].x, wi);
+        f.acc_mac(a1, v[k].y, wi);
+      }
+    }
+    for (; i < i1; ++i) {
       const ull2 v = nt_load ? __builtin_nontemporal_load(Tp + i * mp + pc) : Tp[i * mp + pc];
       const u64 wi = w[i];
       f.acc_mac(a0, v.x, wi);
