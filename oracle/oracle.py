@@ -60,6 +60,7 @@ class Oracle:
         L.sco_g_new.argtypes = [FP, ctypes.c_size_t, u64p, u64p, u64p, u64p, u64p]
         L.sco_g_round_evals.argtypes = [FP, u64p, u64p, ctypes.c_size_t, u64p]
         L.sco_g_grid_sums.argtypes = [FP, u64p, u64p, ctypes.c_size_t, u64p]
+        L.sco_g_gridk_sums.argtypes = [FP, u64p, u64p, ctypes.c_size_t, ctypes.c_int, u64p]
         L.sco_interpolate_quadratic.argtypes = [FP, u64p, u64p]
         L.sco_poly2_eval.argtypes = [FP, u64p, u64]
         L.sco_poly2_eval.restype = u64
@@ -182,6 +183,12 @@ class Oracle:
     def grid_sums(self, a, b):
         s = np.empty(9, dtype=np.uint64)
         self.lib.sco_g_grid_sums(self.fp, _ptr(a), _ptr(b), self._nv(a), _ptr(s))
+        return s
+
+    def gridk_sums(self, a, b, k):
+        """3^k-cell grid in the {0,1,inf} basis, first variable on the slowest axis (k = 1, 2, 3)"""
+        s = np.empty(3 ** k, dtype=np.uint64)
+        self.lib.sco_g_gridk_sums(self.fp, _ptr(a), _ptr(b), self._nv(a), k, _ptr(s))
         return s
 
     def interpolate(self, e):

@@ -519,6 +519,34 @@ void sco_g_grid_sums(const sco_field* f, const u64* a, const u64* b, size_t nv, 
   }
 }
 
+/* The same grid for k = 1, 2 or 3 rounds per pass: S has 3^k cells, the first variable (index
+ * bit 0) on the slowest axis - S[(3u + v)*3 + w] for k = 3.  Cell c = (c_0..c_{k-1}), c_d in
+ * {0,1,inf}, holds the sum over blocks of 2^k entries of ext_a(c) * ext_b(c), where ext takes
+ * the entry with bit d = c_d for c_d in {0,1} and the difference (bit d = 1) - (bit d = 0) for
+ * c_d = inf.  Written for clarity, not speed. */
+static u64 grid_ext(const sco_field* f, const u64* t, int k, const int* c, int d, size_t idx) {
+  if (d == k) return t[idx];
+  if (c[d] < 2) return grid_ext(f, t, k, c, d + 1, idx | ((size_t)c[d] << d));
+  return f_sub(f, grid_ext(f, t, k, c, d + 1, idx | ((size_t)1 << d)), grid_ext(f, t, k, c, d + 1, idx));
+}
+void sco_g_gridk_sums(const sco_field* f, const u64* a, const u64* b, size_t nv, int k, u64* S) {
+  int cells = 1;
+  for (int i = 0; i < k; ++i) cells *= 3;
+  for (int i = 0; i < cells; ++i) S[i] = 0;
+  size_t blocks = (size_t)1 << (nv - (size_t)k);
+  for (size_t q = 0; q < blocks; ++q) {
+    for (int cell = 0; cell < cells; ++cell) {
+      int c[3], rem = cell;
+      for (int d = k - 1; d >= 0; --d) {
+        c[d] = rem % 3;
+        rem /= 3;
+      }
+      u64 ea = grid_ext(f, a + (q << k), k, c, 0, 0), eb = grid_ext(f, b + (q << k), k, c, 0, 0);
+      S[cell] = f_add(f, S[cell], f_mul(f, ea, eb));
+    }
+  }
+}
+
 /* ---- gkr_protocol::round_polynomial::W ----------------
  * f(b,c) = add(b,c) (W(b) + W(c)) + mul(b,c) W(b) W(c); add/mul have 2k variables and are
  * indexed (c << k) | b; w_b, w_c have k variables.  kb = current number of variables of

@@ -27,14 +27,19 @@ def model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allga
     sharded, pending, cache = True, [], None
     evals = []
     n_allreduce = 0
+    L = o.lib
+    add, sub, mul = (lambda x, y: L.sco_add(o.fp, x, y)), (lambda x, y: L.sco_sub(o.fp, x, y)), \
+        (lambda x, y: L.sco_mul(o.fp, x, y))
+    # vpp: 1 = one round per pass, 2 = two, 3 = two with a three-round first pass
     for j in range(n):
         if j:
             pending.append(ch[j - 1])
-        covered = cache is not None and (
-            (cache[1] == j and not pending) or (cache[0] == 2 and cache[1] + 1 == j and len(pending) == 1))
+        covered = cache is not None and 0 <= j - cache[1] < cache[0] and len(pending) == j - cache[1]
         if not covered:
             kf = len(pending)
-            ks = 2 if (vpp == 2 and n - j >= 2) else 1
+            ks = 2 if (vpp >= 2 and n - j >= 2) else 1
+            if vpp == 3 and j == 0 and n >= 3:
+                ks = 3
             cur_log = int(a.size).bit_length() - 1
             if sharded and (cur_log < kf + ks or cur_log <= tail_log):
                 a = allgather(a)
@@ -44,7 +49,7 @@ def model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allga
                 a = o.fix_variables(a, pending)
                 b = o.fix_variables(b, pending)
                 pending = []
-            S = o.grid_sums(a, b) if ks == 2 else o.round_evals(a, b)
+            S = o.gridk_sums(a, b, ks)
             if sharded:
                 limbs = D.split_limbs([int(x) for x in S])
                 allreduce(limbs)
@@ -52,26 +57,29 @@ def model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allga
                 S = D.recombine_limbs(limbs, p)
             cache = (ks, j, [int(x) for x in S])
         ks, j0, S = cache
-        L = o.lib
-
-        def from_inf(h0, h1, hinf):
-            t = L.sco_add(o.fp, h1, hinf)
-            return [h0, h1, L.sco_sub(o.fp, L.sco_add(o.fp, t, t), h0)]
-
-        if ks == 1:
-            e = [int(x) for x in S]   # round_evals already is (H(0), H(1), H(2))
-        elif j == j0:
-            e = from_inf(L.sco_add(o.fp, S[0], S[1]), L.sco_add(o.fp, S[3], S[4]), L.sco_add(o.fp, S[6], S[7]))
-        else:
-            r = pending[0]
-            r2 = L.sco_mul(o.fp, r, r)
-            q = []
-            for v in range(3):
-                s0, s1, si = S[v], S[3 + v], S[6 + v]
-                lin = L.sco_sub(o.fp, L.sco_sub(o.fp, s1, s0), si)
-                q.append(L.sco_add(o.fp, L.sco_add(o.fp, s0, L.sco_mul(o.fp, r, lin)), L.sco_mul(o.fp, r2, si)))
-            e = from_inf(q[0], q[1], q[2])
-        evals.append([int(x) for x in e])
+        # prover_answer: collapse the leading axes at the challenges received since the pass,
+        # the round's variable is the next axis, the axes after it are summed over {0,1}
+        grid = list(S)
+        cells = len(grid)
+        for r in pending:
+            r2 = mul(r, r)
+            cells //= 3
+            grid = [add(add(grid[c], mul(r, sub(sub(grid[cells + c], grid[c]), grid[2 * cells + c]))),
+                        mul(r2, grid[2 * cells + c])) for c in range(cells)]
+        rest = cells // 3
+        h = []
+        for x in range(3):
+            t = 0
+            for c in range(rest):
+                digits, d = [], c
+                while d:
+                    digits.append(d % 3)
+                    d //= 3
+                if 2 not in digits:
+                    t = add(t, grid[x * rest + c])
+            h.append(t)
+        t = add(h[1], h[2])
+        evals.append([h[0], h[1], sub(add(t, t), h[0])])   # H(2) = 2H(1) - H(0) + 2H(inf)
     return evals, ch, n_allreduce
 
 
@@ -111,7 +119,8 @@ def _worker(rank, world, port, cases, q):
 def test_gloo_sharded_schedule(world):
     GOLD = 2**64 - 2**32 + 1
     cases = [(GOLD, 10, 0, 2), (GOLD, 10, 0, 1), (GOLD, 11, 4, 2), (389, 9, 0, 2), (GOLD, 3, 0, 2),
-             (GOLD, world.bit_length() - 1, 0, 2), (5, 8, 2, 1)]
+             (GOLD, world.bit_length() - 1, 0, 2), (5, 8, 2, 1), (GOLD, 10, 0, 3), (GOLD, 11, 4, 3),
+             (389, 9, 0, 3), (GOLD, 3, 0, 3), (GOLD, 4, 0, 3)]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + world + (os.getpid() % 200)

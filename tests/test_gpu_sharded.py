@@ -118,9 +118,10 @@ def test_rccl_world1():
     pkg = load_package()
     import thaler_study_amd.distributed as D
     o = oracle(GOLD)
-    for n, tail_log in [(14, 4), (10, 12), (3, 0)]:
+    for n, tail_log, first in [(14, 4, 0), (14, 4, 3), (10, 12, 0), (3, 0, 3), (3, 0, 2)]:
         ctx = pkg.Context(pkg.Field(GOLD))
         ctx.set_option("tail_log", tail_log)
+        ctx.set_option("first_pass_vars", first)   # 3: the 54-limb all-reduce of the 27-cell first pass
         D.attach_rccl(ctx, 0, 1)
         assert ctx.rank_world() == (0, 1)
         a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)

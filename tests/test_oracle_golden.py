@@ -264,3 +264,29 @@ def test_triangle_restatements():
     flat = sum(k["adjacency"], [])
     t = pyref.tri_transcript(flat, k["k"], [3, 5, 7, 11, 13, 17], k["p"])
     assert t["c_1"] == k["expected_c_1"]
+
+
+def test_gridk_matches_grid_and_round_evals():
+    """the general k-round grid (test infrastructure for the three-round first pass) agrees with
+    the two pinned special cases: k = 2 is sco_g_grid_sums, k = 1 is (H(0), H(1), H(inf))"""
+    for p in (GOLD, 389, 5):
+        o = Oracle(p)
+        for n in (3, 4, 7):
+            a, b = o.generate(21, n), o.generate(22, n)
+            assert np.array_equal(o.gridk_sums(a, b, 2), o.grid_sums(a, b))
+            e = o.round_evals(a, b)          # H(0), H(1), H(2)
+            g1 = [int(x) for x in o.gridk_sums(a, b, 1)]
+            F = o.lib
+            t = F.sco_add(o.fp, g1[1], g1[2])
+            assert [g1[0], g1[1], F.sco_sub(o.fp, F.sco_add(o.fp, t, t), g1[0])] == [int(x) for x in e]
+            # k = 3: summing the last axis over {0,1} gives the k = 2 grid of the same tables
+            g3 = [int(x) for x in o.gridk_sums(a, b, 3)]
+            g2 = [int(x) for x in o.grid_sums(a, b)]
+            # S3[(3u+v)*3+w] summed over w in {0,1} is NOT S2[3u+v] (different blocks), but the
+            # total H(u) = sum_{v,w in {0,1}} S3[u][v][w] equals sum_{v in {0,1}} S2[u][v]
+            for u in range(3):
+                h3 = 0
+                for v in range(2):
+                    for w in range(2):
+                        h3 = F.sco_add(o.fp, h3, g3[(3 * u + v) * 3 + w])
+                assert h3 == F.sco_add(o.fp, g2[3 * u], g2[3 * u + 1])

@@ -373,7 +373,12 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     wave_lds_fence();
     }
   };
-  auto process_tile = [&](size_t tile, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
+  // The 27-cell grid runs at two waves per SIMD and is ALU-heavy: it cannot count on other
+  // waves to cover its loads, so it fetches the wave's next tile before it starts on the
+  // arithmetic of the current one.  (The three-variable fold would need 128 more registers
+  // for the same trick and falls to one wave per SIMD.)
+  constexpr bool kPrefetch = (KS == 3);
+  auto process_tile = [&](size_t tile, size_t next, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
     u64 a[IN], b[IN];
     if constexpr (KF == 3) {
       stage_and_fold3(pa, a);
@@ -385,6 +390,9 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
       for (int k = 0; k < NP; ++k) {
         a[2 * k] = pa[k].x; a[2 * k + 1] = pa[k].y;
         b[2 * k] = pb[k].x; b[2 * k + 1] = pb[k].y;
+      }
+      if constexpr (kPrefetch) {
+        if (next < n_tiles) load_tile(next, pa, pb);
       }
       fold_run<F, KF, IN>(f, a, fw);
       fold_run<F, KF, IN>(f, b, fw);
@@ -419,10 +427,16 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
 
   const size_t tile_stride = (size_t)gridDim.x * kWaves;
   size_t tile = (size_t)blockIdx.x * kWaves + wave;
-  for (; tile < n_tiles; tile += tile_stride) {
+  if constexpr (kPrefetch) {
     ull2 pa[NP], pb[NP];
-    load_tile(tile, pa, pb);
-    process_tile(tile, pa, pb);
+    if (tile < n_tiles) load_tile(tile, pa, pb);
+    for (; tile < n_tiles; tile += tile_stride) process_tile(tile, tile + tile_stride, pa, pb);
+  } else {
+    for (; tile < n_tiles; tile += tile_stride) {
+      ull2 pa[NP], pb[NP];
+      load_tile(tile, pa, pb);
+      process_tile(tile, tile + tile_stride, pa, pb);
+    }
   }
 
   // reduce nine sums at a time (a 27-cell grid would otherwise hold 27 residues next to the

@@ -81,7 +81,8 @@ open(os.path.join(P, "%s_summary.md" % tag), "w").write("\n".join(lines) + "\n")
 
 tj_path = os.path.join(P, "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
-tj["n%d_gpus1_vpp%d" % (n, vpp)] = {
+first = runs[-1][0][1] if vpp == 2 else 1   # rounds served by the first pass of the traced run
+tj["n%d_gpus1_vpp%d_first%d" % (n, vpp, first)] = {
     "hbm_bytes_per_step": tot_p, "fetch_bytes_corrected": sum(fetch) * 2 * 1024, "write_bytes": sum(write) * 1024,
     "source": "%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md" % tag,
 }
