@@ -127,10 +127,14 @@ struct sc_ctx {
   void* host_user = nullptr;
 
   // kernel timing
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // pass-kernel timing (option "time_kernels"): a ring of event pairs, read back only when the
+  // ring is full or the totals are queried, so that timing adds two event records per launch
+  // and no host synchronisation to the rounds it measures
+  static constexpr int kTimerRing = 64;
+  hipEvent_t kt_ev[kTimerRing][2] = {};
+  int kt_used = 0;
   double kt_ms = 0.0;
   long kt_n = 0;
-  bool kt_pending = false;
 };
 
 struct sc_table {
@@ -300,6 +304,20 @@ u64 eval2_from_inf(const HostField& hf, u64 e0, u64 e1, u64 einf) {
   return hf.sub(hf.add(t, t), e0);
 }
 
+// add the durations of the recorded launches to the totals (waits for the last of them)
+void drain_kernel_timers(sc_ctx* ctx) {
+  if (ctx->kt_used == 0) return;
+  (void)hipEventSynchronize(ctx->kt_ev[ctx->kt_used - 1][1]);
+  for (int i = 0; i < ctx->kt_used; ++i) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, ctx->kt_ev[i][0], ctx->kt_ev[i][1]) == hipSuccess) {
+      ctx->kt_ms += ms;
+      ctx->kt_n += 1;
+    }
+  }
+  ctx->kt_used = 0;
+}
+
 template <class F>
 void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const u64* B, u64* A2,
                    u64* B2, const sc::FoldW& fw, size_t n_units, int grid, int log_in, const sc::PassOut& out) {
@@ -344,12 +362,15 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
   out.seq = mailbox ? ++ctx->mailbox_seq : 0;
   if (grid > 1) ctx->ticket_base += (unsigned)grid;
-  if (ctx->time_kernels) SC_HIP(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+  if (ctx->time_kernels) {
+    if (ctx->kt_used == sc_ctx::kTimerRing) drain_kernel_timers(ctx);
+    SC_HIP(ctx, hipEventRecord(ctx->kt_ev[ctx->kt_used][0], ctx->stream));
+  }
   SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, fw, n_units, grid, log_in, out));
   SC_HIP(ctx, hipGetLastError());
   if (ctx->time_kernels) {
-    SC_HIP(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->kt_pending = true;
+    SC_HIP(ctx, hipEventRecord(ctx->kt_ev[ctx->kt_used][1], ctx->stream));
+    ctx->kt_used += 1;
   }
   *from_mailbox = mailbox;
   return SC_OK;
@@ -369,15 +390,6 @@ sc::PassOut next_pass_out(sc_ctx* ctx, int grid) {
   return out;
 }
 
-void account_kernel_time(sc_ctx* ctx) {
-  if (!ctx->time_kernels || !ctx->kt_pending) return;
-  ctx->kt_pending = false;
-  float ms = 0.f;
-  if (hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1) == hipSuccess) {
-    ctx->kt_ms += ms;
-    ctx->kt_n += 1;
-  }
-}
 
 // =====================================================================================
 // 2. collectives
@@ -411,7 +423,6 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
   u64* src = nullptr;
   if (from_mailbox) {
     SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
-    if (ctx->time_kernels) SC_HIP(ctx, hipEventSynchronize(ctx->ev1));
     src = ctx->h_mailbox;
   } else {
     if (across_ranks && ctx->transport == Transport::kRccl) {
@@ -428,15 +439,13 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
                          (int)count, ctx->d_mailbox, seq);
       SC_HIP(ctx, hipGetLastError());
       SC_TRY(wait_mailbox(ctx, seq));
-      if (ctx->time_kernels) SC_HIP(ctx, hipEventSynchronize(ctx->ev1));
-      src = ctx->h_mailbox;
+        src = ctx->h_mailbox;
     } else {
       SC_HIP(ctx, hipMemcpyAsync(ctx->h_sums, ctx->d_sums, count * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
       SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
       src = ctx->h_sums;
     }
   }
-  account_kernel_time(ctx);
   if (across_ranks && ctx->transport == Transport::kHost) {
     if (src != ctx->h_sums) {
       memcpy(ctx->h_sums, src, count * sizeof(u64));
@@ -732,8 +741,10 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
   memset(ctx->h_mailbox, 0, 64 * sizeof(u64));
   SC_CREATE_HIP(hipHostGetDevicePointer((void**)&ctx->d_mailbox, ctx->h_mailbox, 0));
   SC_CREATE_HIP(hipDeviceSynchronize());
-  SC_CREATE_HIP(hipEventCreate(&ctx->ev0));
-  SC_CREATE_HIP(hipEventCreate(&ctx->ev1));
+  for (int i = 0; i < sc_ctx::kTimerRing; ++i) {
+    SC_CREATE_HIP(hipEventCreate(&ctx->kt_ev[i][0]));
+    SC_CREATE_HIP(hipEventCreate(&ctx->kt_ev[i][1]));
+  }
 #undef SC_CREATE_HIP
   *out = ctx;
   return SC_OK;
@@ -751,8 +762,9 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
   if (ctx->h_sums) (void)hipHostFree(ctx->h_sums);
   if (ctx->h_mailbox) (void)hipHostFree(ctx->h_mailbox);
   if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
-  if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-  if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+  for (int i = 0; i < sc_ctx::kTimerRing; ++i)
+    for (int k = 0; k < 2; ++k)
+      if (ctx->kt_ev[i][k]) (void)hipEventDestroy(ctx->kt_ev[i][k]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SC_OK;
@@ -778,6 +790,7 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
     if (value < 1 || value > (int64_t)ctx->partial_rows) return fail(ctx, SC_ERR_ARG, "max_blocks out of range");
     ctx->max_blocks = (int)value;
   } else if (k == "time_kernels") {
+    if (!value) drain_kernel_timers(ctx);
     ctx->time_kernels = value ? 1 : 0;
   } else if (k == "use_mailbox") {
     ctx->use_mailbox = value ? 1 : 0;
@@ -817,6 +830,8 @@ extern "C" void* sc_ctx_stream(const sc_ctx* ctx) { return ctx ? (void*)ctx->str
 
 extern "C" int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset) {
   if (!ctx || !out) return SC_ERR_ARG;
+  SC_TRY(set_device(ctx));
+  drain_kernel_timers(ctx);
   out[0] = (double)ctx->kt_n;
   out[1] = ctx->kt_ms;
   if (reset) {
