@@ -96,7 +96,8 @@ struct sc_ctx {
   // tables outgrow the Infinity Cache (the 27-cell grid costs ALU time, it saves a quarter of the
   // later traffic), two below
   int first_pass_vars = 0;
-  int tail_log = 12;
+  int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
+                      // cheaper than the ~25 us of collective latency of each further sharded pass
   int max_blocks = 2048;
   int time_kernels = 0;
   int nt_load_log = 25;   // tables of >= 2^this entries are loaded nontemporal
