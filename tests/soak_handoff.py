@@ -8,8 +8,10 @@ sys.path.insert(0, os.path.join(ge.ROOT, "oracle"))
 import numpy as np, pyref
 from oracle import Oracle
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # first_pass_vars (3: the 27-cell hand-off at every size)
 o = Oracle(pkg.GOLDILOCKS)
 ctx = pkg.Context(pkg.Field(pkg.GOLDILOCKS))
+ctx.set_option("first_pass_vars", first)
 mm = pkg.matrix_multiplication
 inst = []
 for n in (14, 17, 20, 22):
