@@ -215,7 +215,9 @@ __device__ __forceinline__ void transpose_to_pieces(ull2* __restrict__ lds, ull2
 // fix_variables + to_univariate, sum-check-protocol/src/lib.rs:105-112).
 //
 // unit = one run of IN = 2^(KF+KS) input entries per table -> OUT = 2^KS output entries,
-// owned by one lane; a wave tile is 64 units.  Sums leave through finish_pass (PassOut).
+// owned by one lane; a wave tile is 64 units.  KF in 0..3, KS in 1..3 (KS = 3, the 27-cell grid
+// of a three-round first pass, is only instantiated with KF = 0).  Sums leave through
+// finish_pass (PassOut).
 // Where a pass leaves its sums.
 //  * grid of one block: that block publishes directly.
 //  * larger grids: every block stores its partial residues (sum-major rows), takes a ticket,
@@ -224,8 +226,8 @@ __device__ __forceinline__ void transpose_to_pieces(ull2* __restrict__ lds, ull2
 //    cdna_hip_programming.md Guideline 16 (form R1): partials are stored write-through
 //    (sc1), the storing wave drains them (s_waitcnt vmcnt(0)), then lane 0 adds to the
 //    ticket; the block whose add returns the last ticket acquires at agent scope behind a
-//    workgroup barrier and reads the partials with sc1 loads.  The ticket counter only grows (base = value before this launch), so nothing
-//    has to be re-zeroed between launches.
+//    workgroup barrier and reads the partials with sc1 loads.  The ticket counter only grows
+//    (base = value before this launch), so nothing has to be re-zeroed between launches.
 //  * publish target: `mailbox` (pinned host memory the host spins on: 2*NS split limbs, then
 //    the sequence word at index kMailboxSeq) or, for the sharded transports that still have
 //    to all-reduce on the device, `sums_dev`.
@@ -305,8 +307,6 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
   publish_seq(o);
 }
 
-// The 27 lazy accumulators of a three-round pass need ~280 registers if the scheduler is left
-// alone (one wave per SIMD); asking for two waves caps it at 256 (a few values park in AGPRs).
 template <class F, int KF, int KS>
 __global__ void __launch_bounds__(kBlock)
 pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
@@ -355,22 +355,22 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   // KF = 3: a run is 2^(3+KS) entries; read it back from LDS one output (8 entries) at a time so
   // that only the staged pieces and OUT folded values are live, not the whole run twice.
   auto stage_and_fold3 = [&](ull2 (&p)[NP], u64 (&t)[IN]) {
-    if constexpr (KF == 3) {
+    if constexpr (KF == 3) {  // (the body only instantiates for run lengths swz_slot supports)
 #pragma unroll
-    for (int k = 0; k < NP; ++k) my_lds[swz_slot<NP>(64 * k + lane)] = p[k];
-    wave_lds_fence();
+      for (int k = 0; k < NP; ++k) my_lds[swz_slot<NP>(64 * k + lane)] = p[k];
+      wave_lds_fence();
 #pragma unroll
-    for (int o = 0; o < OUT; ++o) {
-      u64 v[8];
+      for (int o = 0; o < OUT; ++o) {
+        u64 v[8];
 #pragma unroll
-      for (int m = 0; m < 4; ++m) {
-        const ull2 x = my_lds[swz_slot<NP>(NP * lane + 4 * o + m)];
-        v[2 * m] = x.x; v[2 * m + 1] = x.y;
+        for (int m = 0; m < 4; ++m) {
+          const ull2 x = my_lds[swz_slot<NP>(NP * lane + 4 * o + m)];
+          v[2 * m] = x.x; v[2 * m + 1] = x.y;
+        }
+        fold_run<F, 3, 8>(f, v, fw);
+        t[o] = v[0];
       }
-      fold_run<F, 3, 8>(f, v, fw);
-      t[o] = v[0];
-    }
-    wave_lds_fence();
+      wave_lds_fence();
     }
   };
   // The 27-cell grid runs at two waves per SIMD and is ALU-heavy: it cannot count on other
