@@ -30,6 +30,16 @@ namespace sc {
 typedef uint64_t u64;
 typedef uint32_t u32;
 
+// A residue kept as two 32-bit halves.  The hand-scheduled Goldilocks sequences below work on
+// halves; passing them as separate registers (instead of re-packing into an aligned 64-bit
+// pair between a subtraction and the product that consumes it) saves ~80 v_mov per wave tile
+// of the 27-cell grid.
+struct X64 {
+  u32 lo, hi;
+};
+SC_HD X64 split64(u64 v) { return X64{(u32)v, (u32)(v >> 32)}; }
+SC_HD u64 join64(X64 v) { return ((u64)v.hi << 32) | v.lo; }
+
 // 64 x 64 -> 128 product.  Device: four 32x32+64 multiply-adds (v_mad_u64_u32); asking the
 // compiler for `a*b` and `__umul64hi(a,b)` separately costs seven quarter-rate multiplies.
 SC_HD void mul_wide(u64 a, u64 b, u64& hi, u64& lo) {
@@ -86,9 +96,10 @@ struct MontGeneric {
     return (a < b) ? d + p : d;
   }
   SC_HD u64 dbl(u64 a) const { return add(a, a); }
-  SC_HD void sub4(u64 (&d)[4], const u64 (&a)[4], const u64 (&b)[4]) const {
-    for (int k = 0; k < 4; ++k) d[k] = sub(a[k], b[k]);
+  SC_HD void sub4(X64 (&d)[4], const X64 (&a)[4], const X64 (&b)[4]) const {
+    for (int k = 0; k < 4; ++k) d[k] = split64(sub(join64(a[k]), join64(b[k])));
   }
+  SC_HD X64 sub(X64 a, X64 b) const { return split64(sub(join64(a), join64(b))); }
 
   // (hi:lo) < p * 2^64  ->  (hi:lo) * 2^-64 mod p
   SC_HD u64 redc(u64 hi, u64 lo) const {
@@ -115,6 +126,7 @@ struct MontGeneric {
   typedef u64 Acc;
   SC_HD void acc_zero(Acc& a) const { a = 0; }
   SC_HD void acc_mac(Acc& a, u64 x, u64 y) const { a = add(a, mul(x, y)); }
+  SC_HD void acc_mac(Acc& a, X64 x, X64 y) const { acc_mac(a, join64(x), join64(y)); }
   SC_HD u64 acc_get(const Acc& a) const { return a; }
   typedef u64 Acc3;  // short sums (folds): same thing for a generic modulus
   SC_HD void acc3_zero(Acc3& a) const { a = 0; }
@@ -158,9 +170,8 @@ struct GoldilocksMont {
   // 6 instructions + ~4 s_nop from the compiler; four together are 20 instructions, no s_nop.
   // Per chain: d = a - b (borrow bw); on borrow subtract EPS = 2^32 - 1, i.e. d0 += bw (carry c),
   // d1 -= bw, d1 += c.
-  SC_HD void sub4(u64 (&d)[4], const u64 (&a)[4], const u64 (&b)[4]) const {
+  SC_HD void sub4(X64 (&d)[4], const X64 (&a)[4], const X64 (&b)[4]) const {
 #if defined(__HIP_DEVICE_COMPILE__)
-    u32 d0[4], d1[4];
     asm("v_sub_co_u32_e64 %0, vcc, %8, %16\n\t"
         "v_sub_co_u32_e64 %1, s[72:73], %9, %17\n\t"
         "v_sub_co_u32_e64 %2, s[74:75], %10, %18\n\t"
@@ -181,19 +192,17 @@ struct GoldilocksMont {
         "v_addc_co_u32_e64 %5, s[80:81], %5, 0, s[80:81]\n\t"
         "v_addc_co_u32_e64 %6, s[82:83], %6, 0, s[82:83]\n\t"
         "v_addc_co_u32_e64 %7, s[84:85], %7, 0, s[84:85]"
-        : "=&v"(d0[0]), "=&v"(d0[1]), "=&v"(d0[2]), "=&v"(d0[3]), "=&v"(d1[0]), "=&v"(d1[1]), "=&v"(d1[2]),
-          "=&v"(d1[3])
-        : "v"((u32)a[0]), "v"((u32)a[1]), "v"((u32)a[2]), "v"((u32)a[3]), "v"((u32)(a[0] >> 32)),
-          "v"((u32)(a[1] >> 32)), "v"((u32)(a[2] >> 32)), "v"((u32)(a[3] >> 32)), "v"((u32)b[0]), "v"((u32)b[1]),
-          "v"((u32)b[2]), "v"((u32)b[3]), "v"((u32)(b[0] >> 32)), "v"((u32)(b[1] >> 32)), "v"((u32)(b[2] >> 32)),
-          "v"((u32)(b[3] >> 32))
+        : "=&v"(d[0].lo), "=&v"(d[1].lo), "=&v"(d[2].lo), "=&v"(d[3].lo), "=&v"(d[0].hi), "=&v"(d[1].hi),
+          "=&v"(d[2].hi), "=&v"(d[3].hi)
+        : "v"(a[0].lo), "v"(a[1].lo), "v"(a[2].lo), "v"(a[3].lo), "v"(a[0].hi), "v"(a[1].hi), "v"(a[2].hi),
+          "v"(a[3].hi), "v"(b[0].lo), "v"(b[1].lo), "v"(b[2].lo), "v"(b[3].lo), "v"(b[0].hi), "v"(b[1].hi),
+          "v"(b[2].hi), "v"(b[3].hi)
         : "vcc", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85");
-#pragma unroll
-    for (int k = 0; k < 4; ++k) d[k] = ((u64)d1[k] << 32) | d0[k];
 #else
-    for (int k = 0; k < 4; ++k) d[k] = sub(a[k], b[k]);
+    for (int k = 0; k < 4; ++k) d[k] = split64(sub(join64(a[k]), join64(b[k])));
 #endif
   }
+  SC_HD X64 sub(X64 a, X64 b) const { return split64(sub(join64(a), join64(b))); }
 
   // floor(m * p / 2^64) for the m with m*p == lo (mod 2^64), i.e. m = lo * (2^32+1).
   // m*p = (m - (m>>32)) * 2^64 + (m - (m<<32)); the low word borrows iff m < (m<<32).
@@ -229,7 +238,8 @@ struct GoldilocksMont {
     u32 l0, l1, l2, l3;  // little-endian 32-bit limbs of the two's-complement sum
   };
   SC_HD void acc_zero(Acc& a) const { a.l0 = a.l1 = a.l2 = a.l3 = 0; }
-  SC_HD void acc_mac(Acc& a, u64 x, u64 y) const {
+  SC_HD void acc_mac(Acc& a, u64 x, u64 y) const { acc_mac(a, split64(x), split64(y)); }
+  SC_HD void acc_mac(Acc& a, X64 xs, X64 ys) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     // 4 multiplies + 11 add/subtract-with-carry, scheduled by hand: with x = (x1:x0), y = (y1:y0),
     //   t = x0*y0 (weight 1), m = x0*y1 + x1*y0 (weight 2^32, carry sC at 2^96), q = x1*y1 (2^64);
@@ -239,7 +249,7 @@ struct GoldilocksMont {
     // they commute) are interleaved so that every consumer sits three slots after its producer:
     // 15 instructions, no s_nop.  The compiler's own sequence for the same arithmetic is ~17
     // instructions + ~6 s_nop.
-    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
+    const u32 x0 = xs.lo, x1 = xs.hi, y0 = ys.lo, y1 = ys.hi;
     u64 t, m, q, sC, sB, sD;
     asm("v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
         "v_mad_u64_u32 %1, %3, %5, %6, %1\n\t"
@@ -266,7 +276,7 @@ struct GoldilocksMont {
         : "vcc");
 #else
     u64 hi, lo;
-    mul_wide(x, y, hi, lo);
+    mul_wide(join64(xs), join64(ys), hi, lo);
     typedef unsigned __int128 u128;
     u128 s = ((u128)a.l3 << 96) | ((u128)a.l2 << 64) | ((u128)a.l1 << 32) | a.l0;
     s += ((u128)(hi & 0xFFFFFFFFull) << 64) | lo;  // + L
@@ -279,12 +289,19 @@ struct GoldilocksMont {
   }
   // residue of (accumulated value) * 2^-64
   SC_HD u64 acc_get(const Acc& a) const {
+    u32 l0 = a.l0, l1 = a.l1, l2 = a.l2, l3 = a.l3;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // Copy the limbs out through an opaque statement: joining l0/l1 into a 64-bit value below
+    // would otherwise make the register allocator keep them in an aligned pair for the whole
+    // accumulation loop and re-pack them after every acc_mac (three v_mov per product).
+    asm("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3));
+#endif
     // value = L' + T*2^96 == L' - T, L' = low 96 bits, T = top limb as a signed integer
-    const int64_t T = (int64_t)(int32_t)a.l3;
+    const int64_t T = (int64_t)(int32_t)l3;
     const u64 t = (T > 0) ? P - (u64)T : (u64)(-T);  // -T mod p, in [0, p)
     u64 w0;
-    const bool c = __builtin_add_overflow(((u64)a.l1 << 32) | a.l0, t, &w0);
-    const u64 w1 = (u64)a.l2 + (c ? 1u : 0u);
+    const bool c = __builtin_add_overflow(((u64)l1 << 32) | l0, t, &w0);
+    const u64 w1 = (u64)l2 + (c ? 1u : 0u);
     return wide_get(w0, w1, 0);
   }
 

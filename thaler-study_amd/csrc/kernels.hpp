@@ -62,11 +62,11 @@ __device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], const FoldW& 
 //  KS = 2: acc[3u+v] = sum a(u,v)*b(u,v), (u,v) in {0,1,inf}^2, u on index bit 0, v on bit 1
 // one 2x2 slice (index bits u, v) -> its nine extension values in {0,1,inf}^2
 template <class F>
-__device__ __forceinline__ void extend_quad(const F& f, const u64 t0, const u64 t1, const u64 t2, const u64 t3,
-                                            u64 (&e)[3][3]) {
+__device__ __forceinline__ void extend_quad(const F& f, const X64 t0, const X64 t1, const X64 t2, const X64 t3,
+                                            X64 (&e)[3][3]) {
   // e[u][v], u on index bit 0, v on bit 1; four of the five differences depend on the inputs only
-  const u64 hi[4] = {t1, t3, t2, t3}, lo[4] = {t0, t2, t0, t1};
-  u64 d[4];
+  const X64 hi[4] = {t1, t3, t2, t3}, lo[4] = {t0, t2, t0, t1};
+  X64 d[4];
   f.sub4(d, hi, lo);
   e[0][0] = t0; e[1][0] = t1; e[2][0] = d[0];
   e[0][1] = t2; e[1][1] = t3; e[2][1] = d[1];
@@ -81,9 +81,9 @@ __device__ __forceinline__ void accumulate_run(const F& f, typename F::Acc* acc,
     f.acc_mac(acc[1], a[1], b[1]);
     f.acc_mac(acc[2], f.sub(a[1], a[0]), f.sub(b[1], b[0]));
   } else if constexpr (KS == 2) {
-    u64 ea[3][3], eb[3][3];
-    extend_quad(f, a[0], a[1], a[2], a[3], ea);
-    extend_quad(f, b[0], b[1], b[2], b[3], eb);
+    X64 ea[3][3], eb[3][3];
+    extend_quad(f, split64(a[0]), split64(a[1]), split64(a[2]), split64(a[3]), ea);
+    extend_quad(f, split64(b[0]), split64(b[1]), split64(b[2]), split64(b[3]), eb);
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -99,20 +99,22 @@ __device__ __forceinline__ void accumulate_octet(const F& f, typename F::Acc* ac
 #pragma unroll
   for (int step = 0; step < 3; ++step) {
     const int w = (step == 0) ? 0 : (step == 1) ? 2 : 1;
-    u64 sa[4], sb[4];
+    X64 sa[4], sb[4];
     if (w == 2) {
-      const u64 ah[4] = {a[4], a[5], a[6], a[7]}, al[4] = {a[0], a[1], a[2], a[3]};
-      const u64 bh[4] = {b[4], b[5], b[6], b[7]}, bl[4] = {b[0], b[1], b[2], b[3]};
+      const X64 ah[4] = {split64(a[4]), split64(a[5]), split64(a[6]), split64(a[7])};
+      const X64 al[4] = {split64(a[0]), split64(a[1]), split64(a[2]), split64(a[3])};
+      const X64 bh[4] = {split64(b[4]), split64(b[5]), split64(b[6]), split64(b[7])};
+      const X64 bl[4] = {split64(b[0]), split64(b[1]), split64(b[2]), split64(b[3])};
       f.sub4(sa, ah, al);
       f.sub4(sb, bh, bl);
     } else {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        sa[i] = a[4 * w + i];
-        sb[i] = b[4 * w + i];
+        sa[i] = split64(a[4 * w + i]);
+        sb[i] = split64(b[4 * w + i]);
       }
     }
-    u64 ea[3][3], eb[3][3];
+    X64 ea[3][3], eb[3][3];
     extend_quad(f, sa[0], sa[1], sa[2], sa[3], ea);
     extend_quad(f, sb[0], sb[1], sb[2], sb[3], eb);
 #pragma unroll
