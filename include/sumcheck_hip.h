@@ -77,7 +77,7 @@ int sc_ctx_destroy(sc_ctx* ctx);
 /* message of the last failing call on ctx (ctx == NULL: last failing sc_ctx_create) */
 const char* sc_last_error(const sc_ctx* ctx);
 /* Tunables: "vars_per_pass" (1|2, default 2), "first_pass_vars" (rounds served by the prover's
- * first pass, which has nothing to fold: 1|2|3, default 0 = three for tables of >= 2^27 entries,
+ * first pass, which has nothing to fold: 1|2|3, default 0 = three for tables of >= 2^26 entries,
  * two below; capped by vars_per_pass = 1), "tail_log" (shard log-size at which a sharded
  * prover gathers, default 16), "max_blocks" (grid cap, default 2048), "use_mailbox" (kernels
  * publish sums to pinned host memory the host spins on, default 1), "time_kernels" (HIP-event
