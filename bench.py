@@ -200,6 +200,7 @@ def main():
                 "algorithmic_bytes_per_step": alg_bytes,
                 "vars_per_pass": args.vars_per_pass,
                 "first_pass_vars": first_pass,
+                "tail_pass_vars": ctx.get_option("tail_pass_vars"),
                 "parallelism": "hypercube-shard x%d" % world,
                 "parity_gate": "verifier identities at n=%d ok" % n,
                 "transport": transport,

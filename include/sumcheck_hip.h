@@ -78,7 +78,8 @@ int sc_ctx_destroy(sc_ctx* ctx);
 const char* sc_last_error(const sc_ctx* ctx);
 /* Tunables: "vars_per_pass" (1|2, default 2), "first_pass_vars" (rounds served by the prover's
  * first pass, which has nothing to fold: 1|2|3, default 0 = three for tables of >= 2^26 entries,
- * two below; capped by vars_per_pass = 1), "tail_log" (shard log-size at which a sharded
+ * two below; capped by vars_per_pass = 1), "tail_pass_vars" (rounds served by a folding pass whose
+ * input has <= 2^19 entries, where passes are latency-bound: 3 (default) or 2), "tail_log" (shard log-size at which a sharded
  * prover gathers, default 16), "max_blocks" (grid cap, default 2048), "use_mailbox" (kernels
  * publish sums to pinned host memory the host spins on, default 1), "time_kernels" (HIP-event
  * timing of pass kernels), "nt_load_log" / "nt_store_log" (table log-size from which loads /

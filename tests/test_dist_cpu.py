@@ -30,7 +30,7 @@ def model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allga
     L = o.lib
     add, sub, mul = (lambda x, y: L.sco_add(o.fp, x, y)), (lambda x, y: L.sco_sub(o.fp, x, y)), \
         (lambda x, y: L.sco_mul(o.fp, x, y))
-    # vpp: 1 = one round per pass, 2 = two, 3 = two with a three-round first pass
+    # vpp: 1 = one round per pass, 2 = two, 3 = two with three-round first and tail passes
     for j in range(n):
         if j:
             pending.append(ch[j - 1])
@@ -38,9 +38,9 @@ def model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allga
         if not covered:
             kf = len(pending)
             ks = 2 if (vpp >= 2 and n - j >= 2) else 1
-            if vpp == 3 and j == 0 and n >= 3:
-                ks = 3
             cur_log = int(a.size).bit_length() - 1
+            if vpp == 3 and n - j >= 3 and (j == 0 or (kf > 0 and cur_log <= 19)):
+                ks = 3    # three-round first pass / three-round tail passes on small inputs
             if sharded and (cur_log < kf + ks or cur_log <= tail_log):
                 a = allgather(a)
                 b = allgather(b)

@@ -24,8 +24,10 @@ _ctxs = {}
 
 def schedule_options(vpp):
     """test shorthand for the prover schedule: 1 = one round per pass; 2 = two rounds per pass;
-    3 = two rounds per pass and a three-round first pass (the library default)"""
-    return {"vars_per_pass": min(vpp, 2), "first_pass_vars": 3 if vpp == 3 else min(vpp, 2)}
+    3 = two rounds per pass, three from the first pass and from every small tail pass (what the
+    library does by default on a large instance, forced here at every size)"""
+    return {"vars_per_pass": min(vpp, 2), "first_pass_vars": 3 if vpp == 3 else min(vpp, 2),
+            "tail_pass_vars": 3 if vpp == 3 else 2}
 
 
 def ctx_for(pkg, p, **opts):
@@ -123,6 +125,22 @@ def test_prover_vs_oracle_sizes(pkg, p, vpp):
         assert c1 == ref["c_1"], "n=%d c_1" % n
         assert np.array_equal(evals, ref["evals"]), "n=%d round sums" % n
         assert g.evaluate([int(x) for x in ch]) == ref["final_eval"], "n=%d final evaluation" % n
+
+
+@pytest.mark.parametrize("first,tail", [(2, 3), (3, 2), (1, 3), (0, 3)])
+def test_prover_mixed_pass_widths(pkg, first, tail):
+    """first-pass and tail-pass widths are independent options: every combination gives the
+    reference's transcript (first = 0 is the size rule)"""
+    ctx = ctx_for(pkg, GOLD, first_pass_vars=first, tail_pass_vars=tail)
+    o = oracle(GOLD)
+    for n in (3, 4, 5, 6, 8, 9, 10, 11, 14, 17, 21):
+        a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A + n, n)
+        b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B + n, n)
+        g = pkg.matrix_multiplication.G(a, b)
+        c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+        ref = o.prove(o.generate(pyref.SEED_A + n, n), o.generate(pyref.SEED_B + n, n), ch)
+        assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]), (first, tail, n)
+        assert g.evaluate([int(x) for x in ch]) == ref["final_eval"]
 
 
 def test_random_tables_uploaded(pkg):

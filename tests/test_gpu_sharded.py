@@ -58,6 +58,7 @@ def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove"):
             ctx.set_option("tail_log", tail_log)
             ctx.set_option("vars_per_pass", min(vpp, 2))
             ctx.set_option("first_pass_vars", 3 if vpp == 3 else min(vpp, 2))
+            ctx.set_option("tail_pass_vars", 3 if vpp == 3 else 2)
             ar, ag = lb.collectives(rank)
             ctx.comm_init_host(rank, world, ar, ag)
             start, length = pkg.distributed.shard_range(n, rank, world)

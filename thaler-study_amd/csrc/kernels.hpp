@@ -465,6 +465,88 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
 }
 
 // ------------------------------------------------------------------------------------
+// Three rounds per pass for SMALL tables (<= 2^19 entries, cache-resident): the tail of a proof
+// is a chain of latency-bound passes (launch + one tile + hand-off, ~15 us each whatever the
+// size), so serving three rounds instead of two per pass cuts a third of them.  Bandwidth does
+// not matter here, latency does: every thread folds ONE output per table (2^KF inputs, one
+// round of loads), leaves it in LDS, and one thread in eight then accumulates the 27-cell grid
+// of its octet.  Same arithmetic as pass_kernel<KF, 3> would do.
+template <class F, int KF>
+__global__ void __launch_bounds__(kBlock)
+small_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
+                   u64* __restrict__ B2, FoldW fw, size_t n_out, PassOut out) {
+  static_assert(KF >= 1 && KF <= 3, "pending variables folded by a tail pass");
+  constexpr int G = 1 << KF, NS = 27;
+  __shared__ u64 la[kBlock], lb[kBlock];
+  __shared__ typename F::Acc lacc[NS * (kBlock / 8)];
+  __shared__ u64 lsum[NS];
+  __shared__ int lds_flag;
+  typename F::Acc acc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) f.acc_zero(acc[s]);
+
+  const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(A);
+  const ull2* __restrict__ Bp = reinterpret_cast<const ull2*>(B);
+  for (size_t base = (size_t)blockIdx.x * kBlock; base < n_out; base += (size_t)gridDim.x * kBlock) {
+    const size_t i = base + threadIdx.x;
+    u64 ta = 0, tb = 0;
+    if (i < n_out) {
+      ull2 pa[G / 2], pb[G / 2];
+#pragma unroll
+      for (int m = 0; m < G / 2; ++m) {
+        pa[m] = Ap[i * (G / 2) + m];
+        pb[m] = Bp[i * (G / 2) + m];
+      }
+      u64 va[G], vb[G];
+#pragma unroll
+      for (int m = 0; m < G / 2; ++m) {
+        va[2 * m] = pa[m].x; va[2 * m + 1] = pa[m].y;
+        vb[2 * m] = pb[m].x; vb[2 * m + 1] = pb[m].y;
+      }
+      fold_run<F, KF, G>(f, va, fw);
+      fold_run<F, KF, G>(f, vb, fw);
+      ta = va[0];
+      tb = vb[0];
+      A2[i] = ta;
+      B2[i] = tb;
+    }
+    la[threadIdx.x] = ta;
+    lb[threadIdx.x] = tb;
+    __syncthreads();
+    if (threadIdx.x < kBlock / 8 && base + 8 * threadIdx.x < n_out) {
+      u64 a[8], b[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        a[k] = la[8 * threadIdx.x + k];
+        b[k] = lb[8 * threadIdx.x + k];
+      }
+      accumulate_octet<F>(f, acc, a, b);
+    }
+    __syncthreads();
+  }
+
+  // Only the kBlock/8 = 32 accumulating threads (half of wave 0) hold anything.  Reducing 27
+  // sums across them with shuffles on one wave would cost ~5 us of issue time; instead the raw
+  // accumulators go through LDS and all 256 threads share the 27 x 32 reductions-to-residue,
+  // then each group of 32 consecutive threads sums one cell.
+  constexpr int kOct = kBlock / 8;
+  if (threadIdx.x < kOct) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) lacc[s * kOct + threadIdx.x] = acc[s];
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < NS * kOct; idx += kBlock) {  // idx = cell * 32 + thread
+    u64 r = f.acc_get(lacc[idx]);
+#pragma unroll
+    for (int off = kOct / 2; off >= 1; off >>= 1) r = f.add(r, shfl_down_u64(r, off));
+    if ((idx & (kOct - 1)) == 0) lsum[idx / kOct] = r;
+  }
+  __syncthreads();
+  const u64 mine = (threadIdx.x < NS) ? lsum[threadIdx.x] : 0;
+  finish_pass<F, NS>(f, out, mine, &lds_flag);
+}
+
+// ------------------------------------------------------------------------------------
 // Single-table kernels (DenseMultilinearExtension::fix_variables / evaluate on their own,
 // and the two GEMV-shaped halves of matrix_multiplication::G::new).
 

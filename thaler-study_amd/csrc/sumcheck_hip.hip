@@ -96,6 +96,9 @@ struct sc_ctx {
   // of >= 2^26 entries (the 27-cell grid runs at two waves per SIMD, which a small grid cannot
   // hide; on large tables it saves an eighth of the traffic), two below
   int first_pass_vars = 0;
+  // rounds served by a folding pass once its input is small (<= kTailPass3Log): 3, or 2 to keep
+  // two everywhere
+  int tail_pass_vars = 3;
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
                       // cheaper than the ~25 us of collective latency of each further sharded pass
   int max_blocks = 2048;
@@ -305,6 +308,9 @@ u64 eval2_from_inf(const HostField& hf, u64 e0, u64 e1, u64 einf) {
   return hf.sub(hf.add(t, t), e0);
 }
 
+// inputs of at most this many entries (log2) per table take the three-round tail pass
+constexpr int kTailPass3Log = 19;
+
 // add the durations of the recorded launches to the totals (waits for the last of them)
 void drain_kernel_timers(sc_ctx* ctx) {
   if (ctx->kt_used == 0) return;
@@ -328,6 +334,15 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
   const int nt_st = (log_in - kf) >= ctx->nt_store_log ? 1 : 0;
 #define SC_PASS(KF, KS) \
   hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS>), g, b, 0, s, f, A, B, A2, B2, fw, n_units, out, nt_ld, nt_st)
+  if (ks == 3 && kf > 0) {  // tail pass: one thread per output (kernels.hpp, small_pass3_kernel)
+    const size_t n_out = n_units * 8;
+    switch (kf) {
+      case 1: hipLaunchKernelGGL((sc::small_pass3_kernel<F, 1>), g, b, 0, s, f, A, B, A2, B2, fw, n_out, out); break;
+      case 2: hipLaunchKernelGGL((sc::small_pass3_kernel<F, 2>), g, b, 0, s, f, A, B, A2, B2, fw, n_out, out); break;
+      default: hipLaunchKernelGGL((sc::small_pass3_kernel<F, 3>), g, b, 0, s, f, A, B, A2, B2, fw, n_out, out); break;
+    }
+    return;
+  }
   switch (kf * 4 + ks) {
     case 0 * 4 + 1: SC_PASS(0, 1); break;
     case 0 * 4 + 2: SC_PASS(0, 2); break;
@@ -348,11 +363,11 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
 // still have to be all-reduced on the device (RCCL transport).
 int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, const u64* r,
                 int log_in, bool across_ranks, bool* from_mailbox) {
-  if (kf < 0 || kf > 3 || ks < 1 || ks > 3 || (ks == 3 && kf != 0) || log_in < kf + ks)
+  if (kf < 0 || kf > 3 || ks < 1 || ks > 3 || log_in < kf + ks)
     return fail(ctx, SC_ERR_ARG, "launch_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
   const sc::FoldW fw = make_fold_weights(ctx, r, kf);
   size_t n_units = (size_t)1 << (log_in - kf - ks);
-  int grid = grid_for(ctx, n_units);
+  int grid = grid_for(ctx, (ks == 3 && kf > 0) ? n_units * 8 : n_units);
   const bool mailbox = ctx->use_mailbox && !(across_ranks && ctx->transport == Transport::kRccl);
   sc::PassOut out;
   out.partials = ctx->d_partials;
@@ -784,6 +799,9 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "first_pass_vars") {
     if (value < 0 || value > 3) return fail(ctx, SC_ERR_ARG, "first_pass_vars must be 0 (auto), 1, 2 or 3");
     ctx->first_pass_vars = (int)value;
+  } else if (k == "tail_pass_vars") {
+    if (value != 2 && value != 3) return fail(ctx, SC_ERR_ARG, "tail_pass_vars must be 2 or 3");
+    ctx->tail_pass_vars = (int)value;
   } else if (k == "tail_log") {
     if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "tail_log out of range");
     ctx->tail_log = (int)value;
@@ -810,6 +828,7 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   std::string k(key);
   if (k == "vars_per_pass") *value = ctx->vars_per_pass;
   else if (k == "first_pass_vars") *value = ctx->first_pass_vars;
+  else if (k == "tail_pass_vars") *value = ctx->tail_pass_vars;
   else if (k == "tail_log") *value = ctx->tail_log;
   else if (k == "max_blocks") *value = ctx->max_blocks;
   else if (k == "time_kernels") *value = ctx->time_kernels;
@@ -1347,6 +1366,9 @@ int prover_pass(sc_prover* pr, size_t j) {
     if (ctx->vars_per_pass == 2 && remaining >= 3 && first == 3) ks = 3;
     if (first < ks) ks = first;
   }
+  // tail: once the input is small every pass is latency-bound, so serve three rounds with each
+  if (kf > 0 && ctx->vars_per_pass == 2 && ctx->tail_pass_vars == 3 && remaining >= 3 && pr->cur_log <= kTailPass3Log)
+    ks = 3;
   if (kf > 3) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges", kf);
 
   // Sharded: pairs (2b, 2b+1) stay shard-local while the local table still has the kf+ks
