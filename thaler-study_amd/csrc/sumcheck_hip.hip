@@ -99,6 +99,7 @@ struct sc_ctx {
   // rounds served by a folding pass once its input is small (<= kTailPass3Log): 3, or 2 to keep
   // two everywhere
   int tail_pass_vars = 3;
+  int tail_pass_log = 19;  // largest input (log2 entries per table) that takes the three-round tail pass
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
                       // cheaper than the ~25 us of collective latency of each further sharded pass
   int max_blocks = 2048;
@@ -307,9 +308,6 @@ u64 eval2_from_inf(const HostField& hf, u64 e0, u64 e1, u64 einf) {
   u64 t = hf.add(e1, einf);
   return hf.sub(hf.add(t, t), e0);
 }
-
-// inputs of at most this many entries (log2) per table take the three-round tail pass
-constexpr int kTailPass3Log = 19;
 
 // add the durations of the recorded launches to the totals (waits for the last of them)
 void drain_kernel_timers(sc_ctx* ctx) {
@@ -802,6 +800,9 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "tail_pass_vars") {
     if (value != 2 && value != 3) return fail(ctx, SC_ERR_ARG, "tail_pass_vars must be 2 or 3");
     ctx->tail_pass_vars = (int)value;
+  } else if (k == "tail_pass_log") {
+    if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "tail_pass_log out of range");
+    ctx->tail_pass_log = (int)value;
   } else if (k == "tail_log") {
     if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "tail_log out of range");
     ctx->tail_log = (int)value;
@@ -829,6 +830,7 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   if (k == "vars_per_pass") *value = ctx->vars_per_pass;
   else if (k == "first_pass_vars") *value = ctx->first_pass_vars;
   else if (k == "tail_pass_vars") *value = ctx->tail_pass_vars;
+  else if (k == "tail_pass_log") *value = ctx->tail_pass_log;
   else if (k == "tail_log") *value = ctx->tail_log;
   else if (k == "max_blocks") *value = ctx->max_blocks;
   else if (k == "time_kernels") *value = ctx->time_kernels;
@@ -1367,7 +1369,7 @@ int prover_pass(sc_prover* pr, size_t j) {
     if (first < ks) ks = first;
   }
   // tail: once the input is small every pass is latency-bound, so serve three rounds with each
-  if (kf > 0 && ctx->vars_per_pass == 2 && ctx->tail_pass_vars == 3 && remaining >= 3 && pr->cur_log <= kTailPass3Log)
+  if (kf > 0 && ctx->vars_per_pass == 2 && ctx->tail_pass_vars == 3 && remaining >= 3 && pr->cur_log <= ctx->tail_pass_log)
     ks = 3;
   if (kf > 3) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges", kf);
 
