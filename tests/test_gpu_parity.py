@@ -166,6 +166,30 @@ def test_random_tables_uploaded(pkg):
             assert np.array_equal(chn, ch)
 
 
+@pytest.mark.parametrize("vpp", [2, 3])
+def test_extreme_words(pkg, vpp):
+    """tables made only of the largest and smallest Montgomery words (p-1, p-2, 0, 1) and
+    challenges p-1: every 128-bit product is as large as it gets, which is what the lazy signed
+    accumulators and the carry chains of the hand-scheduled arithmetic have to survive"""
+    p = GOLD
+    ctx = ctx_for(pkg, p, vars_per_pass=vpp)
+    o = oracle(p)
+    for n, pattern in [(16, [p - 1]), (18, [p - 1, p - 2]), (17, [p - 1, 0, 1, p - 1, p - 2, 0, 0xFFFFFFFF, 1 << 32]),
+                       (20, [p - 1, p - 1, p - 1, 0])]:
+        words = np.array([pattern[i % len(pattern)] for i in range(1 << n)], dtype=np.uint64)   # raw words
+        other = words[::-1].copy()
+        a = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, words)
+        b = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, other)
+        g = pkg.matrix_multiplication.G(a, b)
+        ch = np.array([p - 1 - (j % 3) for j in range(n)], dtype=np.uint64)
+        it = iter(ch)
+        c1, evals, chn = pkg.matrix_multiplication.prove(ctx, g, 0, draw=lambda _u, _j, _e: int(next(it)))
+        ref = o.prove(words, other, ch)
+        assert ref["status"] == 0 and c1 == ref["c_1"], n
+        assert np.array_equal(evals, ref["evals"]), n
+        assert g.evaluate([int(x) for x in ch]) == ref["final_eval"], n
+
+
 # ---- trait methods one by one (SURVEY.md section 8a rows a5-a9) ------------------------------
 
 @pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
