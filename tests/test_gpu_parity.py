@@ -266,6 +266,14 @@ def test_fix_variables_all_k(pkg, p):
         assert t.evaluate(pt) == o.evaluate(ot, pt)
         assert t.evaluate(pt, order=pkg.ORDER_BE) == o.vsbw(ot, pt)
         assert np.array_equal(t.to_evaluations(), ot)
+    # many variables at once: the one-pass segment dot (8..17 variables per pass) and its chaining
+    n = 20
+    ot = o.generate(5, n)
+    t = pkg.DenseMultilinearExtension.generate(ctx, 5, n)
+    pt = [o.challenge(6, j) for j in range(n)]
+    for k in (8, 11, 16, 17, 18, 20):
+        got = t.fix_variables(pt[:k]).to_evaluations()
+        assert np.array_equal(got, o.fix_variables(ot, pt[:k], pkg.ORDER_LE)), (n, k)
 
 
 def test_relabel_and_clone(pkg):

@@ -721,6 +721,69 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
   finish_pass<F, 1>(f, out, res[0], &lds_flag);
 }
 
+// LE fix of the LOW k variables (8 <= k <= 17) in ONE pass: out[b] = sum_c eq(r, c) * t[b*2^k + c],
+// i.e. evaluate_kernel's inner product on every contiguous segment of 2^k entries, one wave per
+// segment (coalesced 1 KiB wave loads, tile weights eqA in LDS, bit-0 and lane weights applied
+// once per segment, a shuffle reduction, one 8-byte store).  A chain of three-variable folds
+// reads the table 1.14 times and writes an eighth of it; this reads it once.
+// (DenseMultilinearExtension::fix_variables with many variables; the f_B half of G::new.)
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVec rv, size_t n_out, int nt_load) {
+  constexpr int kWaves = kBlock / kWave;
+  __shared__ u64 eqA[1024];  // k - 7 <= 10
+  const int lane = threadIdx.x & (kWave - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+  const int ta = k - 7;
+  for (int i = threadIdx.x; i < (1 << ta); i += kBlock) {
+    u64 w = f.one();
+    for (int j = 0; j < ta; ++j) {
+      const u64 rj = rv.v[7 + j];
+      w = f.mul(w, ((i >> j) & 1) ? rj : f.sub(f.one(), rj));
+    }
+    eqA[i] = w;
+  }
+  u64 wl = f.one();
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const u64 rj = rv.v[1 + j];
+    wl = f.mul(wl, ((lane >> j) & 1) ? rj : f.sub(f.one(), rj));
+  }
+  const u64 r0 = rv.v[0], one_minus_r0 = f.sub(f.one(), r0);
+  __syncthreads();
+  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+  const int tiles = 1 << ta;
+  for (size_t seg = (size_t)blockIdx.x * kWaves + wave; seg < n_out; seg += (size_t)gridDim.x * kWaves) {
+    const ull2* __restrict__ Sp = Tp + (seg << (k - 1)) + lane;
+    typename F::Acc a0, a1;
+    f.acc_zero(a0);
+    f.acc_zero(a1);
+    int i = 0;
+    for (; i + 8 <= tiles; i += 8) {
+      ull2 pc[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) pc[q] = nt_load ? __builtin_nontemporal_load(Sp + (size_t)(i + q) * kWave) : Sp[(size_t)(i + q) * kWave];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const u64 w = eqA[i + q];
+        f.acc_mac(a0, pc[q].x, w);
+        f.acc_mac(a1, pc[q].y, w);
+      }
+    }
+    for (; i < tiles; ++i) {
+      const ull2 pc = Sp[(size_t)i * kWave];
+      const u64 w = eqA[i];
+      f.acc_mac(a0, pc.x, w);
+      f.acc_mac(a1, pc.y, w);
+    }
+    u64 v = f.add(f.mul(one_minus_r0, f.acc_get(a0)), f.mul(r0, f.acc_get(a1)));
+    v = f.mul(v, wl);
+#pragma unroll
+    for (int off = kWave / 2; off >= 1; off >>= 1) v = f.add(v, shfl_down_u64(v, off));
+    if (lane == 0) out[seg] = v;
+  }
+}
+
 // "Column dot": out[c] = sum_{i in [i0, i1)} w[i] * t[i*M + c]  for one chunk of rows per
 // blockIdx.y; partial[y][c] holds chunk y (reduced by sum_rows_kernel when there are
 // several).  This is fix_variables of the TOP k index bits (BE order), and the f_A half of
@@ -740,8 +803,8 @@ coldot_kernel(F f, const u64* __restrict__ T, const u64* __restrict__ w, size_t 
     f.acc_zero(a0);
     f.acc_zero(a1);
     size_t i = i0;
-    for (; i + 4 <= i1; i += 4) {  // fixed-count inner loop: see evaluate_kernel
-      ull2 v[4];
+    for (; i + 4 <= i1; i += 4) {  // fixed-count inner loop: see evaluate_kernel.  Four rows in
+      ull2 v[4];                   // flight per thread: eight (rows are M*8 bytes apart) halves the rate
 #pragma unroll
       for (int k = 0; k < 4; ++k)
         v[k] = nt_load ? __builtin_nontemporal_load(Tp + (i + k) * mp + pc) : Tp[(i + k) * mp + pc];

@@ -575,8 +575,9 @@ int coldot(sc_ctx* ctx, const u64* in, const u64* w, size_t rows, size_t M, u64*
 }
 
 // Fold k variables of a device table (LE or BE), producing a pool buffer.  `in` is never
-// written.  LE: up to three variables per pass (read N, write N/8).  BE: one "column dot"
-// pass against the eq table of the k leading variables.
+// written.  LE: eight or more variables in one streaming segment-dot pass, fewer at up to three
+// per pass (read N, write N/8).  BE: one "column dot" pass against the eq table of the k
+// leading variables.
 int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, int order, u64** out,
                size_t* out_len) {
   if (k == 0) {
@@ -612,7 +613,18 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
   while (done < k) {
     int step;
     u64* nxt = nullptr;
-    if (order == SC_ORDER_LE) {
+    if (order == SC_ORDER_LE && k - done >= 8) {
+      // many variables left: one streaming pass over contiguous segments (kernels.hpp, fix_low_kernel)
+      step = (int)std::min<size_t>(17, k - done);
+      const size_t nlen = cur_len >> step;
+      SC_TRY(pool_alloc(ctx, nlen, &nxt));
+      const sc::RVec rv = make_rvec(r + done, (size_t)step);
+      const int grid = (int)std::min<size_t>((nlen + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
+      const int nt = cur_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                      cur, nxt, step, rv, nlen, nt));
+      cur_len = nlen;
+    } else if (order == SC_ORDER_LE) {
       step = (int)std::min<size_t>(3, k - done);
       while (step > 1 && (cur_len >> step) < 2) --step;
       size_t nlen = cur_len >> step;
