@@ -207,7 +207,8 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "sc::pass_kernel<GoldilocksMont,KF,KS> (all %d launches of a step)" % (n_launch // args.steps),
+                "kernel": "sc::pass_kernel<GoldilocksMont,KF,KS> and its tail form small_pass3_kernel (all %d launches "
+                          "of a step)" % (n_launch // args.steps),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

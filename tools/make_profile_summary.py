@@ -25,10 +25,17 @@ with open(os.path.join(P, "%s_kernel_stats.csv" % tag), "w") as f:
 
 # ---- per-launch trace of the last prover run
 trace = list(csv.DictReader(open(one(d_stats, "*_kernel_trace.csv"))))
+def is_pass(name):
+    return "pass_kernel<" in name or "small_pass3_kernel<" in name
 def passinfo(r):
-    m = re.search(r"pass_kernel<sc::(\w+), (\d), (\d)>", r["Kernel_Name"])
-    return (int(m.group(2)), int(m.group(3)), int(r["Grid_Size_X"]) // 256, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-seq = [passinfo(r) for r in trace if "pass_kernel" in r["Kernel_Name"]]
+    m = re.search(r"small_pass3_kernel<sc::(\w+), (\d)>", r["Kernel_Name"])
+    if m:
+        kf, ks = int(m.group(2)), 3      # the three-round tail pass
+    else:
+        m = re.search(r"pass_kernel<sc::(\w+), (\d), (\d)>", r["Kernel_Name"])
+        kf, ks = int(m.group(2)), int(m.group(3))
+    return (kf, ks, int(r["Grid_Size_X"]) // 256, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+seq = [passinfo(r) for r in trace if is_pass(r["Kernel_Name"])]
 runs, cur = [], []
 for x in seq:
     if x[0] == 0 and cur:
@@ -38,7 +45,7 @@ runs.append(cur)
 
 def counters(d, name):
     rows = list(csv.DictReader(open(one(d, "*_counter_collection.csv"))))
-    vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == name and "pass_kernel" in r["Kernel_Name"]]
+    vals = [float(r["Counter_Value"]) for r in rows if r["Counter_Name"] == name and is_pass(r["Kernel_Name"])]
     return vals[-len(runs[-1]):]
 fetch = counters(d_fetch, "FETCH_SIZE")
 write = counters(d_write, "WRITE_SIZE")
