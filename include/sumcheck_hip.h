@@ -80,7 +80,8 @@ const char* sc_last_error(const sc_ctx* ctx);
  * first pass, which has nothing to fold: 1|2|3, default 0 = three for tables of >= 2^26 entries,
  * two below; capped by vars_per_pass = 1), "tail_pass_vars" (rounds served by a folding pass whose
  * input has <= 2^19 entries, where passes are latency-bound: 3 (default) or 2), "tail_log" (shard log-size at which a sharded
- * prover gathers, default 16), "max_blocks" (grid cap, default 2048), "use_mailbox" (kernels
+ * prover gathers, default 16), "max_blocks" (grid cap of the streaming kernels, default 3 per CU = 768; a pass never
+ * launches more blocks than are resident at once), "use_mailbox" (kernels
  * publish sums to pinned host memory the host spins on, default 1), "time_kernels" (HIP-event
  * timing of pass kernels), "nt_load_log" / "nt_store_log" (table log-size from which loads /
  * stores are nontemporal). */

@@ -102,7 +102,10 @@ struct sc_ctx {
   int tail_pass_log = 19;  // largest input (log2 entries per table) that takes the three-round tail pass
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
                       // cheaper than the ~25 us of collective latency of each further sharded pass
-  int max_blocks = 2048;
+  // grid cap of the streaming kernels: three 256-thread blocks per CU (set in sc_ctx_create).
+  // Measured at n = 28: fix_variables k=1 685 us with 2048 blocks, 611 with 1024, 580 with 768,
+  // 629 with 512 - more blocks than that only add concurrent DRAM streams and a longer final reduction
+  int max_blocks = 768;
   int num_cus = 256;
   // blocks of each pass-kernel instantiation that fit on the chip at once ([generic|goldilocks][kf][ks],
   // 0 = not asked yet); [..][kf][0] with ks = 3, kf > 0 is the tail kernel
@@ -270,6 +273,15 @@ int grid_for(const sc_ctx* ctx, size_t n_threads_needed) {
   size_t g = (n_threads_needed + sc::kBlock - 1) / sc::kBlock;
   if (g < 1) g = 1;
   if (g > (size_t)ctx->max_blocks) g = ctx->max_blocks;
+  return (int)g;
+}
+// kernels that are bound by arithmetic or by scattered accesses, not by a stream: fill every
+// wave slot (eight blocks per CU)
+int grid_for_wide(const sc_ctx* ctx, size_t n_threads_needed) {
+  size_t g = (n_threads_needed + sc::kBlock - 1) / sc::kBlock;
+  const size_t cap = std::min<size_t>((size_t)8 * ctx->num_cus, ctx->partial_rows);
+  if (g < 1) g = 1;
+  if (g > cap) g = cap;
   return (int)g;
 }
 
@@ -585,7 +597,7 @@ int build_eq_table(sc_ctx* ctx, const u64* r, int nbits, u64** out) {
   u64* t = nullptr;
   SC_TRY(pool_alloc(ctx, (size_t)1 << nbits, &t));
   sc::RVec rv = make_rvec(r, (size_t)nbits);
-  int grid = grid_for(ctx, (size_t)1 << nbits);
+  int grid = grid_for_wide(ctx, (size_t)1 << nbits);
   SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::eq_table_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
                                                   rv, 0, nbits, t));
   hipError_t e = hipGetLastError();
@@ -812,6 +824,7 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
   {
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cus > 0) ctx->num_cus = cus;
+    ctx->max_blocks = 3 * ctx->num_cus;
   }
   ctx->partial_rows = 4096;
   SC_CREATE_HIP(hipMalloc(&ctx->d_partials, ctx->partial_rows * 32 * sizeof(u64)));
@@ -1020,7 +1033,7 @@ extern "C" int sc_table_generate(sc_ctx* ctx, uint64_t seed, uint64_t start, siz
   SC_TRY(set_device(ctx));
   sc_table* t = nullptr;
   SC_TRY(new_table(ctx, len, &t));
-  int grid = grid_for(ctx, len);
+  int grid = grid_for_wide(ctx, len);
   SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::generate_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
                                                   f, (u64)seed, (u64)start, len, t->d));
   hipError_t e = hipGetLastError();
@@ -1182,7 +1195,7 @@ extern "C" int sc_table_relabel(sc_ctx* ctx, const sc_table* in, size_t a, size_
   SC_TRY(set_device(ctx));
   sc_table* t = nullptr;
   SC_TRY(new_table(ctx, in->len, &t));
-  int grid = grid_for(ctx, in->len);
+  int grid = grid_for_wide(ctx, in->len);
   hipLaunchKernelGGL(sc::relabel_kernel, dim3(grid), dim3(sc::kBlock), 0, ctx->stream, (const u64*)in->d, t->d, in->len,
                      (unsigned)a, (unsigned)b, (unsigned)k);
   hipError_t e = hipGetLastError();
@@ -1728,7 +1741,7 @@ extern "C" int sc_gkr_wiring(sc_ctx* ctx, const int32_t* gate_type, const uint32
     if (e == hipSuccess) e = hipMemsetAsync(ta->d, 0, len * sizeof(u64), ctx->stream);
     if (e == hipSuccess) e = hipMemsetAsync(tm->d, 0, len * sizeof(u64), ctx->stream);
     if (e == hipSuccess) {
-      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_wiring_scatter_kernel<F>), dim3(grid_for(ctx, n_gates)),
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_wiring_scatter_kernel<F>), dim3(grid_for_wide(ctx, n_gates)),
                                                       dim3(sc::kBlock), 0, ctx->stream, f, (const u64*)eq, (const int*)d_type,
                                                       (const unsigned*)d_in0, (const unsigned*)d_in1, n_gates, (int)k_next,
                                                       ta->d, tm->d));
@@ -1757,7 +1770,7 @@ extern "C" int sc_gkr_w_to_evaluations(sc_ctx* ctx, const sc_table* add, const s
   SC_TRY(set_device(ctx));
   sc_table* t = nullptr;
   SC_TRY(new_table(ctx, add->len, &t));
-  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_to_evaluations_kernel<F>), dim3(grid_for(ctx, add->len)),
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_to_evaluations_kernel<F>), dim3(grid_for_wide(ctx, add->len)),
                                                   dim3(sc::kBlock), 0, ctx->stream, f, w.add, w.mul, w.w_b, w.kb, w.w_c, w.kc,
                                                   t->d));
   hipError_t e = hipGetLastError();
@@ -1848,7 +1861,7 @@ int gkr_sparse_round(sc_gkr_prover* pr, int shift, u64 r_prev, u64 e[3]) {
   const u64* V = pr->kb >= 1 ? pr->w_b : pr->w_c;
   const int logV = pr->kb >= 1 ? pr->kb : pr->kc;
   const u64* Fx = pr->kb >= 1 ? pr->w_c : pr->w_b;
-  const int grid = grid_for(ctx, pr->n_entries);
+  const int grid = grid_for_wide(ctx, pr->n_entries);
   sc::PassOut out = next_pass_out(ctx, grid);
   SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_sparse_round_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
                                                   f, (const unsigned*)pr->sp_idx, (const int*)pr->sp_type, pr->sp_val,
@@ -1897,7 +1910,7 @@ extern "C" int sc_gkr_prover_create_sparse(sc_ctx* ctx, const int32_t* gate_type
     if (e == hipSuccess) e = hipMemcpyAsync(d_in0, in0, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(d_in1, in1, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) {
-      hipLaunchKernelGGL(sc::gkr_sparse_init_kernel, dim3(grid_for(ctx, n_gates)), dim3(sc::kBlock), 0, ctx->stream,
+      hipLaunchKernelGGL(sc::gkr_sparse_init_kernel, dim3(grid_for_wide(ctx, n_gates)), dim3(sc::kBlock), 0, ctx->stream,
                          (const u64*)eq, (const unsigned*)d_in0, (const unsigned*)d_in1, n_gates, (int)k_next, pr->sp_idx,
                          pr->sp_val);
       e = hipGetLastError();
@@ -2078,7 +2091,7 @@ extern "C" int sc_tri_to_evaluations(sc_ctx* ctx, const sc_table* f1, const sc_t
   const size_t total = (size_t)1 << (v.xv + v.yv + v.zv);
   sc_table* t = nullptr;
   SC_TRY(new_table(ctx, total, &t));
-  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::tri_to_evaluations_kernel<F>), dim3(grid_for(ctx, total)),
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::tri_to_evaluations_kernel<F>), dim3(grid_for_wide(ctx, total)),
                                                   dim3(sc::kBlock), 0, ctx->stream, f, v.f1, v.f2, v.f3, v.xv, v.yv, v.zv, t->d));
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -2098,7 +2111,7 @@ extern "C" int sc_tri_round_sums(sc_ctx* ctx, const sc_table* f1, const sc_table
   SC_TRY(set_device(ctx));
   if (v.xv + v.yv + v.zv < 1) return fail(ctx, SC_ERR_ARG, "triangle G: no variable left");
   const size_t total = (size_t)1 << (v.xv + v.yv + v.zv - 1);
-  const int grid = grid_for(ctx, total);
+  const int grid = grid_for_wide(ctx, total);
   sc::PassOut out = next_pass_out(ctx, grid);
   SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::tri_sums_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
                                                   v.f1, v.f2, v.f3, v.xv, v.yv, v.zv, out));
@@ -2217,7 +2230,7 @@ extern "C" int sc_tri_prover_create(sc_ctx* ctx, const sc_table* adj, size_t var
   tp->k = (int)var_len;
   int rc = pool_alloc(ctx, adj->len, &tp->P);
   if (rc == SC_OK) {
-    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::matsq_kernel<F>), dim3(grid_for(ctx, adj->len)), dim3(sc::kBlock), 0,
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::matsq_kernel<F>), dim3(grid_for_wide(ctx, adj->len)), dim3(sc::kBlock), 0,
                                                     ctx->stream, f, (const u64*)adj->d, tp->k, tp->P));
     if (hipGetLastError() != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "matsq_kernel launch failed");
   }

@@ -7,6 +7,8 @@ class pyref:  # seeds of the synthetic instance; tools n
     SEED_A, SEED_B, SEED_R, SEED_PT = 0xA5A5000000000001, 0xB6B6000000000002, 0xC7C7000000000003, 0xD8D8000000000004
 F = pkg.Field(pkg.GOLDILOCKS)
 ctx = pkg.Context(F)
+for kv in sys.argv[2:]:
+    ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 def med(fn, reps=9):
     fn(); fn()
     ts = []
