@@ -287,23 +287,40 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
   __syncthreads();
   if (!*lds_flag) return;
   const int n_blocks = gridDim.x;
-  for (int s = wave; s < NS; s += kBlock / kWave) {
-    const u64* row = o.partials + (size_t)s * o.n_rows;
-    u64 t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+  // each wave takes the rows wave, wave+4, ... two at a time: the loads of one row are a chain of
+  // dependent rounds (~1 us each from L2), so two rows in flight halve the serial tail
+  constexpr int kWavesPerBlock = kBlock / kWave;
+  for (int s = wave; s < NS; s += 2 * kWavesPerBlock) {
+    const int s2 = s + kWavesPerBlock;
+    const bool two = s2 < NS;
+    const u64* row0 = o.partials + (size_t)s * o.n_rows;
+    const u64* row1 = o.partials + (size_t)(two ? s2 : s) * o.n_rows;
+    u64 a0 = 0, a1 = 0, c0 = 0, c1 = 0;
     int b = lane;
-    for (; b + 3 * kWave < n_blocks; b += 4 * kWave) {
-      const u64 x0 = __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const u64 x1 = __hip_atomic_load(row + b + kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const u64 x2 = __hip_atomic_load(row + b + 2 * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const u64 x3 = __hip_atomic_load(row + b + 3 * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      t0 = f.add(t0, x0); t1 = f.add(t1, x1); t2 = f.add(t2, x2); t3 = f.add(t3, x3);
-    }
-    for (; b < n_blocks; b += kWave)
-      t0 = f.add(t0, __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    u64 t = f.add(f.add(t0, t1), f.add(t2, t3));
+    for (; b + 3 * kWave < n_blocks; b += 4 * kWave) {  // eight loads in flight per lane
+      u64 x[4], y[4];
 #pragma unroll
-    for (int off = kWave / 2; off >= 1; off >>= 1) t = f.add(t, shfl_down_u64(t, off));
-    if (lane == 0) publish_value(o, s, t);
+      for (int q = 0; q < 4; ++q) {
+        x[q] = __hip_atomic_load(row0 + b + q * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        y[q] = __hip_atomic_load(row1 + b + q * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      a0 = f.add(a0, f.add(x[0], x[2])); a1 = f.add(a1, f.add(x[1], x[3]));
+      c0 = f.add(c0, f.add(y[0], y[2])); c1 = f.add(c1, f.add(y[1], y[3]));
+    }
+    for (; b < n_blocks; b += kWave) {
+      a0 = f.add(a0, __hip_atomic_load(row0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      c0 = f.add(c0, __hip_atomic_load(row1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+    u64 t = f.add(a0, a1), u = f.add(c0, c1);
+#pragma unroll
+    for (int off = kWave / 2; off >= 1; off >>= 1) {
+      t = f.add(t, shfl_down_u64(t, off));
+      u = f.add(u, shfl_down_u64(u, off));
+    }
+    if (lane == 0) {
+      publish_value(o, s, t);
+      if (two) publish_value(o, s2, u);
+    }
   }
   __syncthreads();
   publish_seq(o);
