@@ -76,15 +76,19 @@ int sc_ctx_create(const sc_field* f, int device, sc_ctx** out);
 int sc_ctx_destroy(sc_ctx* ctx);
 /* message of the last failing call on ctx (ctx == NULL: last failing sc_ctx_create) */
 const char* sc_last_error(const sc_ctx* ctx);
-/* Tunables: "vars_per_pass" (1|2, default 2), "first_pass_vars" (rounds served by the prover's
- * first pass, which has nothing to fold: 1|2|3, default 0 = three for tables of >= 2^26 entries,
- * two below; capped by vars_per_pass = 1), "tail_pass_vars" (rounds served by a folding pass whose
- * input has <= 2^19 entries, where passes are latency-bound: 3 (default) or 2), "tail_log" (shard log-size at which a sharded
- * prover gathers, default 16), "max_blocks" (grid cap of the streaming kernels, default 3 per CU = 768; a pass never
- * launches more blocks than are resident at once), "use_mailbox" (kernels
- * publish sums to pinned host memory the host spins on, default 1), "time_kernels" (HIP-event
- * timing of pass kernels), "nt_load_log" / "nt_store_log" (table log-size from which loads /
- * stores are nontemporal). */
+/* Tunables (all have working defaults; they exist for measurements and tests):
+ *   "vars_per_pass"    rounds served by one device pass: 1 | 2 (default 2)
+ *   "first_pass_vars"  rounds served by the prover's first pass, which has nothing to fold:
+ *                      1 | 2 | 3, default 0 = three for tables of >= 2^26 entries, two below
+ *                      (never more than vars_per_pass allows)
+ *   "tail_pass_vars"   rounds served by a folding pass whose input has <= 2^"tail_pass_log"
+ *                      (default 19) entries, where every pass is latency-bound: 3 (default) | 2
+ *   "tail_log"         shard log-size at which a sharded prover gathers (default 16)
+ *   "max_blocks"       grid cap of the streaming kernels (default 3 per CU = 768); a pass never
+ *                      launches more blocks than are resident at once
+ *   "use_mailbox"      kernels publish sums to pinned host memory the host spins on (default 1)
+ *   "time_kernels"     HIP-event timing of pass kernels (see sc_ctx_kernel_time)
+ *   "nt_load_log" / "nt_store_log"  table log-size from which loads / stores are nontemporal */
 int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value);
 int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* value);
 int sc_ctx_synchronize(sc_ctx* ctx);
