@@ -166,7 +166,7 @@ def main():
     achieved = (alg_bytes / world) * args.steps / kernel_s / 1e9 if kernel_s > 0 else None
 
     # rounds served by the first pass: the library's size rule unless the option pins it
-    first_pass = ctx.get_option("first_pass_vars") or (3 if nl >= 26 else 2)
+    first_pass = ctx.get_option("first_pass_vars") or (3 if nl >= 18 else 2)
     first_pass = min(first_pass, 3 if args.vars_per_pass == 2 else 1)
     result = None
     if rank == 0:

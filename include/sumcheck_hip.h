@@ -79,7 +79,7 @@ const char* sc_last_error(const sc_ctx* ctx);
 /* Tunables (all have working defaults; they exist for measurements and tests):
  *   "vars_per_pass"    rounds served by one device pass: 1 | 2 (default 2)
  *   "first_pass_vars"  rounds served by the prover's first pass, which has nothing to fold:
- *                      1 | 2 | 3, default 0 = three for tables of >= 2^26 entries, two below
+ *                      1 | 2 | 3, default 0 = three for tables of >= 2^18 entries, two below
  *                      (never more than vars_per_pass allows)
  *   "tail_pass_vars"   rounds served by a folding pass whose input has <= 2^"tail_pass_log"
  *                      (default 19) entries, where every pass is latency-bound: 3 (default) | 2

@@ -93,8 +93,8 @@ struct sc_ctx {
   // options
   int vars_per_pass = 2;
   // rounds served by the first pass (which folds nothing): 1..3, or 0 = by size - three for tables
-  // of >= 2^26 entries (the 27-cell grid runs at two waves per SIMD, which a small grid cannot
-  // hide; on large tables it saves an eighth of the traffic), two below
+  // of >= 2^18 entries (it saves an eighth of the traffic of a large proof and a pass of a small
+  // one), two below
   int first_pass_vars = 0;
   // rounds served by a folding pass once its input is small (<= kTailPass3Log): 3, or 2 to keep
   // two everywhere
@@ -1439,7 +1439,9 @@ struct sc_prover {
 
 namespace {
 
-constexpr int kFirstPass3Log = 26;  // measured: n = 24 0.35 vs 0.38 ms, 25 equal, 26 0.79 vs 0.73, 28 2.41 vs 2.13
+// measured (two vs three rounds from the first pass, ms): n = 16 0.109 / 0.116, 18 0.128 / 0.125, 20 0.167 / 0.152,
+// 22 0.204 / 0.198, 24 0.307 / 0.294, 26 0.75 / 0.68, 28 2.36 / 2.13
+constexpr int kFirstPass3Log = 18;
 
 int prover_pass(sc_prover* pr, size_t j) {
   sc_ctx* ctx = pr->ctx;
