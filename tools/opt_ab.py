@@ -10,6 +10,9 @@ SEED_A, SEED_B, SEED_R = 0xA5A5000000000001, 0xB6B6000000000002, 0xC7C7000000000
 opt, va, vb = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
 ns = [int(x) for x in sys.argv[4:]] or [24, 28]
 ctx = pkg.Context(pkg.Field(pkg.GOLDILOCKS))
+for kv in os.environ.get("SC_AB_FIXED", "").split(","):   # options held fixed during the comparison
+    if kv:
+        ctx.set_option(kv.split("=")[0], int(kv.split("=")[1]))
 for n in ns:
     a = pkg.DenseMultilinearExtension.generate(ctx, SEED_A, n)
     b = pkg.DenseMultilinearExtension.generate(ctx, SEED_B, n)
