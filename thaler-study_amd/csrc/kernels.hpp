@@ -20,6 +20,23 @@ constexpr int kMaxSums = 27;      // 3^3 grid cells of a three-round pass
 
 typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
 
+// 16-byte global accesses with a COMPILE-TIME streaming hint.  Tables that are read once (or
+// written for a much later reader) go around the caches with `nt` accesses: on this chip a plain
+// read stream reaches 6.2-6.3 TB/s, a nontemporal one 6.9-7.0 TB/s, a copy 5.3 against 5.5 TB/s
+// with nontemporal stores (tools/streambench.hip).  The hint has to be a template parameter:
+// written as `flag ? __builtin_nontemporal_load(p) : *p` the two loads are merged into one
+// plain load and the hint is lost (that is what the first version of these kernels did).
+template <bool NT>
+__device__ __forceinline__ ull2 ld16(const ull2* __restrict__ p) {
+  if constexpr (NT) return __builtin_nontemporal_load(p);
+  else return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st16(ull2* __restrict__ p, ull2 v) {
+  if constexpr (NT) __builtin_nontemporal_store(v, p);
+  else *p = v;
+}
+
 // Fold weights of one pass: w[c] = eq((r0,..,r_{KF-1}), c) = prod_j (bit_j(c) ? r_j : 1 - r_j),
 // computed exactly on the host (Montgomery words).  KF = 1 uses w[1] = r0.
 struct FoldW {
@@ -326,10 +343,12 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
   publish_seq(o);
 }
 
-template <class F, int KF, int KS>
+// NT: bit 0 = nontemporal loads, bit 1 = nontemporal stores (see ld16 / st16)
+template <class F, int KF, int KS, int NT>
 __global__ void __launch_bounds__(kBlock)
 pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
-            u64* __restrict__ B2, FoldW fw, size_t n_units, PassOut out, int nt_load, int nt_store) {
+            u64* __restrict__ B2, FoldW fw, size_t n_units, PassOut out) {
+  constexpr bool kNtLoad = (NT & 1) != 0, kNtStore = (NT & 2) != 0;
   constexpr int IN = 1 << (KF + KS), OUT = 1 << KS, NS = (KS == 1) ? 3 : (KS == 2) ? 9 : 27;
   constexpr int NP = IN / 2, NPO = OUT / 2;  // 16-byte pieces per lane, in and out
   constexpr int kWaves = kBlock / kWave;
@@ -358,8 +377,8 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
 #pragma unroll
       for (int k = 0; k < NP; ++k) {
         const size_t q = q0 + (size_t)k * kWave + lane;
-        pa[k] = nt_load ? __builtin_nontemporal_load(Ap + q) : Ap[q];
-        pb[k] = nt_load ? __builtin_nontemporal_load(Bp + q) : Bp[q];
+        pa[k] = ld16<kNtLoad>(Ap + q);
+        pb[k] = ld16<kNtLoad>(Bp + q);
       }
     } else {
 #pragma unroll
@@ -430,13 +449,8 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
       for (int k = 0; k < NPO; ++k) {
         const size_t q = o0 + (size_t)k * kWave + lane;
         if (q < out_pieces) {
-          if (nt_store) {
-            __builtin_nontemporal_store(oa[k], A2p + q);
-            __builtin_nontemporal_store(ob[k], B2p + q);
-          } else {
-            A2p[q] = oa[k];
-            B2p[q] = ob[k];
-          }
+          st16<kNtStore>(A2p + q, oa[k]);
+          st16<kNtStore>(B2p + q, ob[k]);
         }
       }
     }
@@ -570,9 +584,9 @@ small_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u6
 // LE fold of KF in {1,2,3} variables in one pass: coalesced 16-byte loads, wave-private LDS
 // transposition (a lane needs 2^(KF+1) consecutive entries), one coalesced 16-byte store
 // per lane.  n_units = number of output pieces (pairs of output entries).
-template <class F, int KF>
+template <class F, int KF, bool NT>
 __global__ void __launch_bounds__(kBlock)
-fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, FoldW fw, size_t n_units, int nt_load) {
+fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, FoldW fw, size_t n_units) {
   constexpr int IN = 2 << KF, NP = IN / 2;
   constexpr int kWaves = kBlock / kWave;
   __shared__ ull2 lds_t[kWaves * kWave * NP];
@@ -587,7 +601,8 @@ fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, FoldW fw, size
     for (int k = 0; k < NP; ++k) {
       const size_t q = tile * kWave * NP + (size_t)k * kWave + lane;
       const ull2 zero = {0, 0};
-      pv[k] = (q < in_pieces) ? (nt_load ? __builtin_nontemporal_load(Tp + q) : Tp[q]) : zero;
+      pv[k] = zero;
+      if (q < in_pieces) pv[k] = ld16<NT>(Tp + q);
     }
     transpose_to_runs<NP>(my_lds, pv, lane);
     u64 v[IN];
@@ -657,10 +672,9 @@ eq_table_kernel(F f, RVec rv, int off, int nbits, u64* __restrict__ out) {
 // eqB; the bit-0 and lane weights are applied once per thread at the end.  This is the
 // streaming form of vsbw_multilinear_from_evaluations' "eq table, then dot product"
 // (multilinear-extensions/src/lib.rs:6-24) without materialising the 2^n eq table.
-template <class F>
+template <class F, bool NT>
 __global__ void __launch_bounds__(kBlock)
-evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chunk_log, u64 w_extra, PassOut out,
-                int nt_load) {
+evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chunk_log, u64 w_extra, PassOut out) {
   constexpr int kWaves = kBlock / kWave;
   __shared__ u64 eqA[1024];  // ta <= 10
   __shared__ u64 lds[kWaves];
@@ -700,7 +714,7 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const size_t q = (tile0 + i + k) * kWave + lane;
-        pc[k] = nt_load ? __builtin_nontemporal_load(Tp + q) : Tp[q];
+        pc[k] = ld16<NT>(Tp + q);
       }
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
@@ -711,7 +725,7 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
     }
     for (; i < C; ++i) {
       const size_t q = (tile0 + i) * kWave + lane;
-      const ull2 pc = nt_load ? __builtin_nontemporal_load(Tp + q) : Tp[q];
+      const ull2 pc = ld16<NT>(Tp + q);
       const u64 w = eqA[in_seg + i];
       f.acc_mac(a0, pc.x, w);
       f.acc_mac(a1, pc.y, w);
@@ -744,9 +758,9 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
 // once per segment, a shuffle reduction, one 8-byte store).  A chain of three-variable folds
 // reads the table 1.14 times and writes an eighth of it; this reads it once.
 // (DenseMultilinearExtension::fix_variables with many variables; the f_B half of G::new.)
-template <class F>
+template <class F, bool NT>
 __global__ void __launch_bounds__(kBlock)
-fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVec rv, size_t n_out, int nt_load) {
+fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVec rv, size_t n_out) {
   constexpr int kWaves = kBlock / kWave;
   __shared__ u64 eqA[1024];  // k - 7 <= 10
   const int lane = threadIdx.x & (kWave - 1);
@@ -779,7 +793,7 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
     for (; i + 8 <= tiles; i += 8) {
       ull2 pc[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) pc[q] = nt_load ? __builtin_nontemporal_load(Sp + (size_t)(i + q) * kWave) : Sp[(size_t)(i + q) * kWave];
+      for (int q = 0; q < 8; ++q) pc[q] = ld16<NT>(Sp + (size_t)(i + q) * kWave);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const u64 w = eqA[i + q];
@@ -806,10 +820,10 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
 // several).  This is fix_variables of the TOP k index bits (BE order), and the f_A half of
 // G::new: f_A[col] = sum_row eq(r1)[row] * A[row][col] (matrix-multiplication/src/lib.rs:81-83,
 // relabel + fold collapsed into one pass).  Lanes own 16-byte pieces of c: coalesced.
-template <class F>
+template <class F, bool NT>
 __global__ void __launch_bounds__(kBlock)
 coldot_kernel(F f, const u64* __restrict__ T, const u64* __restrict__ w, size_t rows, size_t rows_per_chunk,
-              size_t M, u64* __restrict__ partial, int nt_load) {
+              size_t M, u64* __restrict__ partial) {
   const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
   ull2* __restrict__ Pp = reinterpret_cast<ull2*>(partial);
   const size_t mp = M / 2;  // pieces per row
@@ -824,7 +838,7 @@ coldot_kernel(F f, const u64* __restrict__ T, const u64* __restrict__ w, size_t 
       ull2 v[4];                   // flight per thread: eight (rows are M*8 bytes apart) halves the rate
 #pragma unroll
       for (int k = 0; k < 4; ++k)
-        v[k] = nt_load ? __builtin_nontemporal_load(Tp + (i + k) * mp + pc) : Tp[(i + k) * mp + pc];
+        v[k] = ld16<NT>(Tp + (i + k) * mp + pc);
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const u64 wi = w[i + k];
@@ -833,7 +847,7 @@ coldot_kernel(F f, const u64* __restrict__ T, const u64* __restrict__ w, size_t 
       }
     }
     for (; i < i1; ++i) {
-      const ull2 v = nt_load ? __builtin_nontemporal_load(Tp + i * mp + pc) : Tp[i * mp + pc];
+      const ull2 v = ld16<NT>(Tp + i * mp + pc);
       const u64 wi = w[i];
       f.acc_mac(a0, v.x, wi);
       f.acc_mac(a1, v.y, wi);

@@ -347,7 +347,7 @@ void drain_kernel_timers(sc_ctx* ctx) {
 template <class F>
 int pass_resident_blocks_t(sc_ctx* ctx, int kf, int ks) {
   const void* fn = nullptr;
-#define SC_FN(KF, KS) fn = reinterpret_cast<const void*>(&sc::pass_kernel<F, KF, KS>)
+#define SC_FN(KF, KS) fn = reinterpret_cast<const void*>(&sc::pass_kernel<F, KF, KS, 1>)
   if (ks == 3 && kf > 0) {
     if (kf == 1) fn = reinterpret_cast<const void*>(&sc::small_pass3_kernel<F, 1>);
     else if (kf == 2) fn = reinterpret_cast<const void*>(&sc::small_pass3_kernel<F, 2>);
@@ -391,10 +391,18 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
                    u64* B2, const sc::FoldW& fw, size_t n_units, int grid, int log_in, const sc::PassOut& out) {
   dim3 g(grid), b(sc::kBlock);
   hipStream_t s = ctx->stream;
-  const int nt_ld = log_in >= ctx->nt_load_log ? 1 : 0;
-  const int nt_st = (log_in - kf) >= ctx->nt_store_log ? 1 : 0;
-#define SC_PASS(KF, KS) \
-  hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS>), g, b, 0, s, f, A, B, A2, B2, fw, n_units, out, nt_ld, nt_st)
+  // streaming hints are compile-time (kernels.hpp, ld16/st16): 0 = cached, 1 = stream the inputs,
+  // 3 = stream inputs and outputs
+  const int nt = (log_in >= ctx->nt_load_log ? 1 : 0) | ((kf > 0 && (log_in - kf) >= ctx->nt_store_log) ? 2 : 0);
+#define SC_PASS(KF, KS)                                                                                            \
+  do {                                                                                                             \
+    if (nt == 3)                                                                                                   \
+      hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS, 3>), g, b, 0, s, f, A, B, A2, B2, fw, n_units, out);          \
+    else if (nt & 1)                                                                                               \
+      hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS, 1>), g, b, 0, s, f, A, B, A2, B2, fw, n_units, out);          \
+    else                                                                                                           \
+      hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS, 0>), g, b, 0, s, f, A, B, A2, B2, fw, n_units, out);          \
+  } while (0)
   if (ks == 3 && kf > 0) {  // tail pass: one thread per output (kernels.hpp, small_pass3_kernel)
     const size_t n_out = n_units * 8;
     switch (kf) {
@@ -626,8 +634,12 @@ int coldot(sc_ctx* ctx, const u64* in, const u64* w, size_t rows, size_t M, u64*
   size_t gx = (mp + sc::kBlock - 1) / sc::kBlock;
   if (gx > 1024) gx = 1024;
   const int nt = (rows * M) >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
-  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::coldot_kernel<F>), dim3((unsigned)gx, (unsigned)chunks), dim3(sc::kBlock),
-                                                  0, ctx->stream, f, in, w, rows, rows_per_chunk, M, partial, nt));
+  if (nt)
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::coldot_kernel<F, true>), dim3((unsigned)gx, (unsigned)chunks),
+                                                    dim3(sc::kBlock), 0, ctx->stream, f, in, w, rows, rows_per_chunk, M, partial));
+  else
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::coldot_kernel<F, false>), dim3((unsigned)gx, (unsigned)chunks),
+                                                    dim3(sc::kBlock), 0, ctx->stream, f, in, w, rows, rows_per_chunk, M, partial));
   if (chunks > 1) {
     int grid = grid_for(ctx, M);
     SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::sum_rows_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
@@ -685,8 +697,12 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
       const sc::RVec rv = make_rvec(r + done, (size_t)step);
       const int grid = (int)std::min<size_t>((nlen + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
       const int nt = cur_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
-      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
-                                                      cur, nxt, step, rv, nlen, nt));
+      if (nt)
+        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F, true>), dim3(grid), dim3(sc::kBlock), 0,
+                                                        ctx->stream, f, cur, nxt, step, rv, nlen));
+      else
+        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F, false>), dim3(grid), dim3(sc::kBlock), 0,
+                                                        ctx->stream, f, cur, nxt, step, rv, nlen));
       cur_len = nlen;
     } else if (order == SC_ORDER_LE) {
       step = (int)std::min<size_t>(3, k - done);
@@ -698,9 +714,15 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
         size_t n_units = nlen / 2;
         int grid = grid_for(ctx, n_units);
         const int nt = cur_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
-#define SC_FOLD(KF)                                                                                                 \
-  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_kernel<F, KF>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, \
-                                                  f, cur, nxt, fw, n_units, nt))
+#define SC_FOLD(KF)                                                                                                  \
+  do {                                                                                                               \
+    if (nt)                                                                                                          \
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_kernel<F, KF, true>), dim3(grid), dim3(sc::kBlock), 0, \
+                                                      ctx->stream, f, cur, nxt, fw, n_units));                       \
+    else                                                                                                             \
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_kernel<F, KF, false>), dim3(grid), dim3(sc::kBlock), 0, \
+                                                      ctx->stream, f, cur, nxt, fw, n_units));                       \
+  } while (0)
         if (step == 3) SC_FOLD(3);
         else if (step == 2) SC_FOLD(2);
         else SC_FOLD(1);
@@ -1145,8 +1167,12 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
   out.seq = mailbox ? ++ctx->mailbox_seq : 0;
   if (grid > 1) ctx->ticket_base += (unsigned)grid;
   const int nt = nv >= ctx->nt_load_log ? 1 : 0;
-  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::evaluate_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, d,
-                                                  nv, rv, ta, chunk_log, w_extra, out, nt));
+  if (nt)
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::evaluate_kernel<F, true>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
+                                                    f, d, nv, rv, ta, chunk_log, w_extra, out));
+  else
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::evaluate_kernel<F, false>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
+                                                    f, d, nv, rv, ta, chunk_log, w_extra, out));
   SC_HIP(ctx, hipGetLastError());
   *from_mailbox = mailbox;
   return SC_OK;
