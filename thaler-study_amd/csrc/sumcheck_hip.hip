@@ -111,7 +111,7 @@ struct sc_ctx {
   // 0 = not asked yet); [..][kf][0] with ks = 3, kf > 0 is the tail kernel
   int resident_blocks[2][4][4] = {};
   int time_kernels = 0;
-  int nt_load_log = 25;   // tables of >= 2^this entries are loaded nontemporal
+  int nt_load_log = 22;   // tables of >= 2^this entries are loaded nontemporal (measured: 21-25 equal, 27 and off worse)
   int nt_store_log = 25;  // outputs of >= 2^this entries are stored nontemporal
 
   // workspace

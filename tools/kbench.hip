@@ -24,8 +24,12 @@ double run(const char* tag, u64* A, u64* B, u64* A2, u64* B2, u64* P, u64* S, in
     PassOut out; out.partials = P; out.n_rows = 4096; out.ticket = (unsigned*)(S + 40); out.ticket_base = g_ticket_base;
     out.sums_dev = S; out.mailbox = nullptr; out.seq = 0;
     if (grid > 1) g_ticket_base += grid;
-    hipLaunchKernelGGL((pass_kernel<GoldilocksMont, KF, KS>), dim3(grid), dim3(kBlock), 0, 0, f, A, B, A2, B2,
-                       fw, n_units, out, nt_ld, nt_st);
+    if (nt_ld && nt_st)
+      hipLaunchKernelGGL((pass_kernel<GoldilocksMont, KF, KS, 3>), dim3(grid), dim3(kBlock), 0, 0, f, A, B, A2, B2, fw, n_units, out);
+    else if (nt_ld)
+      hipLaunchKernelGGL((pass_kernel<GoldilocksMont, KF, KS, 1>), dim3(grid), dim3(kBlock), 0, 0, f, A, B, A2, B2, fw, n_units, out);
+    else
+      hipLaunchKernelGGL((pass_kernel<GoldilocksMont, KF, KS, 0>), dim3(grid), dim3(kBlock), 0, 0, f, A, B, A2, B2, fw, n_units, out);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     if (r >= 2) ts.push_back(ms);
