@@ -100,6 +100,9 @@ struct MontGeneric {
     for (int k = 0; k < 4; ++k) d[k] = split64(sub(join64(a[k]), join64(b[k])));
   }
   SC_HD X64 sub(X64 a, X64 b) const { return split64(sub(join64(a), join64(b))); }
+  SC_HD void sub2(X64 (&d)[2], const X64 (&a)[2], const X64 (&b)[2]) const {
+    for (int k = 0; k < 2; ++k) d[k] = split64(sub(join64(a[k]), join64(b[k])));
+  }
 
   // (hi:lo) < p * 2^64  ->  (hi:lo) * 2^-64 mod p
   SC_HD u64 redc(u64 hi, u64 lo) const {
@@ -167,9 +170,12 @@ struct GoldilocksMont {
   // Four independent differences d[k] = a[k] - b[k] (mod p).  On the device the four borrow
   // chains are interleaved by hand: gfx950 needs two wait states between a VALU that writes a
   // carry (SGPR pair / VCC) and the VALU that consumes it, so one subtraction on its own is
-  // 6 instructions + ~4 s_nop from the compiler; four together are 20 instructions, no s_nop.
-  // Per chain: d = a - b (borrow bw); on borrow subtract EPS = 2^32 - 1, i.e. d0 += bw (carry c),
-  // d1 -= bw, d1 += c.
+  // 6 instructions + ~4 s_nop from the compiler; four together are 16 VALU + 4 SALU, no s_nop.
+  // Per chain: d = a - b (borrow bw); on borrow subtract EPS = 2^32 - 1, i.e. d0 += bw (carry c)
+  // and d1 -= (bw & ~c); that mask is formed on the scalar unit (a VALU-written carry can be read
+  // by the next SALU instruction, and SALU issue does not take a VALU slot): 4 VALU per subtraction.
+  // s_andn2 writes SCC: the clobber list says so (without it a loop counter compare kept in SCC
+  // across the block is destroyed and the kernel never ends - found the hard way).
   SC_HD void sub4(X64 (&d)[4], const X64 (&a)[4], const X64 (&b)[4]) const {
 #if defined(__HIP_DEVICE_COMPILE__)
     asm("v_sub_co_u32_e64 %0, vcc, %8, %16\n\t"
@@ -184,25 +190,49 @@ struct GoldilocksMont {
         "v_addc_co_u32_e64 %1, s[80:81], %1, 0, s[72:73]\n\t"
         "v_addc_co_u32_e64 %2, s[82:83], %2, 0, s[74:75]\n\t"
         "v_addc_co_u32_e64 %3, s[84:85], %3, 0, s[76:77]\n\t"
-        "v_subb_co_u32_e64 %4, vcc, %4, 0, vcc\n\t"
-        "v_subb_co_u32_e64 %5, s[72:73], %5, 0, s[72:73]\n\t"
-        "v_subb_co_u32_e64 %6, s[74:75], %6, 0, s[74:75]\n\t"
-        "v_subb_co_u32_e64 %7, s[76:77], %7, 0, s[76:77]\n\t"
-        "v_addc_co_u32_e64 %4, s[78:79], %4, 0, s[78:79]\n\t"
-        "v_addc_co_u32_e64 %5, s[80:81], %5, 0, s[80:81]\n\t"
-        "v_addc_co_u32_e64 %6, s[82:83], %6, 0, s[82:83]\n\t"
-        "v_addc_co_u32_e64 %7, s[84:85], %7, 0, s[84:85]"
+        "s_andn2_b64 vcc, vcc, s[78:79]\n\t"
+        "s_andn2_b64 s[72:73], s[72:73], s[80:81]\n\t"
+        "s_andn2_b64 s[74:75], s[74:75], s[82:83]\n\t"
+        "s_andn2_b64 s[76:77], s[76:77], s[84:85]\n\t"
+        "v_subb_co_u32_e64 %4, s[78:79], %4, 0, vcc\n\t"
+        "v_subb_co_u32_e64 %5, s[80:81], %5, 0, s[72:73]\n\t"
+        "v_subb_co_u32_e64 %6, s[82:83], %6, 0, s[74:75]\n\t"
+        "v_subb_co_u32_e64 %7, s[84:85], %7, 0, s[76:77]"
         : "=&v"(d[0].lo), "=&v"(d[1].lo), "=&v"(d[2].lo), "=&v"(d[3].lo), "=&v"(d[0].hi), "=&v"(d[1].hi),
           "=&v"(d[2].hi), "=&v"(d[3].hi)
         : "v"(a[0].lo), "v"(a[1].lo), "v"(a[2].lo), "v"(a[3].lo), "v"(a[0].hi), "v"(a[1].hi), "v"(a[2].hi),
           "v"(a[3].hi), "v"(b[0].lo), "v"(b[1].lo), "v"(b[2].lo), "v"(b[3].lo), "v"(b[0].hi), "v"(b[1].hi),
           "v"(b[2].hi), "v"(b[3].hi)
-        : "vcc", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85");
+        : "vcc", "scc", "s72", "s73", "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85");
 #else
     for (int k = 0; k < 4; ++k) d[k] = split64(sub(join64(a[k]), join64(b[k])));
 #endif
   }
   SC_HD X64 sub(X64 a, X64 b) const { return split64(sub(join64(a), join64(b))); }
+  // two independent differences, same scheme (the two-way interleave leaves one idle slot after
+  // each carry producer; the scalar instructions fill two of them)
+  SC_HD void sub2(X64 (&d)[2], const X64 (&a)[2], const X64 (&b)[2]) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("v_sub_co_u32_e64 %0, vcc, %4, %8\n\t"
+        "v_sub_co_u32_e64 %1, s[72:73], %5, %9\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %2, vcc, %6, %10, vcc\n\t"
+        "v_subb_co_u32_e64 %3, s[72:73], %7, %11, s[72:73]\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %0, s[74:75], %0, 0, vcc\n\t"
+        "v_addc_co_u32_e64 %1, s[76:77], %1, 0, s[72:73]\n\t"
+        "s_andn2_b64 vcc, vcc, s[74:75]\n\t"
+        "s_andn2_b64 s[72:73], s[72:73], s[76:77]\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %2, s[74:75], %2, 0, vcc\n\t"
+        "v_subb_co_u32_e64 %3, s[76:77], %3, 0, s[72:73]"
+        : "=&v"(d[0].lo), "=&v"(d[1].lo), "=&v"(d[0].hi), "=&v"(d[1].hi)
+        : "v"(a[0].lo), "v"(a[1].lo), "v"(a[0].hi), "v"(a[1].hi), "v"(b[0].lo), "v"(b[1].lo), "v"(b[0].hi), "v"(b[1].hi)
+        : "vcc", "scc", "s72", "s73", "s74", "s75", "s76", "s77");
+#else
+    for (int k = 0; k < 2; ++k) d[k] = split64(sub(join64(a[k]), join64(b[k])));
+#endif
+  }
 
   // floor(m * p / 2^64) for the m with m*p == lo (mod 2^64), i.e. m = lo * (2^32+1).
   // m*p = (m - (m>>32)) * 2^64 + (m - (m<<32)); the low word borrows iff m < (m<<32).

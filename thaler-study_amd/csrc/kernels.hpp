@@ -78,16 +78,26 @@ __device__ __forceinline__ void fold_run(const F& f, u64 (&v)[IN], const FoldW& 
 //  KS = 1: acc[0..2] = H(0), H(1), H(inf)
 //  KS = 2: acc[3u+v] = sum a(u,v)*b(u,v), (u,v) in {0,1,inf}^2, u on index bit 0, v on bit 1
 // one 2x2 slice (index bits u, v) -> its nine extension values in {0,1,inf}^2
+// both tables' quads at once: e[u][v], u on index bit 0, v on bit 1.  Four of the five
+// differences per table depend on the inputs only (one sub4 each); the two (inf,inf) corners go
+// through one sub2.
 template <class F>
-__device__ __forceinline__ void extend_quad(const F& f, const X64 t0, const X64 t1, const X64 t2, const X64 t3,
-                                            X64 (&e)[3][3]) {
-  // e[u][v], u on index bit 0, v on bit 1; four of the five differences depend on the inputs only
-  const X64 hi[4] = {t1, t3, t2, t3}, lo[4] = {t0, t2, t0, t1};
-  X64 d[4];
-  f.sub4(d, hi, lo);
-  e[0][0] = t0; e[1][0] = t1; e[2][0] = d[0];
-  e[0][1] = t2; e[1][1] = t3; e[2][1] = d[1];
-  e[0][2] = d[2]; e[1][2] = d[3]; e[2][2] = f.sub(d[1], d[0]);
+__device__ __forceinline__ void extend_quads(const F& f, const X64 (&ta)[4], const X64 (&tb)[4], X64 (&ea)[3][3],
+                                             X64 (&eb)[3][3]) {
+  const X64 ha[4] = {ta[1], ta[3], ta[2], ta[3]}, la[4] = {ta[0], ta[2], ta[0], ta[1]};
+  const X64 hb[4] = {tb[1], tb[3], tb[2], tb[3]}, lb[4] = {tb[0], tb[2], tb[0], tb[1]};
+  X64 da[4], db[4];
+  f.sub4(da, ha, la);
+  f.sub4(db, hb, lb);
+  const X64 ch[2] = {da[1], db[1]}, cl[2] = {da[0], db[0]};
+  X64 corner[2];
+  f.sub2(corner, ch, cl);
+  ea[0][0] = ta[0]; ea[1][0] = ta[1]; ea[2][0] = da[0];
+  ea[0][1] = ta[2]; ea[1][1] = ta[3]; ea[2][1] = da[1];
+  ea[0][2] = da[2]; ea[1][2] = da[3]; ea[2][2] = corner[0];
+  eb[0][0] = tb[0]; eb[1][0] = tb[1]; eb[2][0] = db[0];
+  eb[0][1] = tb[2]; eb[1][1] = tb[3]; eb[2][1] = db[1];
+  eb[0][2] = db[2]; eb[1][2] = db[3]; eb[2][2] = corner[1];
 }
 
 template <class F, int KS>
@@ -99,8 +109,9 @@ __device__ __forceinline__ void accumulate_run(const F& f, typename F::Acc* acc,
     f.acc_mac(acc[2], f.sub(a[1], a[0]), f.sub(b[1], b[0]));
   } else if constexpr (KS == 2) {
     X64 ea[3][3], eb[3][3];
-    extend_quad(f, split64(a[0]), split64(a[1]), split64(a[2]), split64(a[3]), ea);
-    extend_quad(f, split64(b[0]), split64(b[1]), split64(b[2]), split64(b[3]), eb);
+    const X64 ta[4] = {split64(a[0]), split64(a[1]), split64(a[2]), split64(a[3])};
+    const X64 tb[4] = {split64(b[0]), split64(b[1]), split64(b[2]), split64(b[3])};
+    extend_quads(f, ta, tb, ea, eb);
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
@@ -132,8 +143,7 @@ __device__ __forceinline__ void accumulate_octet(const F& f, typename F::Acc* ac
       }
     }
     X64 ea[3][3], eb[3][3];
-    extend_quad(f, sa[0], sa[1], sa[2], sa[3], ea);
-    extend_quad(f, sb[0], sb[1], sb[2], sb[3], eb);
+    extend_quads(f, sa, sb, ea, eb);
 #pragma unroll
     for (int u = 0; u < 3; ++u)
 #pragma unroll
