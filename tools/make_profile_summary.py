@@ -32,7 +32,7 @@ def passinfo(r):
     if m:
         kf, ks = int(m.group(2)), 3      # the three-round tail pass
     else:
-        m = re.search(r"pass_kernel<sc::(\w+), (\d), (\d)>", r["Kernel_Name"])
+        m = re.search(r"pass_kernel<sc::(\w+), (\d), (\d)(?:, \d)?>", r["Kernel_Name"])
         kf, ks = int(m.group(2)), int(m.group(3))
     return (kf, ks, int(r["Grid_Size_X"]) // 256, (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 seq = [passinfo(r) for r in trace if is_pass(r["Kernel_Name"])]

@@ -3,7 +3,7 @@ import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 28
 def fmt(r):
-    m = re.search(r'pass_kernel<sc::(\w+), (\d), (\d)>', r['Kernel_Name'])
+    m = re.search(r'pass_kernel<sc::(\w+), (\d), (\d)(?:, \d)?>', r['Kernel_Name'])
     return (m.group(2) + m.group(3), int(r['Grid_Size_X']) // 256, (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 seq = [fmt(r) for r in rows if 'pass_kernel' in r['Kernel_Name']]
 # split into prover runs: a run starts with a kf=0 pass
