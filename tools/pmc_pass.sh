@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 rocprofv3 -L > $O/counters.txt 2>&1
 i=0
-for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_LDS" "SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INST_CYCLES_VMEM" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM"; do
+for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM"; do
   i=$((i+1))
   rm -rf $O/pmc$i
   rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc$i -- python3 $R/tools/probe.py 28 2 > $O/pmc$i.log 2>&1
@@ -22,4 +22,4 @@ for k, v in agg.items():
 PY
   rm -rf $O/pmc$i
 done
-cat $O/pmc1.txt $O/pmc2.txt $O/pmc3.txt $O/pmc4.txt | grep -E "0, 3>|3, 2>" | grep -v "n=0"
+cat $O/pmc1.txt $O/pmc2.txt $O/pmc3.txt $O/pmc4.txt | grep -E "0, 3, 1>|3, 2, 3>" | grep -v "n=0"
