@@ -913,8 +913,7 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
     if (value < 1 || value > (int64_t)ctx->partial_rows) return fail(ctx, SC_ERR_ARG, "max_blocks out of range");
     ctx->max_blocks = (int)value;
   } else if (k == "time_kernels") {
-    if (!value) drain_kernel_timers(ctx);
-    ctx->time_kernels = value ? 1 : 0;
+    ctx->time_kernels = value ? 1 : 0;  // recorded pairs stay in the ring until it fills or the totals are read
   } else if (k == "use_mailbox") {
     ctx->use_mailbox = value ? 1 : 0;
   } else if (k == "nt_load_log") {
