@@ -1,7 +1,8 @@
 // gfx950 device kernels of the sumcheck prover hot path.
 //
-// All kernels stream evaluation tables of 64-bit field words; they are bound by HBM
-// bandwidth, not by MFMA/VALU (DESIGN.md "Kernels").  Wavefront = 64 lanes.  Every global
+// All kernels stream evaluation tables of 64-bit field words; they are bound by HBM bandwidth
+// (MFMA does not apply to exact 64-bit modular arithmetic) - except the 27-cell first pass,
+// whose VALU issue rate is the limit (DESIGN.md "Kernels").  Wavefront = 64 lanes.  Every global
 // access is "lane i <-> 16-byte piece base+i" (dwordx4, 1 KiB contiguous per wave
 // instruction); where the arithmetic needs a lane to own a longer run of consecutive
 // entries (both halves of every LE fold pair, entries 2b and 2b+1 -
