@@ -98,6 +98,30 @@ void* sc_ctx_stream(const sc_ctx* ctx);
  * out[0] = number of pass launches, out[1] = sum of their durations in ms (HIP events on
  * the context's stream; enabled by option "time_kernels" = 1). */
 int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset);
+/* Per-launch records of the same instrumentation (option "time_kernels" = 1): what each timed
+ * launch was, the HBM bytes it has to move (every input once, every output once) and its HIP-event
+ * duration.  A benchmark derives bytes actually moved and per-kernel GB/s from the launches that
+ * really ran instead of from a model.  Copies min(cap, n) records, stores the number available in
+ * *n_out, clears the log if reset.  The log keeps at most 65536 records. */
+#define SC_KIND_PASS 0       /* pass_kernel<kf,ks>: fold kf variables of both tables + grid sums of ks rounds */
+#define SC_KIND_TAIL_PASS 1  /* small_pass3_kernel<kf>: the same for cache-resident tables, ks = 3 */
+#define SC_KIND_EVALUATE 2   /* evaluate_kernel: one table, kf = number of variables */
+#define SC_KIND_FOLD 3       /* fold_kernel<kf>: LE fix of kf <= 3 variables of one table */
+#define SC_KIND_FIX_LOW 4    /* fix_low_kernel: LE fix of 8..17 variables in one pass */
+#define SC_KIND_FOLD_BE 5    /* fold_be_kernel: BE fix of one variable */
+#define SC_KIND_COLDOT 6     /* coldot_kernel (+ sum_rows_kernel): BE multi-variable fix / f_A of G::new */
+#define SC_KIND_GKR 7        /* GKR W pass: fold add/mul/w + round sums */
+#define SC_KIND_MATSQ 8      /* triangle counting: square of the adjacency matrix */
+#define SC_KIND_TAIL_RESIDENT 9 /* resident tail kernel: all remaining rounds of a small instance in one launch */
+typedef struct sc_launch_record {
+  int32_t kind;           /* SC_KIND_* */
+  int32_t kf, ks;         /* variables folded / rounds served (meaning per kind above) */
+  int32_t log_in;         /* log2 entries per input table */
+  uint64_t bytes_read;    /* HBM bytes the launch must read */
+  uint64_t bytes_written; /* HBM bytes the launch must write */
+  double ms;              /* duration (HIP events on the context's stream) */
+} sc_launch_record;
+int sc_ctx_launch_log(sc_ctx* ctx, sc_launch_record* out, size_t cap, size_t* n_out, int reset);
 
 /* ---- sharding (one process per GPU) ------------------------------ */
 

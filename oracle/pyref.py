@@ -521,3 +521,44 @@ def tri_transcript(adj, var_len, challenges, p):
     final = tri_evaluate(adj, adj, adj, var_len, challenges, p)
     assert claim == final
     return {"c_1": c1, "evals": evals, "final_eval": final}
+
+
+# ---- gkr_protocol::{Prover, Verifier}: the message loop of the reference's protocol tests ---------
+# gkr-protocol/src/lib.rs:38-218 (Verifier), :324-474 (Prover), driven as in
+# protocol_test_from_book (:550-624) / three_layer_protocol_test (:626-702).  Randomness is a
+# scripted list consumed in the order the reference draws it: k_0 values for r_0 (Begin, :193),
+# then per layer one value per sumcheck round (verifier.round draws before it checks, :283 of
+# sum-check-protocol; the last one by final_random_point, :108), then the line parameter (:157).
+
+def gkr_transcript(layers, num_inputs, inputs, draws, p):
+    """Runs the whole GKR protocol on canonical ints and returns every message.  Raises
+    AssertionError where the reference's verifier would reject (unwrap / assert_eq!)."""
+    draws = list(draws)
+    vals = circuit_evaluate(layers, inputs, p)                     # Prover::new, :346-357
+    k = [(len(l) - 1).bit_length() for l in layers] + [(num_inputs - 1).bit_length()]
+    out = {"circuit_outputs": vals[0], "layers": []}              # Begin, :363-367
+    r_i = [draws.pop(0) for _ in range(k[0])]                      # :193
+    m_i = mle_evaluate(vals[0], r_i, p)                            # :195
+    out["r_0"], out["m_0"] = list(r_i), m_i
+    for i in range(len(layers)):
+        k_next = k[i + 1]
+        add_f, mul_f = wiring_fixed(layers[i], k_next, r_i, p)     # :388-416 (prover), :90-91 (verifier)
+        w = vals[i + 1]
+        n = 2 * k_next
+        ch = [draws.pop(0) for _ in range(n)]                      # n-1 by verifier.round, 1 by final_random_point
+        tr = w_transcript(add_f, mul_f, w, w, ch, p)               # rounds + the sumcheck verifier's identities
+        assert tr["c_1"] == m_i, "layer %d: c_1 != m_i" % i        # the claim the layer reduces
+        b, c = ch[:k_next], ch[k_next:]                            # :442, :155
+        q = restrict_poly(b, c, w, p)                              # :444
+        q0, q1 = poly_eval(q, 0, p), poly_eval(q, 1 % p, p)        # :146-147
+        ev = (mle_evaluate(add_f, ch, p) * (q0 + q1) + mle_evaluate(mul_f, ch, p) * q0 * q1) % p   # :149
+        assert ev == poly_eval(tr["coeffs"][-1], ch[-1], p), "layer %d: final round message" % i   # :151
+        r_line = draws.pop(0)                                      # :153
+        r_next = [(bi + r_line * (ci - bi)) % p for bi, ci in zip(b, c)]       # :156-158
+        m_next = poly_eval(q, r_line, p)                           # :159
+        out["layers"].append({"c_1": tr["c_1"], "num_vars": n, "evals": tr["evals"], "coeffs": tr["coeffs"],
+                              "challenges": ch, "q": q, "r_line": r_line, "r_next": r_next, "m_next": m_next})
+        r_i, m_i = r_next, m_next
+    out["check_input"] = mle_evaluate([x % p for x in inputs], r_i, p) == m_i   # :210-217
+    assert not draws, "unused draws"
+    return out

@@ -28,7 +28,15 @@ def test_bench_line_small_instance():
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
     assert r["achieved"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert r["steps_sampled"] >= 1 and r["launches_per_step"] >= 1
+    assert 0 < r["frac"] <= 1.0, "roofline.frac must be a physical fraction"
+    assert r["steps_sampled"] >= 1 and r["step"]["launches"] >= 1
+    assert r["kernel"] and r["bytes_per_launch"] > 0 and r["avg_launch_us"] > 0
+    # bytes moved come from the launches that ran: n = 18 -> first pass reads 2 x 2^18 x 8 B, ...
+    st = r["step"]
+    assert 0 < st["frac_of_kernel_time"] <= 1.0 and 0 < st["frac_of_wall_time"] <= st["frac_of_kernel_time"]
+    assert st["bytes_moved"] >= 16 * 2**18 and st["bytes_moved"] <= 64 * 2**18
+    assert abs(sum(k["bytes_per_launch"] * k["launches_per_step"] for k in r["kernels"]) - st["bytes_moved"]) < 1
+    assert d["ms_per_step_median"] > 0
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and "sample" in c
 
@@ -50,3 +58,36 @@ def test_bench_two_ranks_on_one_device():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert "host" in d["config"]["transport"]
+
+
+@pytest.mark.gpu
+def test_bench_mle_workload():
+    """--workload mle (BASELINE configs[1]): evaluate + fix_variables, own roofline object, parity gate"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mle", "--num-vars", "20", "--steps", "5",
+                          "--warmup", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["config"]["num_vars"] == 20 and d["n_gpus"] == 1 and d["value"] > 0
+    assert "bit-exact vs CPU oracle" in d["config"]["parity_gate"]
+    r = d["roofline"]
+    assert "evaluate_kernel" in r["kernel"] and r["bytes_per_launch"] == 8 * 2**20
+    assert 0 < r["frac"] <= 1.0
+    kinds = " ".join(k["kernel"] for k in r["kernels"])
+    assert "fold_kernel" in kinds and "fix_low_kernel" in kinds and "evaluate_kernel" in kinds
+    assert d["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_refuses_silent_transport_fallback():
+    """a rank whose data-plane transport cannot be created (injected here) makes bench.py exit non-zero on
+    every rank instead of quietly measuring the host transport"""
+    env = dict(os.environ, SC_BENCH_SINGLE_DEVICE="1", SC_BENCH_FAIL_TRANSPORT_RANK="all")
+    port = 29850 + (os.getpid() % 100)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--num-vars", "16", "--steps", "2", "--warmup", "0", "--cpu-num-vars", "0"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]

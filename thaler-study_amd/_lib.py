@@ -26,6 +26,14 @@ class ScField(ctypes.Structure):
     _fields_ = [("p", u64), ("p_inv_neg", u64), ("r_mod_p", u64), ("r2_mod_p", u64)]
 
 
+class ScLaunchRecord(ctypes.Structure):
+    _fields_ = [("kind", ctypes.c_int32), ("kf", ctypes.c_int32), ("ks", ctypes.c_int32), ("log_in", ctypes.c_int32),
+                ("bytes_read", u64), ("bytes_written", u64), ("ms", ctypes.c_double)]
+
+
+KIND_NAMES = {0: "pass", 1: "tail_pass", 2: "evaluate", 3: "fold", 4: "fix_low", 5: "fold_be", 6: "coldot", 7: "gkr",
+              8: "matsq", 9: "tail_resident"}
+
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, voidp, u64p, size_t)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, voidp, u64p, u64p, size_t)
 DRAW_FN = ctypes.CFUNCTYPE(u64, voidp, size_t, u64p)
@@ -44,6 +52,7 @@ SIGNATURES = {
     "sc_ctx_synchronize": (ctypes.c_int, [voidp]),
     "sc_ctx_stream": (voidp, [voidp]),
     "sc_ctx_kernel_time": (ctypes.c_int, [voidp, ctypes.POINTER(ctypes.c_double), ctypes.c_int]),
+    "sc_ctx_launch_log": (ctypes.c_int, [voidp, ctypes.POINTER(ScLaunchRecord), size_t, ctypes.POINTER(size_t), ctypes.c_int]),
     "sc_comm_unique_id": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
     "sc_ctx_comm_init_rccl": (ctypes.c_int, [voidp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.c_int]),
     "sc_ctx_comm_init_host": (ctypes.c_int, [voidp, ctypes.c_int, ctypes.c_int, ALLREDUCE_FN, ALLGATHER_FN, voidp]),

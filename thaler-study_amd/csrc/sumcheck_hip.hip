@@ -143,10 +143,13 @@ struct sc_ctx {
   // ring is full or the totals are queried, so that timing adds two event records per launch
   // and no host synchronisation to the rounds it measures
   static constexpr int kTimerRing = 64;
+  static constexpr size_t kLaunchLogCap = 1 << 16;
   hipEvent_t kt_ev[kTimerRing][2] = {};
+  sc_launch_record kt_meta[kTimerRing] = {};  // what each pending event pair brackets
   int kt_used = 0;
   double kt_ms = 0.0;
   long kt_n = 0;
+  std::vector<sc_launch_record> launch_log;   // drained records (sc_ctx_launch_log)
 };
 
 struct sc_table {
@@ -334,9 +337,38 @@ void drain_kernel_timers(sc_ctx* ctx) {
     if (hipEventElapsedTime(&ms, ctx->kt_ev[i][0], ctx->kt_ev[i][1]) == hipSuccess) {
       ctx->kt_ms += ms;
       ctx->kt_n += 1;
+      if (ctx->launch_log.size() < sc_ctx::kLaunchLogCap) {
+        sc_launch_record r = ctx->kt_meta[i];
+        r.ms = ms;
+        ctx->launch_log.push_back(r);
+      }
     }
   }
   ctx->kt_used = 0;
+}
+
+// Bracket the launch(es) that follow with an event pair on the context's stream (option
+// "time_kernels"); bytes_read / bytes_written are what the launch has to move through HBM (every
+// input once, every output once).  timer_end() after the launch.
+int timer_begin(sc_ctx* ctx, int kind, int kf, int ks, int log_in, u64 bytes_read, u64 bytes_written) {
+  if (!ctx->time_kernels) return SC_OK;
+  if (ctx->kt_used == sc_ctx::kTimerRing) drain_kernel_timers(ctx);
+  sc_launch_record& m = ctx->kt_meta[ctx->kt_used];
+  m.kind = kind;
+  m.kf = kf;
+  m.ks = ks;
+  m.log_in = log_in;
+  m.bytes_read = bytes_read;
+  m.bytes_written = bytes_written;
+  m.ms = 0.0;
+  SC_HIP(ctx, hipEventRecord(ctx->kt_ev[ctx->kt_used][0], ctx->stream));
+  return SC_OK;
+}
+int timer_end(sc_ctx* ctx) {
+  if (!ctx->time_kernels) return SC_OK;
+  SC_HIP(ctx, hipEventRecord(ctx->kt_ev[ctx->kt_used][1], ctx->stream));
+  ctx->kt_used += 1;
+  return SC_OK;
 }
 
 // A pass is launched with at most as many blocks as are resident at once (occupancy x CUs) and
@@ -448,16 +480,11 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
   out.seq = mailbox ? ++ctx->mailbox_seq : 0;
   if (grid > 1) ctx->ticket_base += (unsigned)grid;
-  if (ctx->time_kernels) {
-    if (ctx->kt_used == sc_ctx::kTimerRing) drain_kernel_timers(ctx);
-    SC_HIP(ctx, hipEventRecord(ctx->kt_ev[ctx->kt_used][0], ctx->stream));
-  }
+  SC_TRY(timer_begin(ctx, (ks == 3 && kf > 0) ? SC_KIND_TAIL_PASS : SC_KIND_PASS, kf, ks, log_in, (u64)16 << log_in,
+                     kf > 0 ? (u64)16 << (log_in - kf) : 0));
   SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, fw, n_units, grid, log_in, out));
   SC_HIP(ctx, hipGetLastError());
-  if (ctx->time_kernels) {
-    SC_HIP(ctx, hipEventRecord(ctx->kt_ev[ctx->kt_used][1], ctx->stream));
-    ctx->kt_used += 1;
-  }
+  SC_TRY(timer_end(ctx));
   *from_mailbox = mailbox;
   return SC_OK;
 }
@@ -634,6 +661,7 @@ int coldot(sc_ctx* ctx, const u64* in, const u64* w, size_t rows, size_t M, u64*
   size_t gx = (mp + sc::kBlock - 1) / sc::kBlock;
   if (gx > 1024) gx = 1024;
   const int nt = (rows * M) >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
+  SC_TRY(timer_begin(ctx, SC_KIND_COLDOT, log2_of(rows), 0, log2_of(rows * M), (u64)8 * rows * M + 8 * rows, (u64)8 * M));
   if (nt)
     SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::coldot_kernel<F, true>), dim3((unsigned)gx, (unsigned)chunks),
                                                     dim3(sc::kBlock), 0, ctx->stream, f, in, w, rows, rows_per_chunk, M, partial));
@@ -647,6 +675,7 @@ int coldot(sc_ctx* ctx, const u64* in, const u64* w, size_t rows, size_t M, u64*
     pool_release(ctx, partial);
   }
   SC_HIP(ctx, hipGetLastError());
+  SC_TRY(timer_end(ctx));
   return SC_OK;
 }
 
@@ -697,12 +726,14 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
       const sc::RVec rv = make_rvec(r + done, (size_t)step);
       const int grid = (int)std::min<size_t>((nlen + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
       const int nt = cur_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
+      SC_TRY(timer_begin(ctx, SC_KIND_FIX_LOW, step, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * nlen));
       if (nt)
         SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F, true>), dim3(grid), dim3(sc::kBlock), 0,
                                                         ctx->stream, f, cur, nxt, step, rv, nlen));
       else
         SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F, false>), dim3(grid), dim3(sc::kBlock), 0,
                                                         ctx->stream, f, cur, nxt, step, rv, nlen));
+      SC_TRY(timer_end(ctx));
       cur_len = nlen;
     } else if (order == SC_ORDER_LE) {
       step = (int)std::min<size_t>(3, k - done);
@@ -710,6 +741,7 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
       size_t nlen = cur_len >> step;
       SC_TRY(pool_alloc(ctx, nlen, &nxt));
       const sc::FoldW fw = make_fold_weights(ctx, r + done, step);
+      SC_TRY(timer_begin(ctx, SC_KIND_FOLD, step, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * nlen));
       if (nlen >= 2) {
         size_t n_units = nlen / 2;
         int grid = grid_for(ctx, n_units);
@@ -731,14 +763,17 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
         SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_le_small_kernel<F>), dim3(1), dim3(64), 0,
                                                         ctx->stream, f, cur, nxt, r[done], nlen));
       }
+      SC_TRY(timer_end(ctx));
       cur_len = nlen;
     } else {
       step = 1;
       size_t half = cur_len / 2;
       SC_TRY(pool_alloc(ctx, half, &nxt));
       int grid = grid_for(ctx, (half + 1) / 2);
+      SC_TRY(timer_begin(ctx, SC_KIND_FOLD_BE, 1, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * half));
       SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_be_kernel<F>), dim3(grid), dim3(sc::kBlock), 0,
                                                       ctx->stream, f, cur, nxt, r[done], half));
+      SC_TRY(timer_end(ctx));
       cur_len = half;
     }
     SC_HIP(ctx, hipGetLastError());
@@ -965,6 +1000,17 @@ extern "C" int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset) {
   return SC_OK;
 }
 
+extern "C" int sc_ctx_launch_log(sc_ctx* ctx, sc_launch_record* out, size_t cap, size_t* n_out, int reset) {
+  if (!ctx || !n_out || (cap && !out)) return SC_ERR_ARG;
+  SC_TRY(set_device(ctx));
+  drain_kernel_timers(ctx);
+  const size_t n = std::min(cap, ctx->launch_log.size());
+  for (size_t i = 0; i < n; ++i) out[i] = ctx->launch_log[i];
+  *n_out = ctx->launch_log.size();
+  if (reset) ctx->launch_log.clear();
+  return SC_OK;
+}
+
 // =====================================================================================
 // C ABI: sharding
 // =====================================================================================
@@ -1166,6 +1212,7 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
   out.seq = mailbox ? ++ctx->mailbox_seq : 0;
   if (grid > 1) ctx->ticket_base += (unsigned)grid;
   const int nt = nv >= ctx->nt_load_log ? 1 : 0;
+  SC_TRY(timer_begin(ctx, SC_KIND_EVALUATE, nv, 0, nv, (u64)8 << nv, 0));
   if (nt)
     SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::evaluate_kernel<F, true>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
                                                     f, d, nv, rv, ta, chunk_log, w_extra, out));
@@ -1173,6 +1220,7 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
     SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::evaluate_kernel<F, false>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
                                                     f, d, nv, rv, ta, chunk_log, w_extra, out));
   SC_HIP(ctx, hipGetLastError());
+  SC_TRY(timer_end(ctx));
   *from_mailbox = mailbox;
   return SC_OK;
 }

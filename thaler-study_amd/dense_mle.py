@@ -66,6 +66,16 @@ class Context:
         self.check(self.lib.sc_ctx_kernel_time(self.h, out, 1 if reset else 0))
         return int(out[0]), float(out[1])
 
+    def launch_log(self, reset=True, cap=65536):
+        """per-launch records of the timed launches: list of dicts (kind, kf, ks, log_in, bytes_read,
+        bytes_written, ms)"""
+        buf = (_lib.ScLaunchRecord * cap)()
+        n = ctypes.c_size_t()
+        self.check(self.lib.sc_ctx_launch_log(self.h, buf, cap, ctypes.byref(n), 1 if reset else 0))
+        return [{"kind": _lib.KIND_NAMES.get(r.kind, str(r.kind)), "kf": r.kf, "ks": r.ks, "log_in": r.log_in,
+                 "bytes_read": int(r.bytes_read), "bytes_written": int(r.bytes_written), "ms": float(r.ms)}
+                for r in buf[:min(n.value, cap)]]
+
     # ---- sharding -----------------------------------------------------------------------
     def comm_init_rccl(self, unique_id, rank, world):
         buf = (ctypes.c_uint8 * 128).from_buffer_copy(bytes(unique_id))

@@ -96,3 +96,9 @@ def attach_rccl(ctx, rank, world, group=None):
     uid = Context.rccl_unique_id() if rank == 0 else None
     uid = broadcast_bytes(uid, src=0, group=group)
     ctx.comm_init_rccl(uid, rank, world)
+
+
+def attach_default(ctx, rank, world, group=None):
+    """the data-plane transport a multi-GPU run uses unless told otherwise; returns its name"""
+    attach_rccl(ctx, rank, world, group)
+    return "rccl"

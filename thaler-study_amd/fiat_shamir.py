@@ -9,9 +9,15 @@ Wire format: `ark-serialize` `serialize_uncompressed` of `(F, SparsePolynomial<F
 of `SparsePolynomial<F>` (later rounds), restated from the published layout - field element =
 canonical integer, little-endian, ceil(modulus_bits / 8) bytes; Vec = u64-LE length then items;
 `usize` = u64 LE.  Challenges: any `HashToField`; `Sha256FieldHasher` restates ark-ff's
-`DefaultFieldHasher<Sha256, 128>` (RFC 9380 expand_message_xmd, empty DST unless given).
-PARITY UNPINNED: the reference's only assertion here is accept/reject (fiat-shamir/src/lib.rs:231-234)
-and the Rust cannot be run in this image, so byte-identity with arkworks is not checked.
+`DefaultFieldHasher<Sha256, 128>` (RFC 9380 expand_message_xmd, empty DST unless given).  The
+expander is pinned against RFC 9380 appendix K.1 (tests/golden/rfc9380_k1_xmd_sha256.json) in
+its "rfc9380" mode (Z_pad = the SHA-256 block, 64 bytes); the default "arkworks" mode follows
+ark-ff's `DefaultFieldHasher::new`, which builds its `ExpanderXmd` with
+`block_size = len_per_base_elem` = ceil((modulus_bits + 128) / 8) - so Z_pad is 17 bytes for p = 5,
+24 for Goldilocks, and 64 only by coincidence for BLS12-381.
+PARITY UNPINNED for arkworks byte identity: the reference's only assertion here is accept/reject
+(fiat-shamir/src/lib.rs:231-234) and the Rust cannot be run in this image, so no ark-ff known answer
+exists to pin the arkworks mode or the serializer against.
 """
 import hashlib
 
@@ -65,16 +71,26 @@ def deserialize_poly(field, data, off=0):
 class Sha256FieldHasher:
     """ark_ff::field_hashers::DefaultFieldHasher<Sha256, 128> restated (RFC 9380, section 5.3.1)"""
 
-    def __init__(self, field, dst=b""):
+    def __init__(self, field, dst=b"", z_pad="arkworks"):
         self.field, self.dst = field, bytes(dst)
         self.len_per_elem = (field.p.bit_length() + 128 + 7) // 8
+        # ark-ff: ExpanderXmd { block_size: len_per_base_elem }; RFC 9380: s_in_bytes of SHA-256
+        if z_pad == "arkworks":
+            self.z_pad = self.len_per_elem
+        elif z_pad == "rfc9380":
+            self.z_pad = 64
+        else:
+            self.z_pad = int(z_pad)
 
     def _expand(self, msg, n):
         ell = (n + 31) // 32
-        if ell > 255 or len(self.dst) > 255:
+        if ell > 255 or n >= 1 << 16:
             raise ValueError("expand_message_xmd: output too long")
-        dst_prime = self.dst + bytes([len(self.dst)])
-        b0 = hashlib.sha256(bytes(64) + msg + n.to_bytes(2, "big") + b"\x00" + dst_prime).digest()
+        dst = self.dst
+        if len(dst) > 255:                      # construct_dst_prime / RFC 9380 section 5.3.3
+            dst = hashlib.sha256(b"H2C-OVERSIZE-DST-" + dst).digest()
+        dst_prime = dst + bytes([len(dst)])
+        b0 = hashlib.sha256(bytes(self.z_pad) + msg + n.to_bytes(2, "big") + b"\x00" + dst_prime).digest()
         out, bi = b"", hashlib.sha256(b0 + b"\x01" + dst_prime).digest()
         out += bi
         for i in range(2, ell + 1):

@@ -222,3 +222,221 @@ def restrict_poly(b, c, mle):
     out = np.zeros(k + 1, dtype=np.uint64)
     ctx.check(ctx.lib.sc_table_restrict_to_line(ctx.h, mle.h, _u64p(bb), _u64p(cc), k, _u64p(out)))
     return SparsePolynomial.from_coefficients_vec(ctx.field, [(d, int(v)) for d, v in enumerate(out)])
+
+
+# ---- the GKR message state machines (gkr-protocol/src/lib.rs:38-218, :324-474) -----------------------
+# Host control flow, mirrored so that the reference's protocol tests (protocol_test_from_book :550-624,
+# three_layer_protocol_test :626-702) replay on the GPU `W` prover unchanged: every table operation
+# below (wiring predicates, W's sumcheck, restrict_poly, the MLE evaluations of the verifier) is a
+# libsumcheck_hip.so call.
+
+class WrongVerifierState(Exception):
+    """Error::WrongVerifierState (:27-31)"""
+
+    def __init__(self):
+        super().__init__("Verifier is in the wrong state.")
+
+
+class ProverMessage:
+    """:255-289"""
+
+    def __init__(self, kind, **fields):
+        self.kind = kind
+        self.__dict__.update(fields)
+
+    @classmethod
+    def Begin(cls, circuit_outputs):
+        return cls("Begin", circuit_outputs=list(circuit_outputs))
+
+    @classmethod
+    def SumCheckProverMessage(cls, p):
+        return cls("SumCheckProverMessage", p=p)
+
+    @classmethod
+    def FinalRoundMessage(cls, p, q):
+        return cls("FinalRoundMessage", p=p, q=q)
+
+    @classmethod
+    def StartSumCheck(cls, c_1, round, num_vars):
+        return cls("StartSumCheck", c_1=c_1, round=round, num_vars=num_vars)
+
+    def __eq__(self, other):
+        return isinstance(other, ProverMessage) and self.__dict__ == other.__dict__
+
+    def __repr__(self):
+        return "ProverMessage.%s(%r)" % (self.kind, {k: v for k, v in self.__dict__.items() if k != "kind"})
+
+
+class VerifierMessage:
+    """:231-252"""
+
+    def __init__(self, kind, **fields):
+        self.kind = kind
+        self.__dict__.update(fields)
+
+    @classmethod
+    def SumCheckRoundResult(cls, res):
+        return cls("SumCheckRoundResult", res=res)
+
+    @classmethod
+    def RoundStarted(cls, round):
+        return cls("RoundStarted", round=round)
+
+    @classmethod
+    def R(cls, r):
+        return cls("R", r=list(r))
+
+    def __repr__(self):
+        return "VerifierMessage.%s(%r)" % (self.kind, {k: v for k, v in self.__dict__.items() if k != "kind"})
+
+
+class Verifier:
+    """:38-218.  `rng` arguments are sum_check_protocol.RngF objects (F::rand(rng) = rng.draw())."""
+
+    def __init__(self, ctx, circuit):
+        self.ctx, self.field, self.circuit = ctx, ctx.field, circuit
+        self.r, self.m = [], []
+        self.state = None                      # VerifierState::Empty
+
+    @classmethod
+    def new(cls, ctx, circuit):
+        return cls(ctx, circuit)
+
+    def _start_round(self, c_1, round, num_vars):
+        """:89-107 - add_i_ext / mul_i_ext (circuit.rs:156-213) straight from the gate list"""
+        from .sum_check_protocol import Verifier as SumCheckVerifier
+        add_i, mul_i = wiring(self.ctx, self.circuit, round, self.r[-1])
+        verifier = SumCheckVerifier.new(num_vars, None, self.field)
+        verifier.set_c_1(c_1)
+        self.state = {"bc": [], "verifier": verifier, "add_i": add_i, "mul_i": mul_i}
+        return VerifierMessage.RoundStarted(round)
+
+    def final_random_point(self, rng):
+        """:110-121"""
+        from .sum_check_protocol import VerifierRoundResult
+        if self.state is None:
+            raise WrongVerifierState()
+        final_point = rng.draw()
+        self.state["bc"].append(final_point)
+        return VerifierMessage.SumCheckRoundResult(VerifierRoundResult.JthRound(final_point))
+
+    def _sum_check_step(self, message, rng):
+        """:123-139"""
+        if self.state is None:
+            raise WrongVerifierState()
+        res = self.state["verifier"].round(message, rng)        # .unwrap(): a mismatch raises
+        if not res.is_final():
+            self.state["bc"].append(res.value)
+        return VerifierMessage.SumCheckRoundResult(res)
+
+    def _final_round_message(self, p, q, rng):
+        """:141-174"""
+        if self.state is None:
+            raise WrongVerifierState()
+        f = self.field
+        bc, add_i, mul_i = self.state["bc"], self.state["add_i"], self.state["mul_i"]
+        q_0, q_1 = q.evaluate(f.zero), q.evaluate(f.one)
+        ev = f.add(f.mul(add_i.evaluate(bc), f.add(q_0, q_1)), f.mul(f.mul(mul_i.evaluate(bc), q_0), q_1))
+        if ev != p.evaluate(bc[-1]):
+            raise AssertionError("assert_eq!(eval, p.evaluate(bc.last().unwrap()))")        # :151
+        r = rng.draw()
+        half = len(bc) // 2
+        r_next = [l.evaluate(r) for l in line(f, bc[:half], bc[half:])]
+        self.r.append(r_next)
+        self.m.append(q.evaluate(r))
+        return VerifierMessage.R(r_next)
+
+    def receive_prover_msg(self, msg, rng):
+        """:177-207"""
+        if msg.kind == "SumCheckProverMessage":
+            return self._sum_check_step(msg.p, rng)
+        if msg.kind == "StartSumCheck":
+            return self._start_round(msg.c_1, msg.round, msg.num_vars)
+        if msg.kind == "FinalRoundMessage":
+            return self._final_round_message(msg.p, msg.q, rng)
+        num_output_vars = self.circuit.num_vars_at(0)
+        d = DenseMultilinearExtension.from_evaluations_vec(self.ctx, num_output_vars,
+                                                           np.array(msg.circuit_outputs, dtype=np.uint64))
+        r_zero = [rng.draw() for _ in range(num_output_vars)]
+        self.r, self.m = [r_zero], [d.evaluate(r_zero)]
+        return VerifierMessage.R(r_zero)
+
+    def check_input(self, input):
+        """:210-217"""
+        w = DenseMultilinearExtension.from_evaluations_vec(self.ctx, (len(input)).bit_length() - 1,
+                                                           np.array(input, dtype=np.uint64))
+        return w.evaluate(self.r[-1]) == self.m[-1]
+
+
+class Prover:
+    """:324-474.  `sparse=True` builds each layer's sumcheck straight from the gate list
+    (sc_gkr_prover_create_sparse) instead of the dense add_i / mul_i tables - same messages."""
+
+    def __init__(self, ctx, circuit, input, sparse=False):
+        self.ctx, self.field, self.circuit = ctx, ctx.field, circuit
+        self.evaluation = circuit.evaluate(self.field, list(input))           # :346
+        self.i, self.prover, self.w, self.r, self.sparse = 0, None, None, [], sparse
+
+    @classmethod
+    def new(cls, ctx, circuit, input, sparse=False):
+        return cls(ctx, circuit, input, sparse)
+
+    def start_protocol(self):
+        """:363-367"""
+        return ProverMessage.Begin(self.evaluation[0])
+
+    def start_round(self, i, r_i):
+        """:373-436"""
+        from .sum_check_protocol import Prover as SumCheckProver
+        k_next = self.circuit.num_vars_at(i + 1)
+        if self.sparse:
+            eng = SparseLayerProver(self.ctx, self.circuit, self.evaluation, i, r_i)
+            self.w = eng._w_next
+            prover = _EngineProver(eng, self.field)
+            num_vars = 2 * k_next
+        else:
+            w = start_round_w(self.ctx, self.circuit, self.evaluation, i, r_i)
+            self.w = w.w_b
+            num_vars = w.add_i.num_vars()
+            prover = SumCheckProver.new(w)
+        self.i, self.prover, self.r = i, prover, []
+        return ProverMessage.StartSumCheck(prover.c_1(), i, num_vars)
+
+    def round_msg(self, j):
+        """:439-456"""
+        if j == 2 * self.circuit.num_vars_at(self.i + 1) - 1:
+            half = len(self.r) // 2
+            q = restrict_poly(self.r[:half], self.r[half:], self.w)
+            p = self.prover.round(self.r[j - 1] if j else self.field.one, j)
+            return ProverMessage.FinalRoundMessage(p, q)
+        point = self.field.one if j == 0 else self.r[j - 1]
+        return ProverMessage.SumCheckProverMessage(self.prover.round(point, j))
+
+    def receive_verifier_msg(self, verifier_msg):
+        """:459-468"""
+        if verifier_msg.kind == "SumCheckRoundResult":
+            if verifier_msg.res.is_final():
+                raise RuntimeError("panic!()")
+            self.r.append(verifier_msg.res.value)
+
+    def c_1(self):
+        """:471-473"""
+        return self.prover.c_1()
+
+
+class _EngineProver:
+    """sum_check_protocol.Prover's surface over a bare native engine (the sparse layer prover has no
+    table-backed W to hand to Prover::new)"""
+
+    def __init__(self, engine, field):
+        self._engine, self.field = engine, field
+        self.c_1_value = engine.c1()
+
+    def c_1(self):
+        return self.c_1_value
+
+    def round(self, r_prev, j):
+        return self._engine.round(r_prev, j)
+
+    def num_vars(self):
+        return self._engine.num_vars()

@@ -195,19 +195,26 @@ class VerifierRoundResult:
 
 
 class Verifier:
-    """:227-331"""
+    """:227-331.
 
-    def __init__(self, n, g, field=None):
+    strict=True (default) adds, in the final round, the check the reference omits: g_n(0) + g_n(1)
+    must equal g_{n-1}(r_{n-1}) (the reference's last branch :298-310 only tests g_n(r_n) == g(r), so
+    a prover that is self-consistent on a false c_1 up to round n-1 and then sends the honest g_n is
+    accepted), and reports a failed oracle check as FinalRound(False) instead of panicking.
+    strict=False is the reference bit for bit: no such check, and a failed `assert_eq!` (:303) raises."""
+
+    def __init__(self, n, g, field=None, strict=True):
         self.n = n
         self.g = g
         self.field = field if field is not None else g.field
+        self.strict = strict
         self.c_1 = 0
         self.g_part = []
         self.r = []
 
     @classmethod
-    def new(cls, n, g, field=None):
-        return cls(n, g, field)
+    def new(cls, n, g, field=None, strict=True):
+        return cls(n, g, field, strict)
 
     def set_c_1(self, c_1):
         self.c_1 = c_1
@@ -223,12 +230,18 @@ class Verifier:
             self.r.append(r_j)
             return VerifierRoundResult.JthRound(r_j)
         if len(self.r) == self.n - 1:                                      # :298-310
+            if self.strict:
+                prev_evaluation = self.g_part[-1].evaluate(self.r[-1])
+                evaluation = f.add(g_j.evaluate(f.zero), g_j.evaluate(f.one))
+                if prev_evaluation != evaluation:
+                    raise ProverClaimMismatch("%d" % f.to_int(prev_evaluation), "%d" % f.to_int(evaluation))
             self.r.append(r_j)
             if self.g is None:
                 raise NoPolySet()
             lhs = g_j.evaluate(r_j)
             rhs = self.g.evaluate(self.r)
-            assert lhs == rhs, "assert_eq!(g_j.evaluate(&r_j), g.evaluate(&self.r).unwrap())"   # :303
+            if lhs != rhs and not self.strict:                                                   # :303
+                raise AssertionError("assert_eq!(g_j.evaluate(&r_j), g.evaluate(&self.r).unwrap())")
             return VerifierRoundResult.FinalRound(lhs == rhs)
         prev_evaluation = self.g_part[-1].evaluate(self.r[-1])             # :313-328
         evaluation = f.add(g_j.evaluate(f.zero), g_j.evaluate(f.one))
