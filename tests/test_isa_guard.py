@@ -1,0 +1,97 @@
+"""Compile-time guards on the gfx950 ISA of the hot kernels (CPU-only: hipcc cross-compiles).
+They pin two regressions DESIGN.md describes - the streaming (`nt`) hint silently lost when written as a
+run-time select, and hand-written carry-chain asm breaking the compiler's register/SCC bookkeeping -
+plus the occupancy and no-scratch assumptions the launch code relies on."""
+import os
+import re
+import subprocess
+
+import pytest
+
+from conftest import ROOT
+
+CSRC = os.path.join(ROOT, "thaler-study_amd", "csrc")
+
+
+@pytest.fixture(scope="module")
+def isa():
+    subprocess.check_call(["make", "-C", CSRC, "isa"], stdout=subprocess.DEVNULL)
+    text = open(os.path.join(CSRC, "build", "sumcheck_hip.s")).read()
+    usage = open(os.path.join(CSRC, "build", "resource_usage.txt")).read()
+    return text, usage
+
+
+def kernel_usage(usage, mangled_fragment):
+    """{field: int} of the first kernel whose mangled name contains the fragment"""
+    blocks = usage.split("remark: Function Name: ")[1:]
+    for b in blocks:
+        name = b.split(" ")[0]
+        if mangled_fragment in name:
+            out = {}
+            for key in ("TotalSGPRs", "VGPRs", "ScratchSize [bytes/lane]", "Occupancy [waves/SIMD]", "LDS Size [bytes/block]",
+                        "VGPRs Spill", "SGPRs Spill"):
+                m = re.search(re.escape(key) + r": (\d+)", b)
+                out[key] = int(m.group(1))
+            return out
+    raise AssertionError("no kernel matching %s" % mangled_fragment)
+
+
+def kernel_body(text, mangled_fragment):
+    m = re.search(r"^(_ZN2sc\S*%s\S*):[^\n]*\n(.*?)\n\.Lfunc_end" % re.escape(mangled_fragment), text, flags=re.S | re.M)
+    assert m, mangled_fragment
+    return m.group(2)
+
+
+GOLD = "INS_14GoldilocksMontE"
+
+
+def test_first_pass_occupancy_and_no_scratch(isa):
+    _, usage = isa
+    u = kernel_usage(usage, "pass_kernel%sLi0ELi3ELi1E" % GOLD)           # 27-cell first pass, nt loads
+    assert u["Occupancy [waves/SIMD]"] >= 2, u
+    assert u["ScratchSize [bytes/lane]"] == 0 and u["VGPRs Spill"] == 0 and u["SGPRs Spill"] == 0, u
+    assert u["VGPRs"] <= 256
+    for frag in ("pass_kernel%sLi3ELi2ELi3E" % GOLD, "pass_kernel%sLi2ELi2ELi1E" % GOLD, "small_pass3_kernel%sLi3E" % GOLD,
+                 "evaluate_kernel%sLb1E" % GOLD, "fix_low_kernel%sLb1E" % GOLD):
+        u = kernel_usage(usage, frag)
+        assert u["ScratchSize [bytes/lane]"] == 0 and u["VGPRs Spill"] == 0, (frag, u)
+        assert u["Occupancy [waves/SIMD]"] >= 2, (frag, u)
+    # every kernel of the library: no scratch, no spills
+    for b in usage.split("remark: Function Name: ")[1:]:
+        name = b.split(" ")[0]
+        assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", b), name
+        assert re.search(r"VGPRs Spill: 0\b", b), name
+
+
+def test_streaming_variants_carry_nt_and_cached_variants_do_not(isa):
+    text, _ = isa
+    nt1 = kernel_body(text, "pass_kernel%sLi0ELi3ELi1E" % GOLD)
+    loads = re.findall(r"global_load_dwordx4[^\n]*", nt1)
+    # the full-tile path streams (8 nt loads per tile and table pair, twice: prologue + prefetch); only the
+    # ragged last tile uses plain predicated loads
+    assert sum(" nt" in l for l in loads) >= 8, "first pass lost its nontemporal loads"
+    nt3 = kernel_body(text, "pass_kernel%sLi3ELi2ELi3E" % GOLD)
+    assert any(" nt" in l for l in re.findall(r"global_load_dwordx4[^\n]*", nt3))
+    assert any(" nt" in l for l in re.findall(r"global_store_dwordx4[^\n]*", nt3)), "streamed outputs lost their nt stores"
+    nt0 = kernel_body(text, "pass_kernel%sLi2ELi2ELi0E" % GOLD)
+    assert not any(" nt" in l for l in re.findall(r"global_(?:load|store)_dwordx4[^\n]*", nt0))
+    ev = kernel_body(text, "evaluate_kernel%sLb1E" % GOLD)
+    assert any(" nt" in l for l in re.findall(r"global_load_dwordx4[^\n]*", ev))
+
+
+def test_carry_chain_asm_is_intact(isa):
+    """the hand-scheduled Goldilocks sequences (field.hpp sub4/sub2/acc_mac) appear as written: carries on
+    the pinned SGPR pairs s[72:85], the borrow mask formed by s_andn2_b64 on the scalar unit, and no
+    compiler-inserted s_nop inside a block"""
+    text, usage = isa
+    body = kernel_body(text, "pass_kernel%sLi0ELi3ELi1E" % GOLD)
+    assert len(re.findall(r"s_andn2_b64 s\[72:73\], s\[72:73\], s\[80:81\]", body)) >= 1
+    assert body.count("v_mad_u64_u32") >= 27 * 4
+    # the pinned pairs are clobbers the register allocator must respect: nothing else may be live in them
+    # across a block, which shows up as the kernel needing at least s85
+    u = kernel_usage(usage, "pass_kernel%sLi0ELi3ELi1E" % GOLD)
+    assert u["TotalSGPRs"] >= 86 and u["TotalSGPRs"] <= 102, u
+    # one sub4 block = 16 VALU + 4 SALU in a row
+    blk = re.search(r"v_sub_co_u32_e64 v\d+, vcc, v\d+, v\d+\n(?:\s+[^\n]+\n){18}\s+v_subb_co_u32_e64 v\d+, s\[84:85\], v\d+, 0, s\[76:77\]", body)
+    assert blk, "sub4 block not found as written"
+    assert "s_nop" not in blk.group(0)

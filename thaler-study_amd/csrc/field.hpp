@@ -260,10 +260,16 @@ struct GoldilocksMont {
     return add(sub(x, y), z);
   }
 
-  // Unreduced sum of up to 2^31 products in FOUR registers.  2^96 == -1 (mod p), so a 128-bit
-  // product x*y = L + H*2^96 (L = its low 96 bits, H < 2^32) is congruent to L - H: a 128-bit
-  // two's-complement accumulator takes 2^31 such terms (|sum| < 2^127) and needs no carry word -
-  // one register and about a third of the add-with-carry work less than a 160-bit sum.
+  // Unreduced sum of products in FOUR registers.  2^96 == -1 (mod p), so a 128-bit product
+  // x*y = L + H*2^96 (L = its low 96 bits, H < 2^32) is congruent to L - H: a 128-bit
+  // two's-complement accumulator needs no carry word - one register and about a third of the
+  // add-with-carry work less than a 160-bit sum.  Capacity: the device sequence adds, per product,
+  // t + m*2^32 + q0*2^64 - (q1 + sC) with t, q0*2^64 < 2^96 and m*2^32 < 2^97, i.e. less than 3*2^96;
+  // the sum stays inside (-2^127, 2^127) for kAccMaxTerms = 2^28 terms with a wide margin (the exact
+  // bound is about 2^29.4).  Beyond that it would wrap mod 2^128, which is not 0 mod p.  Every
+  // kernel's per-thread accumulation count is far below (tiles per wave, rows per chunk, 2^k <= 2^17
+  // entries per dot product); the host checks the caller-sized ones against kAccMaxTerms.
+  static constexpr u64 kAccMaxTerms = (u64)1 << 28;
   struct Acc {
     u32 l0, l1, l2, l3;  // little-endian 32-bit limbs of the two's-complement sum
   };

@@ -89,6 +89,10 @@ struct sc_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   mutable std::string err;
+  // set by the first HIP failure other than an allocation failure (a faulted kernel, a lost mailbox
+  // word): the stream, the ticket counter and the pool can no longer be trusted, so every later call
+  // fails fast with SC_ERR_STATE instead of spinning on a hand-off that will never come
+  mutable bool poisoned = false;
 
   // options
   int vars_per_pass = 2;
@@ -159,6 +163,10 @@ struct sc_table {
 
 namespace {
 
+inline void poison(const sc_ctx* ctx) {
+  if (ctx) ctx->poisoned = true;
+}
+
 int fail(const sc_ctx* ctx, int code, const char* fmt, ...) {
   char buf[512];
   va_list ap;
@@ -173,9 +181,11 @@ int fail(const sc_ctx* ctx, int code, const char* fmt, ...) {
 #define SC_HIP(ctx, call)                                                                  \
   do {                                                                                     \
     hipError_t e_ = (call);                                                                \
-    if (e_ != hipSuccess)                                                                  \
+    if (e_ != hipSuccess) {                                                                \
+      if (e_ != hipErrorOutOfMemory) poison(ctx);                                          \
       return fail(ctx, e_ == hipErrorOutOfMemory ? SC_ERR_OOM : SC_ERR_HIP, "%s: %s (%s:%d)", \
                   #call, hipGetErrorString(e_), __FILE__, __LINE__);                       \
+    }                                                                                      \
   } while (0)
 
 #define SC_TRY(expr)            \
@@ -266,6 +276,8 @@ int new_table(sc_ctx* ctx, size_t len, sc_table** out) {
 }
 
 int set_device(sc_ctx* ctx) {
+  if (ctx->poisoned)
+    return fail(ctx, SC_ERR_STATE, "context is unusable after an earlier HIP failure (%s); destroy it", ctx->err.c_str());
   SC_HIP(ctx, hipSetDevice(ctx->device));
   return SC_OK;
 }
@@ -478,19 +490,24 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   out.ticket_base = ctx->ticket_base;
   out.sums_dev = ctx->d_sums;
   out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
-  out.seq = mailbox ? ++ctx->mailbox_seq : 0;
-  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  out.seq = mailbox ? ctx->mailbox_seq + 1 : 0;
   SC_TRY(timer_begin(ctx, (ks == 3 && kf > 0) ? SC_KIND_TAIL_PASS : SC_KIND_PASS, kf, ks, log_in, (u64)16 << log_in,
                      kf > 0 ? (u64)16 << (log_in - kf) : 0));
   SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, fw, n_units, grid, log_in, out));
   SC_HIP(ctx, hipGetLastError());
+  // the launch is in the stream: only now do the ticket base and the mailbox sequence move (a failed
+  // launch must leave them where the device-side counter still is)
+  if (mailbox) ctx->mailbox_seq += 1;
+  if (grid > 1) ctx->ticket_base += (unsigned)grid;
   SC_TRY(timer_end(ctx));
   *from_mailbox = mailbox;
   return SC_OK;
 }
 
-// PassOut of the next launch with `grid` blocks that publishes to the mailbox (unsharded paths)
+// PassOut of the next launch with `grid` blocks that publishes to the mailbox (unsharded paths).
+// Nothing is committed here: call commit_pass_out() once the launch is known to be in the stream.
 sc::PassOut next_pass_out(sc_ctx* ctx, int grid) {
+  (void)grid;
   sc::PassOut out;
   out.partials = ctx->d_partials;
   out.n_rows = (int)ctx->partial_rows;
@@ -498,9 +515,14 @@ sc::PassOut next_pass_out(sc_ctx* ctx, int grid) {
   out.ticket_base = ctx->ticket_base;
   out.sums_dev = ctx->d_sums;
   out.mailbox = ctx->use_mailbox ? ctx->d_mailbox : nullptr;
-  out.seq = ctx->use_mailbox ? ++ctx->mailbox_seq : 0;
-  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  out.seq = ctx->use_mailbox ? ctx->mailbox_seq + 1 : 0;
   return out;
+}
+int commit_pass_out(sc_ctx* ctx, const sc::PassOut& out, int grid) {
+  SC_HIP(ctx, hipGetLastError());
+  if (out.mailbox) ctx->mailbox_seq += 1;
+  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  return SC_OK;
 }
 
 
@@ -516,12 +538,19 @@ int wait_mailbox(sc_ctx* ctx, u64 seq) {
   while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
     if ((++spins & 0x3FFF) == 0) {
       hipError_t q = hipStreamQuery(ctx->stream);
-      if (q != hipSuccess && q != hipErrorNotReady)
+      if (q != hipSuccess && q != hipErrorNotReady) {
+        poison(ctx);
         return fail(ctx, SC_ERR_HIP, "pass kernel failed: %s", hipGetErrorString(q));
+      }
       double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if (q == hipSuccess && el > 2.0)
+      if (q == hipSuccess && el > 2.0) {
+        poison(ctx);
         return fail(ctx, SC_ERR_HIP, "pass kernel finished but its mailbox word never arrived");
-      if (el > 120.0) return fail(ctx, SC_ERR_HIP, "timed out waiting for the pass kernel");
+      }
+      if (el > 120.0) {
+        poison(ctx);
+        return fail(ctx, SC_ERR_HIP, "timed out waiting for the pass kernel");
+      }
     }
     __builtin_ia32_pause();
   }
@@ -547,10 +576,11 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
     if (ctx->use_mailbox && count <= (size_t)sc::kMailboxSeq) {
       // device -> pinned mailbox by a one-wave kernel; the host spins instead of a
       // memcpy + stream synchronise (about 8 us less per pass)
-      const u64 seq = ++ctx->mailbox_seq;
+      const u64 seq = ctx->mailbox_seq + 1;
       hipLaunchKernelGGL(sc::mailbox_copy_kernel, dim3(1), dim3(sc::kWave), 0, ctx->stream, (const u64*)ctx->d_sums,
                          (int)count, ctx->d_mailbox, seq);
       SC_HIP(ctx, hipGetLastError());
+      ctx->mailbox_seq = seq;
       SC_TRY(wait_mailbox(ctx, seq));
         src = ctx->h_mailbox;
     } else {
@@ -656,6 +686,8 @@ int coldot(sc_ctx* ctx, const u64* in, const u64* w, size_t rows, size_t M, u64*
   }
   const size_t rows_per_chunk = (rows + chunks - 1) / chunks;
   chunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+  if (rows_per_chunk > sc::GoldilocksMont::kAccMaxTerms)   // one lazy accumulator sums rows_per_chunk products
+    return fail(ctx, SC_ERR_UNSUPPORTED, "coldot: %zu rows per chunk exceed the lazy accumulator's capacity", rows_per_chunk);
   u64* partial = out;
   if (chunks > 1) SC_TRY(pool_alloc(ctx, chunks * M, &partial));
   size_t gx = (mp + sc::kBlock - 1) / sc::kBlock;
@@ -715,6 +747,16 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
   u64* owned = nullptr;  // intermediate we own (never `in`)
   size_t cur_len = len;
   size_t done = 0;
+  // a failing step gives back the intermediate of the previous one (and its own output)
+#define SC_CHAIN(expr)                \
+  do {                                \
+    int rc_ = (expr);                 \
+    if (rc_ != SC_OK) {               \
+      pool_release(ctx, nxt);         \
+      pool_release(ctx, owned);       \
+      return rc_;                     \
+    }                                 \
+  } while (0)
   while (done < k) {
     int step;
     u64* nxt = nullptr;
@@ -722,26 +764,26 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
       // many variables left: one streaming pass over contiguous segments (kernels.hpp, fix_low_kernel)
       step = (int)std::min<size_t>(17, k - done);
       const size_t nlen = cur_len >> step;
-      SC_TRY(pool_alloc(ctx, nlen, &nxt));
+      SC_CHAIN(pool_alloc(ctx, nlen, &nxt));
       const sc::RVec rv = make_rvec(r + done, (size_t)step);
       const int grid = (int)std::min<size_t>((nlen + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
       const int nt = cur_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
-      SC_TRY(timer_begin(ctx, SC_KIND_FIX_LOW, step, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * nlen));
+      SC_CHAIN(timer_begin(ctx, SC_KIND_FIX_LOW, step, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * nlen));
       if (nt)
         SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F, true>), dim3(grid), dim3(sc::kBlock), 0,
                                                         ctx->stream, f, cur, nxt, step, rv, nlen));
       else
         SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F, false>), dim3(grid), dim3(sc::kBlock), 0,
                                                         ctx->stream, f, cur, nxt, step, rv, nlen));
-      SC_TRY(timer_end(ctx));
+      SC_CHAIN(timer_end(ctx));
       cur_len = nlen;
     } else if (order == SC_ORDER_LE) {
       step = (int)std::min<size_t>(3, k - done);
       while (step > 1 && (cur_len >> step) < 2) --step;
       size_t nlen = cur_len >> step;
-      SC_TRY(pool_alloc(ctx, nlen, &nxt));
+      SC_CHAIN(pool_alloc(ctx, nlen, &nxt));
       const sc::FoldW fw = make_fold_weights(ctx, r + done, step);
-      SC_TRY(timer_begin(ctx, SC_KIND_FOLD, step, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * nlen));
+      SC_CHAIN(timer_begin(ctx, SC_KIND_FOLD, step, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * nlen));
       if (nlen >= 2) {
         size_t n_units = nlen / 2;
         int grid = grid_for(ctx, n_units);
@@ -763,25 +805,34 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
         SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_le_small_kernel<F>), dim3(1), dim3(64), 0,
                                                         ctx->stream, f, cur, nxt, r[done], nlen));
       }
-      SC_TRY(timer_end(ctx));
+      SC_CHAIN(timer_end(ctx));
       cur_len = nlen;
     } else {
       step = 1;
       size_t half = cur_len / 2;
-      SC_TRY(pool_alloc(ctx, half, &nxt));
+      SC_CHAIN(pool_alloc(ctx, half, &nxt));
       int grid = grid_for(ctx, (half + 1) / 2);
-      SC_TRY(timer_begin(ctx, SC_KIND_FOLD_BE, 1, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * half));
+      SC_CHAIN(timer_begin(ctx, SC_KIND_FOLD_BE, 1, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * half));
       SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_be_kernel<F>), dim3(grid), dim3(sc::kBlock), 0,
                                                       ctx->stream, f, cur, nxt, r[done], half));
-      SC_TRY(timer_end(ctx));
+      SC_CHAIN(timer_end(ctx));
       cur_len = half;
     }
-    SC_HIP(ctx, hipGetLastError());
+    {
+      hipError_t le = hipGetLastError();
+      if (le != hipSuccess) {
+        poison(ctx);
+        pool_release(ctx, nxt);
+        pool_release(ctx, owned);
+        return fail(ctx, SC_ERR_HIP, "fold launch: %s", hipGetErrorString(le));
+      }
+    }
     if (owned) pool_release(ctx, owned);  // stream-ordered reuse: single stream per context
     owned = nxt;
     cur = nxt;
     done += step;
   }
+#undef SC_CHAIN
   *out = owned;
   *out_len = cur_len;
   return SC_OK;
@@ -1209,8 +1260,7 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
   out.ticket_base = ctx->ticket_base;
   out.sums_dev = ctx->d_sums;
   out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
-  out.seq = mailbox ? ++ctx->mailbox_seq : 0;
-  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  out.seq = mailbox ? ctx->mailbox_seq + 1 : 0;
   const int nt = nv >= ctx->nt_load_log ? 1 : 0;
   SC_TRY(timer_begin(ctx, SC_KIND_EVALUATE, nv, 0, nv, (u64)8 << nv, 0));
   if (nt)
@@ -1219,7 +1269,7 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
   else
     SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::evaluate_kernel<F, false>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
                                                     f, d, nv, rv, ta, chunk_log, w_extra, out));
-  SC_HIP(ctx, hipGetLastError());
+  SC_TRY(commit_pass_out(ctx, out, grid));
   SC_TRY(timer_end(ctx));
   *from_mailbox = mailbox;
   return SC_OK;
@@ -1693,7 +1743,13 @@ extern "C" int sc_prover_round(sc_prover* pr, uint64_t r_prev, size_t j, uint64_
   if (r_prev >= ctx->fp.p && j != 0) return fail(ctx, SC_ERR_ARG, "sc_prover_round: challenge is not reduced");
   SC_TRY(set_device(ctx));
   if (j != 0) pr->pending.push_back(r_prev);  // sum-check-protocol/src/lib.rs:106-109
-  if (!cache_covers(pr, j)) SC_TRY(prover_pass(pr, j));
+  if (!cache_covers(pr, j)) {
+    const int rc = prover_pass(pr, j);
+    if (rc != SC_OK) {
+      if (j != 0 && !pr->pending.empty()) pr->pending.pop_back();  // a retried round must not fold r_prev twice
+      return rc;
+    }
+  }
   prover_answer(pr, j, out_e);
   pr->next_round = j + 1;
   return SC_OK;
@@ -1777,11 +1833,10 @@ int w_round_sums(sc_ctx* ctx, const WView& w, u64 e[3]) {
   out.ticket_base = ctx->ticket_base;
   out.sums_dev = ctx->d_sums;
   out.mailbox = ctx->use_mailbox ? ctx->d_mailbox : nullptr;
-  out.seq = ctx->use_mailbox ? ++ctx->mailbox_seq : 0;
-  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  out.seq = ctx->use_mailbox ? ctx->mailbox_seq + 1 : 0;
   SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_sums_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
                                                   w.add, w.mul, V, logV, Fx, n_pieces, out));
-  SC_HIP(ctx, hipGetLastError());
+  SC_TRY(commit_pass_out(ctx, out, grid));
   SC_TRY(collect_sums(ctx, 3, false, ctx->use_mailbox != 0, e));
   HostField hf(ctx->fp);
   e[2] = eval2_from_inf(hf, e[0], e[1], e[2]);
@@ -1943,7 +1998,7 @@ int gkr_sparse_round(sc_gkr_prover* pr, int shift, u64 r_prev, u64 e[3]) {
   SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_sparse_round_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
                                                   f, (const unsigned*)pr->sp_idx, (const int*)pr->sp_type, pr->sp_val,
                                                   pr->n_entries, shift, r_prev, V, logV, Fx, out));
-  SC_HIP(ctx, hipGetLastError());
+  SC_TRY(commit_pass_out(ctx, out, grid));
   SC_TRY(collect_sums(ctx, 3, false, ctx->use_mailbox != 0, e));
   HostField hf(ctx->fp);
   e[2] = eval2_from_inf(hf, e[0], e[1], e[2]);
@@ -2192,7 +2247,7 @@ extern "C" int sc_tri_round_sums(sc_ctx* ctx, const sc_table* f1, const sc_table
   sc::PassOut out = next_pass_out(ctx, grid);
   SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::tri_sums_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
                                                   v.f1, v.f2, v.f3, v.xv, v.yv, v.zv, out));
-  SC_HIP(ctx, hipGetLastError());
+  SC_TRY(commit_pass_out(ctx, out, grid));
   SC_TRY(collect_sums(ctx, 3, false, ctx->use_mailbox != 0, out_e));
   HostField hf(ctx->fp);
   out_e[2] = eval2_from_inf(hf, out_e[0], out_e[1], out_e[2]);
@@ -2265,12 +2320,13 @@ namespace {
 // Fold the challenges the sub-prover has not applied yet plus `r_last`; hand back its tables.
 int prover_finish(sc_prover* pr, u64 r_last, u64** a_out, u64** b_out, size_t* len_out) {
   sc_ctx* ctx = pr->ctx;
-  pr->pending.push_back(r_last);
+  std::vector<u64> rs(pr->pending);   // the sub-prover's own state is left untouched
+  rs.push_back(r_last);
   const size_t len = (size_t)1 << pr->cur_log;
   u64 *na = nullptr, *nb = nullptr;
   size_t la = 0, lb = 0;
-  SC_TRY(fold_chain(ctx, pr->cur_a, len, pr->pending.data(), pr->pending.size(), SC_ORDER_LE, &na, &la));
-  int rc = fold_chain(ctx, pr->cur_b, len, pr->pending.data(), pr->pending.size(), SC_ORDER_LE, &nb, &lb);
+  SC_TRY(fold_chain(ctx, pr->cur_a, len, rs.data(), rs.size(), SC_ORDER_LE, &na, &la));
+  int rc = fold_chain(ctx, pr->cur_b, len, rs.data(), rs.size(), SC_ORDER_LE, &nb, &lb);
   if (rc != SC_OK) {
     pool_release(ctx, na);
     return rc;
@@ -2337,36 +2393,57 @@ extern "C" int sc_tri_prover_round(sc_tri_prover* tp, uint64_t r_prev, size_t j,
   if (j != 0 && r_prev >= ctx->fp.p) return fail(ctx, SC_ERR_ARG, "sc_tri_prover_round: challenge is not reduced");
   SC_TRY(set_device(ctx));
   if (j != 0) tp->r.push_back(r_prev);
+  // a failed round leaves the challenge list as it was, so the round can be retried
+#define SC_TRY_POP(expr)                        \
+  do {                                          \
+    int rc_ = (expr);                           \
+    if (rc_ != SC_OK) {                         \
+      if (j != 0) tp->r.pop_back();             \
+      return rc_;                               \
+    }                                           \
+  } while (0)
   HostField hf(ctx->fp);
   const size_t n = (size_t)1 << k;
   if (j == k) {
     // x fully fixed at r_x = r[0..k): P(r_x, .) is not needed any more, f3(r_x, .) is
+    // every buffer lands in a member of tp at once, so an error return leaks nothing (destroy frees them)
     u64 *pa = nullptr, *pb = nullptr;
     size_t len = 0;
-    SC_TRY(prover_finish(tp->sub, r_prev, &pa, &pb, &len));
+    SC_TRY_POP(prover_finish(tp->sub, r_prev, &pa, &pb, &len));
     pool_release(ctx, pa);
+    pool_release(ctx, tp->f3r);
     tp->f3r = pb;  // f3(r_x, z), 2^k entries
     size_t l1 = 0;
-    SC_TRY(fold_chain(ctx, tp->adj, n * n, tp->r.data(), k, SC_ORDER_LE, &tp->f1y, &l1));  // f1(r_x, y)
-    SC_TRY(pool_alloc(ctx, n, &tp->Q));
-    SC_TRY(coldot(ctx, tp->adj, tp->f3r, n, n, tp->Q));  // Q[y] = sum_z f2[(z<<k)|y] f3r[z]
-    SC_TRY(tri_start_phase(tp, tp->f1y, tp->Q, n));
+    pool_release(ctx, tp->f1y);
+    tp->f1y = nullptr;
+    SC_TRY_POP(fold_chain(ctx, tp->adj, n * n, tp->r.data(), k, SC_ORDER_LE, &tp->f1y, &l1));  // f1(r_x, y)
+    if (!tp->Q) SC_TRY_POP(pool_alloc(ctx, n, &tp->Q));
+    SC_TRY_POP(coldot(ctx, tp->adj, tp->f3r, n, n, tp->Q));  // Q[y] = sum_z f2[(z<<k)|y] f3r[z]
+    SC_TRY_POP(tri_start_phase(tp, tp->f1y, tp->Q, n));
   } else if (j == 2 * k) {
     u64 *pa = nullptr, *pb = nullptr;
     size_t len = 0;
-    SC_TRY(prover_finish(tp->sub, r_prev, &pa, &pb, &len));
+    SC_TRY_POP(prover_finish(tp->sub, r_prev, &pa, &pb, &len));
     pool_release(ctx, pb);
-    SC_HIP(ctx, hipMemcpyAsync(&tp->scale, pa, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));  // f1(r_x, r_y)
-    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    hipError_t ce = hipMemcpyAsync(&tp->scale, pa, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);  // f1(r_x, r_y)
+    if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
     pool_release(ctx, pa);
+    if (ce != hipSuccess) {
+      poison(ctx);
+      tp->r.pop_back();
+      return fail(ctx, SC_ERR_HIP, "triangle prover: %s", hipGetErrorString(ce));
+    }
     size_t l2 = 0;
-    SC_TRY(fold_chain(ctx, tp->adj, n * n, tp->r.data() + k, k, SC_ORDER_LE, &tp->f2r, &l2));  // f2(r_y, z)
-    SC_TRY(tri_start_phase(tp, tp->f2r, tp->f3r, n));
+    pool_release(ctx, tp->f2r);
+    tp->f2r = nullptr;
+    SC_TRY_POP(fold_chain(ctx, tp->adj, n * n, tp->r.data() + k, k, SC_ORDER_LE, &tp->f2r, &l2));  // f2(r_y, z)
+    SC_TRY_POP(tri_start_phase(tp, tp->f2r, tp->f3r, n));
   }
   const size_t local_j = j % k;
   const bool phase_start = (local_j == 0);
   u64 e[3];
-  SC_TRY(sc_prover_round(tp->sub, phase_start ? hf.one() : r_prev, local_j, e));
+  SC_TRY_POP(sc_prover_round(tp->sub, phase_start ? hf.one() : r_prev, local_j, e));
+#undef SC_TRY_POP
   if (j >= 2 * k) {
     for (int i = 0; i < 3; ++i) e[i] = hf.mul(e[i], tp->scale);
   }

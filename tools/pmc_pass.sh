@@ -22,4 +22,4 @@ for k, v in agg.items():
 PY
   rm -rf $O/pmc$i
 done
-cat $O/pmc1.txt $O/pmc2.txt $O/pmc3.txt $O/pmc4.txt | grep -E "0, 3, 1>|3, 2, 3>" | grep -v "n=0"
+cat $O/pmc1.txt $O/pmc2.txt | grep -E "0, 3, 1>|3, 2, 3>" | grep -v "n=0"
