@@ -112,8 +112,12 @@ def setup_transport(args, pkg, ctx_factory, rank, world, dist):
     ctx = ctx_factory()
     transport = "none"
     want = os.environ.get("SC_BENCH_TRANSPORT", "")
-    if world == 1 and os.environ.get("SC_BENCH_FORCE_RCCL") == "1":
-        D.attach_rccl(ctx, 0, 1)   # diagnostic: the collective code path on a single-GPU box
+    if world == 1 and (os.environ.get("SC_BENCH_FORCE_RCCL") == "1" or want in ("rccl", "peer")):
+        # diagnostic: the sharded code path (per-pass exchange, tail gather) with one rank on a single-GPU box
+        if want == "peer":
+            D.attach_peer(ctx, 0, 1)
+            return ctx, "peer(world=1, diagnostic)"
+        D.attach_rccl(ctx, 0, 1)
         return ctx, "rccl(world=1, diagnostic)"
     if world > 1:
         import torch

@@ -87,6 +87,12 @@ const char* sc_last_error(const sc_ctx* ctx);
  *   "max_blocks"       grid cap of the streaming kernels (default 3 per CU = 768); a pass never
  *                      launches more blocks than are resident at once
  *   "use_mailbox"      kernels publish sums to pinned host memory the host spins on (default 1)
+ *   "resident"         serve the latency-bound passes of a proof from ONE resident launch whose phases the
+ *                      host steers through a pinned command line (default 0: measured equal to launches on
+ *                      one GPU); "resident_log": largest table it starts from (default 19);
+ *                      "park_ms": it leaves the GPU after this long without a command (default 20)
+ *   "arena_log"        peer transport: a gather arena holds world * 2^arena_log words per table (default 17;
+ *                      set before sc_ctx_comm_peer_export); "peer_spin_ms": bound of in-kernel waits for peers
  *   "time_kernels"     HIP-event timing of pass kernels (see sc_ctx_kernel_time)
  *   "nt_load_log" / "nt_store_log"  table log-size from which loads / stores are nontemporal */
 int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value);
@@ -138,6 +144,18 @@ typedef int (*sc_allreduce_fn)(void* user, uint64_t* buf, size_t count);
 typedef int (*sc_allgather_fn)(void* user, const uint64_t* send, uint64_t* recv, size_t count);
 int sc_ctx_comm_init_host(sc_ctx* ctx, int rank, int world, sc_allreduce_fn allreduce,
                           sc_allgather_fn allgather, void* user);
+/* Peer transport: the data plane of a one-node run without any collective launch.  Every rank exports a
+ * small region of its HBM (an inbox for the per-pass round sums + arenas for the tail gather), maps every
+ * other rank's region (HIP IPC, written over xGMI), and from then on the last workgroup of each sharded
+ * pass exchanges its sums with the peers itself and hands the totals to its host (kernels.hpp, PeerX).
+ * Up to 8 ranks.  Usage: export on every rank -> all-gather the 64-byte handles by any means (they are
+ * plain bytes) -> connect with the world x 64 bytes in rank order.  Sharding semantics are those of
+ * sc_ctx_comm_init_rccl.  The challenges every rank feeds to sc_prover_round / returns from `draw` must
+ * be identical; the exchange carries a digest of them and a mismatch fails the pass with SC_ERR_STATE. */
+int sc_ctx_comm_peer_export(sc_ctx* ctx, int rank, int world, uint8_t handle[64]);
+int sc_ctx_comm_peer_connect(sc_ctx* ctx, const uint8_t* handles);
+/* the same for ranks that are contexts of ONE process (threads; tests): peers[q] = rank q's context */
+int sc_ctx_comm_peer_connect_local(sc_ctx* ctx, sc_ctx* const* peers);
 int sc_ctx_comm_rank(const sc_ctx* ctx, int* rank, int* world);
 
 /* ---- tables: DenseMultilinearExtension<F> on the device ------------------------------- */
@@ -210,7 +228,10 @@ int sc_prover_destroy(sc_prover* pr);
  * with the round's three sums already read back - the verifier's rng.draw() at
  * sum-check-protocol/src/lib.rs:283, or a Fiat-Shamir hash).  draw == NULL uses the
  * synthetic challenger r_j = to_mont(splitmix64(seed_r + j + 1) mod p).
- * evals (3*n words) and challenges (n words) may be NULL. */
+ * evals (3*n words) and challenges (n words) may be NULL.
+ * Sharded contexts: every rank runs this call; `draw` is invoked on every rank and MUST return the same
+ * challenge everywhere (derive it from the transcript, or draw on one rank and broadcast inside `draw`).
+ * The peer transport checks this (digest in the exchange); the other transports do not. */
 typedef uint64_t (*sc_draw_fn)(void* user, size_t round, const uint64_t evals[3]);
 int sc_prove(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_draw_fn draw, void* user,
              uint64_t seed_r, uint64_t* c1, uint64_t* evals, uint64_t* challenges);

@@ -58,6 +58,16 @@ def test_bench_two_ranks_on_one_device():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert "host" in d["config"]["transport"]
+    # the default data plane: in-kernel exchange through peer-mapped inboxes (HIP IPC between the two processes)
+    env = dict(os.environ, SC_BENCH_SINGLE_DEVICE="1")
+    env.pop("SC_BENCH_TRANSPORT", None)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port + 1), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--num-vars", "20", "--steps", "4", "--warmup", "1", "--cpu-num-vars", "0"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert d["n_gpus"] == 2 and d["config"]["transport"] == "peer" and d["value"] > 0
 
 
 @pytest.mark.gpu

@@ -47,10 +47,11 @@ class Loopback:
         return allreduce, allgather
 
 
-def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove"):
+def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove", transport="host"):
     lb = Loopback(world)
     results = [None] * world
     errors = []
+    ctxs = [None] * world
 
     def body(rank):
         try:
@@ -59,8 +60,17 @@ def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove"):
             ctx.set_option("vars_per_pass", min(vpp, 2))
             ctx.set_option("first_pass_vars", 3 if vpp == 3 else min(vpp, 2))
             ctx.set_option("tail_pass_vars", 3 if vpp == 3 else 2)
-            ar, ag = lb.collectives(rank)
-            ctx.comm_init_host(rank, world, ar, ag)
+            if transport == "peer":
+                # in-kernel exchange through peer-mapped inboxes; threads of one process share the address space
+                ctx.set_option("peer_spin_ms", 20000)
+                ctx.comm_peer_export(rank, world)
+                ctxs[rank] = ctx
+                lb.barrier.wait()
+                ctx.comm_peer_connect_local(ctxs)
+                lb.barrier.wait()
+            else:
+                ar, ag = lb.collectives(rank)
+                ctx.comm_init_host(rank, world, ar, ag)
             start, length = pkg.distributed.shard_range(n, rank, world)
             nl = length.bit_length() - 1
             a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, nl, start=start)
@@ -72,6 +82,8 @@ def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove"):
             e0 = g.round_evals() if nl >= 1 else None
             s0 = g.hypercube_sum()
             results[rank] = (c1, evals, ch, final, e0, s0)
+            if transport == "peer":
+                lb.barrier.wait()      # nobody unmaps a region a peer's kernel may still write
             ctx.close()
         except Exception as e:  # pragma: no cover
             import traceback
@@ -185,3 +197,45 @@ def test_virtual_ranks_g_new(world):
         assert not errors, errors
         for c1, evals in results:
             assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+
+
+@pytest.mark.parametrize("world", [2])
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+def test_virtual_ranks_peer_transport(p, world):
+    """the in-kernel exchange (no collective launch): every sharded pass's last workgroup writes its limbs into
+    every rank's inbox and sums what the peers wrote; the tail gather goes through the peer-mapped arenas.
+    Two ranks only when the ranks are threads of ONE process: a workgroup that waits for a peer needs the
+    peer's kernel to run beside it, and one process's streams share a handful of hardware queues (with four
+    contexts a waiting kernel can sit in front of the kernel it waits for: measured, bounded by peer_spin_ms).
+    One process per rank - the deployment - has no such coupling; the test below runs 2 and 4 processes."""
+    pkg = load_package()
+    o = oracle(p)
+    g = world.bit_length() - 1
+    for n, tail_log, vpp in [(g, 0, 2), (g + 1, 0, 3), (g + 3, 0, 2), (12, 0, 3), (12, 5, 2), (16, 3, 3), (18, 12, 3), (20, 16, 3)]:
+        oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+        ch = challenges(o, n)
+        ref = o.prove(oa, ob, ch)
+        results, _ = run_virtual_ranks(pkg, p, n, world, tail_log, vpp, transport="peer")
+        for rank, (c1, evals, chn, final, e0, s0) in enumerate(results):
+            assert c1 == ref["c_1"], (n, tail_log, rank)
+            assert np.array_equal(evals, ref["evals"]), (n, tail_log, rank)
+            assert final == ref["final_eval"], (n, tail_log, rank)
+            assert s0 == ref["c_1"]
+            if e0 is not None:
+                assert e0 == [int(x) for x in ref["evals"][0]]
+
+
+@pytest.mark.parametrize("nproc", [2, 8])
+def test_peer_transport_processes_one_device(nproc):
+    """2 / 8 PROCESSES on GPU 0 exchanging HIP IPC handles (the mapping a multi-GPU node uses, minus xGMI): sharded
+    proofs, sharded evaluate and the degenerate paths, bit-exact against the oracle on every rank"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    port = 29950 + (os.getpid() % 40)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
+                          "--master-addr", "127.0.0.1", "--master-port", str(port + nproc), os.path.join(root, "tests", "peer_worker.py")],
+                         capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, (out.stdout[-3000:], out.stderr[-3000:])
+    assert out.stdout.count("PEER-OK") == nproc, out.stdout[-3000:]

@@ -56,6 +56,9 @@ SIGNATURES = {
     "sc_comm_unique_id": (ctypes.c_int, [ctypes.POINTER(ctypes.c_uint8)]),
     "sc_ctx_comm_init_rccl": (ctypes.c_int, [voidp, ctypes.POINTER(ctypes.c_uint8), ctypes.c_int, ctypes.c_int]),
     "sc_ctx_comm_init_host": (ctypes.c_int, [voidp, ctypes.c_int, ctypes.c_int, ALLREDUCE_FN, ALLGATHER_FN, voidp]),
+    "sc_ctx_comm_peer_export": (ctypes.c_int, [voidp, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_uint8)]),
+    "sc_ctx_comm_peer_connect": (ctypes.c_int, [voidp, ctypes.POINTER(ctypes.c_uint8)]),
+    "sc_ctx_comm_peer_connect_local": (ctypes.c_int, [voidp, ctypes.POINTER(voidp)]),
     "sc_ctx_comm_rank": (ctypes.c_int, [voidp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "sc_table_upload": (ctypes.c_int, [voidp, u64p, size_t, ctypes.POINTER(voidp)]),
     "sc_table_generate": (ctypes.c_int, [voidp, u64, u64, size_t, ctypes.POINTER(voidp)]),

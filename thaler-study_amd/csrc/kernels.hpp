@@ -155,6 +155,9 @@ __device__ __forceinline__ void accumulate_octet(const F& f, typename F::Acc* ac
 __device__ __forceinline__ u64 shfl_down_u64(u64 v, int off) {
   return (u64)__shfl_down((unsigned long long)v, off, kWave);
 }
+__device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
+  return (u64)__shfl((unsigned long long)v, src, kWave);
+}
 
 // Block-wide modular sum of NS per-thread residues; result valid in threads [0, NS).
 template <class F, int NS>
@@ -262,6 +265,32 @@ __device__ __forceinline__ void transpose_to_pieces(ull2* __restrict__ lds, ull2
 //    the sequence word at index kMailboxSeq) or, for the sharded transports that still have
 //    to all-reduce on the device, `sums_dev`.
 constexpr int kMailboxSeq = 60;   // 2*27 limbs first, the sequence word after them
+constexpr int kMailboxErr = 62;   // 0, or why the pass's cross-rank exchange failed (kXchg*)
+
+// In-kernel exchange of the round sums between the ranks of a sharded prover (one process per GPU,
+// SURVEY.md section 8e).  Each rank owns an INBOX in its own HBM that every peer maps (HIP IPC) and writes
+// over xGMI: inbox[parity][source rank][kInboxWords] 8-byte granules {tag : 32 | value : 32}.  The values
+// are the 32-bit limbs of the pass's sums (a u64 sum of residues would wrap mod 2^64, not mod p), so the
+// data IS the flag (cdna_hip_programming.md Guideline 16, R2): the last block of a pass stores its 2*NS
+// limbs into every rank's inbox with one store each, sweeps its own inbox until every source's tag is
+// this pass's, adds the limbs and publishes the totals to its host - no collective launch, no separate
+// flag, no ordering requirement between the stores.  Two parities: a rank can be at most one pass ahead
+// of a peer that has not read the previous pass yet.  One more granule carries a digest of the
+// challenges the pass folds; ranks that were fed different challenges fail loudly instead of proving
+// different statements.
+constexpr int kMaxPeers = 8;
+constexpr int kInboxWords = 64;
+constexpr int kInboxDigest = 56;     // granule index of the challenge digest
+constexpr int kInboxGather = 57;     // granule index of the table-gather flag
+constexpr int kXchgTimeout = 1, kXchgDigest = 2;
+struct PeerX {
+  u64* inbox[kMaxPeers] = {};   // inbox[q]: rank q's inbox as this process maps it (q == rank: the local one)
+  int world = 0;                // 0: no in-kernel exchange
+  int rank = 0;
+  unsigned tag = 0;             // this pass's exchange tag: the same on every rank, never 0
+  unsigned digest = 0;
+  u64 spin_ticks = 0;           // bound of the sweep (wall clock, 100 MHz)
+};
 struct PassOut {
   u64* partials;
   int n_rows;
@@ -270,6 +299,7 @@ struct PassOut {
   u64* sums_dev;
   u64* mailbox;
   u64 seq;
+  PeerX px;
 };
 
 __device__ __forceinline__ void publish_value(const PassOut& o, int s, u64 v) {
@@ -286,11 +316,66 @@ __device__ __forceinline__ void publish_seq(const PassOut& o) {
     __hip_atomic_store(o.mailbox + kMailboxSeq, o.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// Cross-rank exchange by ONE workgroup (the pass's last block): xl[0 .. 2*NS) are this rank's limbs.
+// Leaves the limb totals in the host mailbox; every thread of the block must call it.
+template <int NS>
+__device__ __forceinline__ void exchange_and_publish(const PassOut& o, u64* xl) {
+  const PeerX& px = o.px;
+  const int lane = threadIdx.x;
+  __syncthreads();   // xl is complete
+  if (threadIdx.x < kWave) {
+    const bool mine = lane < 2 * NS || lane == kInboxDigest;
+    const u64 val = (lane < 2 * NS) ? xl[lane] : (u64)px.digest;
+    const u64 granule = ((u64)px.tag << 32) | (val & 0xFFFFFFFFull);
+    const size_t slot = ((size_t)(px.tag & 1u) * kMaxPeers + (size_t)px.rank) * kInboxWords + (size_t)lane;
+    if (mine) {
+      for (int q = 0; q < px.world; ++q)
+        __hip_atomic_store(px.inbox[q] + slot, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // sweep the local inbox: one granule per source rank and lane
+    u64 total = 0;
+    int err = 0;
+    const unsigned long long t0 = wall_clock64();
+    if (mine) {
+      const u64* base = px.inbox[px.rank] + (size_t)(px.tag & 1u) * kMaxPeers * kInboxWords + (size_t)lane;
+      for (int r = 0; r < px.world && !err; ++r) {
+        unsigned spins = 0;
+        while (true) {
+          const u64 g = __hip_atomic_load(base + (size_t)r * kInboxWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if ((unsigned)(g >> 32) == px.tag) {
+            if (lane == kInboxDigest) err = ((unsigned)g != px.digest) ? kXchgDigest : 0;
+            else total += g & 0xFFFFFFFFull;
+            break;
+          }
+          if ((++spins & 31) == 0 && wall_clock64() - t0 > px.spin_ticks) { err = kXchgTimeout; break; }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+    }
+    if (lane < 2 * NS) __hip_atomic_store(o.mailbox + lane, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // any lane's failure reaches the host before the sequence word does
+    const int any = __any(err != 0) ? 1 : 0;
+    int code = err;
+#pragma unroll
+    for (int off = kWave / 2; off >= 1; off >>= 1) code = max(code, __shfl_down(code, off, kWave));
+    if (lane == 0) __hip_atomic_store(o.mailbox + kMailboxErr, (u64)(any ? code : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  publish_seq(o);
+}
+
 // Tail of every pass: res[0] of thread s < NS holds the block's residue of sum s.
 template <class F, int NS>
 __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my_res, int* lds_flag) {
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  __shared__ u64 xl[2 * NS + 2];   // this rank's limbs on their way to the peers (sharded passes only)
+  const bool xchg = o.px.world > 0;
   if (gridDim.x == 1) {
+    if (xchg) {
+      if (threadIdx.x < NS) write_split(xl, threadIdx.x, my_res);
+      exchange_and_publish<NS>(o, xl);
+      return;
+    }
     if (threadIdx.x < NS) publish_value(o, threadIdx.x, my_res);
     __syncthreads();
     publish_seq(o);
@@ -346,9 +431,18 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
       u = f.add(u, shfl_down_u64(u, off));
     }
     if (lane == 0) {
-      publish_value(o, s, t);
-      if (two) publish_value(o, s2, u);
+      if (xchg) {
+        write_split(xl, s, t);
+        if (two) write_split(xl, s2, u);
+      } else {
+        publish_value(o, s, t);
+        if (two) publish_value(o, s2, u);
+      }
     }
+  }
+  if (xchg) {
+    exchange_and_publish<NS>(o, xl);
+    return;
   }
   __syncthreads();
   publish_seq(o);
@@ -586,6 +680,388 @@ small_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u6
   __syncthreads();
   const u64 mine = (threadIdx.x < NS) ? lsum[threadIdx.x] : 0;
   finish_pass<F, NS>(f, out, mine, &lds_flag);
+}
+
+// ------------------------------------------------------------------------------------
+// The resident prover kernel: every pass after the first two of a proof in ONE launch.
+//
+// From the third pass on a proof is a chain of short passes (at n = 28: 2^25, 2^23, 2^21 entries
+// and then six cache-resident ones) whose cost is launch, drain and hand-off latency, not bytes:
+// 11 launches cost ~290 us of kernel time and ~60 us of launch gaps for 7 % of the traffic.  This
+// kernel stays on the chip for all of them.  A PHASE is what a pass was: fold the kf challenges
+// that arrived since the previous phase, write the folded tables, accumulate the 3^ks grid for the
+// next ks rounds, reduce across blocks (ticket), publish to the host mailbox.  Between phases the
+// blocks wait for the host's next command - the challenges the verifier drew for the rounds just
+// served (sum-check-protocol/src/lib.rs:283) - which block 0 reads from pinned host memory and
+// forwards through a device word every other block polls.  Blocks that have no tile in a phase
+// (and, since tables only shrink, in none after it) exit.
+//
+// Hand-off between phases follows cdna_hip_programming.md Guideline 16: folded tables are stored
+// write-through (`sc1`), every storing wave drains (s_waitcnt vmcnt(0)) before the block's ticket;
+// the next phase starts, in every block, with a relaxed poll of the command word, ONE agent-scope
+// acquire, the drain of that invalidate and a workgroup barrier, then plain loads.
+// Every spin is bounded: without a command for `park_ticks` (wall clock, 100 MHz) block 0 PARKS the
+// kernel - it tells the other blocks and the host, everything exits, and the host continues with
+// ordinary launches from the tables the last finished phase left (a caller that takes seconds
+// between rounds must not pin the GPU, and a lost command must not hang it).
+constexpr int kMaxResidentPhases = 16;
+constexpr u64 kCmdPark = 0x8000000000000000ull;   // dev_cmd sequence word: "parked", phase in the low bits
+constexpr int kMailboxParked = 61;                // host mailbox word: 0, or 1 + the phase the kernel parked before
+constexpr int kCmdWords = 8;                      // one 64-byte line: [0] = sequence, [1..3] = challenges
+struct ResidentPlan {
+  int n_phases;
+  int kf[kMaxResidentPhases], ks[kMaxResidentPhases], log_in[kMaxResidentPhases];
+  int big[kMaxResidentPhases];      // 1: streaming body (wave tiles through LDS), 0: one thread per output
+  int blocks[kMaxResidentPhases];   // blocks with work in the phase (non-increasing)
+};
+struct ResidentCtl {
+  const u64* host_cmd;   // pinned host line the host writes: challenges first, sequence word last
+  u64* dev_cmd;          // device line block 0 forwards it to
+  u64 cmd_base;          // phase p (>= 1) runs on the command with sequence cmd_base + p
+  u64 park_ticks;
+  u64* stamps;           // optional [phases][8] wall-clock stamps of block 0 (diagnostic builds of a run, else null)
+};
+#define SC_STAMP(k) do { if (ctl.stamps && blockIdx.x == 0 && threadIdx.x == 0) ctl.stamps[p * 8 + (k)] = wall_clock64(); } while (0)
+
+__device__ __forceinline__ void st16_sc1(ull2* p, ull2 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
+}
+
+// eq weights of the kf challenges of a phase (FoldW is computed on the host for launched passes; a
+// resident phase gets the raw challenges and every block derives the weights itself: 2^kf products)
+template <class F>
+__device__ __forceinline__ FoldW fold_weights_from(const F& f, const u64* r, int kf) {
+  FoldW fw;
+#pragma unroll
+  for (int c = 0; c < 8; ++c) fw.w[c] = 0;
+  fw.w[0] = f.one();
+  // fully unrolled with compile-time indices (a run-time index into fw.w would put it in scratch)
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    if (j < kf) {
+      const u64 rj = r[j], nrj = f.sub(f.one(), r[j]);
+#pragma unroll
+      for (int c = (1 << j) - 1; c >= 0; --c) {
+        const u64 base = fw.w[c];
+        fw.w[c + (1 << j)] = f.mul(base, rj);
+        fw.w[c] = f.mul(base, nrj);
+      }
+    }
+  }
+  return fw;
+}
+
+// finish_pass for a phase of the resident kernel: n_blocks = blocks active in the phase.  Every wave
+// has drained its table stores before the barrier in front of this call.
+template <class F, int NS>
+__device__ __forceinline__ void finish_phase(const F& f, const PassOut& o, int n_blocks, u64 my_res, int* lds_flag) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  if (n_blocks == 1) {
+    if (threadIdx.x < NS) publish_value(o, threadIdx.x, my_res);
+    __syncthreads();
+    publish_seq(o);
+    return;
+  }
+  if (threadIdx.x < NS)
+    __hip_atomic_store(o.partials + (size_t)threadIdx.x * o.n_rows + blockIdx.x, my_res, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(o.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t - o.ticket_base == (unsigned)n_blocks - 1) ? 1 : 0;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *lds_flag = last;
+  }
+  __syncthreads();
+  if (!*lds_flag) return;
+  constexpr int kWavesPerBlock = kBlock / kWave;
+  for (int s = wave; s < NS; s += kWavesPerBlock) {
+    const u64* row = o.partials + (size_t)s * o.n_rows;
+    u64 a0 = 0, a1 = 0;
+    int b = lane;
+    for (; b + kWave < n_blocks; b += 2 * kWave) {
+      const u64 x = __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const u64 y = __hip_atomic_load(row + b + kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      a0 = f.add(a0, x);
+      a1 = f.add(a1, y);
+    }
+    if (b < n_blocks) a0 = f.add(a0, __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    u64 t = f.add(a0, a1);
+#pragma unroll
+    for (int off = kWave / 2; off >= 1; off >>= 1) t = f.add(t, shfl_down_u64(t, off));
+    if (lane == 0) publish_value(o, s, t);
+  }
+  __syncthreads();
+  publish_seq(o);
+}
+
+// Streaming body of a resident phase: pass_kernel<F,2,2>'s tile loop with plain loads (the phase's
+// acquire is behind us) and write-through stores.  Leaves the block's nine residues in thread s.
+template <class F>
+__device__ __attribute__((noinline)) u64 resident_big22(const F& f, const u64* __restrict__ A, const u64* __restrict__ B,
+                                              u64* __restrict__ A2, u64* __restrict__ B2, const FoldW& fw, size_t n_units,
+                                              int n_blocks, ull2* lds_t /*[4*64*8]*/, u64* lds_r /*[4*9]*/) {
+  constexpr int KF = 2, KS = 2, IN = 16, NP = 8, NPO = 2, NS = 9;
+  constexpr int kWaves = kBlock / kWave;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  ull2* const my_lds = lds_t + wave * kWave * NP;
+  typename F::Acc acc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) f.acc_zero(acc[s]);
+  const size_t n_tiles = (n_units + kWave - 1) / kWave;
+  const size_t in_pieces = n_units * NP, out_pieces = n_units * NPO;
+  const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(A);
+  const ull2* __restrict__ Bp = reinterpret_cast<const ull2*>(B);
+  ull2* A2p = reinterpret_cast<ull2*>(A2);
+  ull2* B2p = reinterpret_cast<ull2*>(B2);
+  for (size_t tile = (size_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (size_t)n_blocks * kWaves) {
+    ull2 pa[NP], pb[NP];
+    const size_t q0 = tile * kWave * NP;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const size_t q = q0 + (size_t)k * kWave + lane;
+      const ull2 zero = {0, 0};
+      pa[k] = (q < in_pieces) ? Ap[q] : zero;
+      pb[k] = (q < in_pieces) ? Bp[q] : zero;
+    }
+    transpose_to_runs<NP>(my_lds, pa, lane);
+    transpose_to_runs<NP>(my_lds, pb, lane);
+    u64 a[IN], b[IN];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      a[2 * k] = pa[k].x; a[2 * k + 1] = pa[k].y;
+      b[2 * k] = pb[k].x; b[2 * k + 1] = pb[k].y;
+    }
+    fold_run<F, KF, IN>(f, a, fw);
+    fold_run<F, KF, IN>(f, b, fw);
+    ull2 oa[NPO], ob[NPO];
+#pragma unroll
+    for (int m = 0; m < NPO; ++m) {
+      oa[m].x = a[2 * m]; oa[m].y = a[2 * m + 1];
+      ob[m].x = b[2 * m]; ob[m].y = b[2 * m + 1];
+    }
+    transpose_to_pieces<NPO>(my_lds, oa, lane);
+    transpose_to_pieces<NPO>(my_lds, ob, lane);
+    const size_t o0 = tile * kWave * NPO;
+#pragma unroll
+    for (int k = 0; k < NPO; ++k) {
+      const size_t q = o0 + (size_t)k * kWave + lane;
+      if (q < out_pieces) {
+        st16_sc1(A2p + q, oa[k]);
+        st16_sc1(B2p + q, ob[k]);
+      }
+    }
+    accumulate_run<F, KS>(f, acc, a, b);
+  }
+  u64 res[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) res[s] = f.acc_get(acc[s]);
+  block_reduce<F, NS>(f, res, lds_r);
+  return res[0];
+}
+
+// One-thread-per-output body of a resident phase (small_pass3_kernel generalised over KS): each thread
+// folds 2^KF inputs of both tables into one output, stores it write-through and leaves it in LDS; one
+// thread in 2^KS then accumulates the 3^KS grid of its run of outputs; the raw accumulators go through
+// LDS so that all 256 threads share their reduction.  Returns the block's residue of sum s in thread s.
+template <class F, int KF, int KS>
+__device__ __attribute__((noinline)) u64 resident_small(const F& f, const u64* __restrict__ A, const u64* __restrict__ B,
+                                              u64* __restrict__ A2, u64* __restrict__ B2, const FoldW& fw, size_t n_out,
+                                              int n_blocks, u64* la, u64* lb, typename F::Acc* lacc, u64* lsum) {
+  constexpr int G = 1 << KF, RUN = 1 << KS, NS = (KS == 1) ? 3 : (KS == 2) ? 9 : 27;
+  constexpr int kAccThreads = kBlock / RUN;
+  typename F::Acc acc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) f.acc_zero(acc[s]);
+  const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(A);
+  const ull2* __restrict__ Bp = reinterpret_cast<const ull2*>(B);
+  for (size_t base = (size_t)blockIdx.x * kBlock; base < n_out; base += (size_t)n_blocks * kBlock) {
+    const size_t i = base + threadIdx.x;
+    u64 ta = 0, tb = 0;
+    if (i < n_out) {
+      u64 va[G], vb[G];
+#pragma unroll
+      for (int m = 0; m < G / 2; ++m) {
+        const ull2 pa = Ap[i * (G / 2) + m], pb = Bp[i * (G / 2) + m];
+        va[2 * m] = pa.x; va[2 * m + 1] = pa.y;
+        vb[2 * m] = pb.x; vb[2 * m + 1] = pb.y;
+      }
+      fold_run<F, KF, G>(f, va, fw);
+      fold_run<F, KF, G>(f, vb, fw);
+      ta = va[0];
+      tb = vb[0];
+      __hip_atomic_store(A2 + i, ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 8-byte sc1 store
+      __hip_atomic_store(B2 + i, tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    la[threadIdx.x] = ta;
+    lb[threadIdx.x] = tb;
+    __syncthreads();
+    if (threadIdx.x < kAccThreads && base + RUN * threadIdx.x < n_out) {
+      u64 a[RUN], b[RUN];
+#pragma unroll
+      for (int k = 0; k < RUN; ++k) {
+        a[k] = la[RUN * threadIdx.x + k];
+        b[k] = lb[RUN * threadIdx.x + k];
+      }
+      if constexpr (KS == 3) accumulate_octet<F>(f, acc, a, b);
+      else accumulate_run<F, KS>(f, acc, a, b);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x < kAccThreads) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) lacc[s * kAccThreads + threadIdx.x] = acc[s];
+  }
+  __syncthreads();
+  // NS * kAccThreads raw accumulators -> residues by all 256 threads; the kAccThreads partials of a cell
+  // are consecutive, so shuffles sum them inside a wave (W = min(kAccThreads, 64) lanes) and, for
+  // KS = 1 (128 partials per cell), the two half sums meet in LDS
+  constexpr int W = kAccThreads < kWave ? kAccThreads : kWave;
+  constexpr int kParts = kAccThreads / W;
+  for (int idx = threadIdx.x; idx < NS * kAccThreads; idx += kBlock) {
+    u64 r = f.acc_get(lacc[idx]);
+#pragma unroll
+    for (int off = W / 2; off >= 1; off >>= 1) r = f.add(r, shfl_down_u64(r, off));
+    if ((idx & (W - 1)) == 0) la[idx / W] = r;   // la is free again: the tile loop has ended
+  }
+  __syncthreads();
+  if (threadIdx.x < NS) {
+    u64 t = la[threadIdx.x * kParts];
+#pragma unroll
+    for (int w = 1; w < kParts; ++w) t = f.add(t, la[threadIdx.x * kParts + w]);
+    lsum[threadIdx.x] = t;
+  }
+  __syncthreads();
+  return (threadIdx.x < NS) ? lsum[threadIdx.x] : 0;
+}
+
+template <class F>
+__global__ void __launch_bounds__(kBlock, 2)
+resident_kernel(F f, const u64* __restrict__ A0, const u64* __restrict__ B0, u64* PA, u64* PB, u64* QA, u64* QB,
+                FoldW fw0, ResidentPlan plan, PassOut out, ResidentCtl ctl) {
+  constexpr int kWaves = kBlock / kWave;
+  // one LDS array, carved per body (cdna_hip_programming.md: a second __shared__ object can de-pipeline)
+  __shared__ ull2 smem[kWaves * kWave * 8 + 1024];
+  __shared__ u64 lds_cmd[4];
+  __shared__ int lds_flag;
+  ull2* const lds_t = smem;                                          // big body: 4 x 64 x 8 pieces (32 KiB)
+  u64* const lds_r = reinterpret_cast<u64*>(smem + kWaves * kWave * 8);   // 4 x 9 words
+  u64* const la = reinterpret_cast<u64*>(smem);                      // small body: 256 + 256 words,
+  u64* const lb = la + kBlock;                                       //   then 27 x 32 accumulators, 27 sums
+  typename F::Acc* const lacc = reinterpret_cast<typename F::Acc*>(lb + kBlock);
+  u64* const lsum = reinterpret_cast<u64*>(smem + kWaves * kWave * 8 + 512);
+
+  const u64* curA = A0;
+  const u64* curB = B0;
+  unsigned ticket_base = out.ticket_base;
+  FoldW fw = fw0;
+  for (int p = 0; p < plan.n_phases; ++p) {
+    const int n_blocks = plan.blocks[p];
+    if ((int)blockIdx.x >= n_blocks) return;   // no tile in this phase, hence in none after it
+    const int kf = plan.kf[p], ks = plan.ks[p], log_in = plan.log_in[p];
+    SC_STAMP(0);
+    if (p > 0) {
+      // ---- wait for the host's command: the challenges of the rounds the previous phase served ----
+      // The command is ONE 64-byte line {sequence, r0, r1, r2, check = seq ^ r0 ^ r1 ^ r2}: five lanes read
+      // it with one load instruction (one PCIe / L2 round trip) and the check word rejects a torn read.
+      if (threadIdx.x < kWave) {
+        const int lane = threadIdx.x;
+        const u64 want = ctl.cmd_base + (u64)p, park = kCmdPark | (u64)p;
+        const unsigned long long t0 = wall_clock64();
+        unsigned spins = 0;
+        u64 mine = 0, seq = 0;
+        bool ok = false;
+        if (blockIdx.x == 0) {
+          while (true) {
+            mine = (lane < 5) ? __hip_atomic_load(ctl.host_cmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
+            seq = shfl_u64(mine, 0);
+            if (seq == park) break;                       // the host's abort
+            if (seq == want) {
+              const u64 chk = seq ^ shfl_u64(mine, 1) ^ shfl_u64(mine, 2) ^ shfl_u64(mine, 3);
+              if (chk == shfl_u64(mine, 4)) { ok = true; break; }
+            }
+            if ((++spins & 63) == 0 && wall_clock64() - t0 > ctl.park_ticks) { seq = park; break; }
+            __builtin_amdgcn_s_sleep(1);
+          }
+          if (!ok && lane == 0)   // park: tell the host which phase was never started
+            __hip_atomic_store(out.mailbox + kMailboxParked, (u64)p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+          // forward the line (or the park word) to the other blocks of the phase: one store instruction
+          if (n_blocks > 1 || !ok) {
+            const u64 fwd = ok ? mine : (lane == 0 ? park : (lane == 4 ? park : 0));
+            if (lane < 5) __hip_atomic_store(ctl.dev_cmd + lane, fwd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else {
+          while (true) {
+            mine = (lane < 5) ? __hip_atomic_load(ctl.dev_cmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+            seq = shfl_u64(mine, 0);
+            const u64 chk = seq ^ shfl_u64(mine, 1) ^ shfl_u64(mine, 2) ^ shfl_u64(mine, 3);
+            if (chk == shfl_u64(mine, 4)) {
+              if (seq == want) { ok = true; break; }
+              if (seq == park) break;
+            }
+            // block 0 parks first; this bound only covers a block 0 that died
+            if ((++spins & 63) == 0 && wall_clock64() - t0 > 4 * ctl.park_ticks) break;
+            __builtin_amdgcn_s_sleep(2);
+          }
+        }
+        if (lane < 4) lds_cmd[lane] = (lane == 0) ? (ok ? want : park) : mine;
+        if (lane == 0) {
+          SC_STAMP(1);
+          // ONE agent-scope acquire per block: the folded tables other blocks stored write-through in the
+          // previous phase are read with plain loads from here on
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      __syncthreads();
+      if (lds_cmd[0] != ctl.cmd_base + (u64)p) return;   // parked
+      u64 r[3] = {lds_cmd[1], lds_cmd[2], lds_cmd[3]};
+      fw = fold_weights_from(f, r, kf);
+      __syncthreads();   // lds_cmd is rewritten in the next phase
+    }
+    SC_STAMP(2);
+    u64* const outA = (p & 1) ? QA : PA;
+    u64* const outB = (p & 1) ? QB : PB;
+    PassOut o = out;
+    o.ticket_base = ticket_base;
+    o.seq = out.seq + (u64)p;
+    const size_t n_out = (size_t)1 << (log_in - kf);
+    u64 mine = 0;
+    int ns = (ks == 1) ? 3 : (ks == 2) ? 9 : 27;
+    if (plan.big[p]) {
+      mine = resident_big22<F>(f, curA, curB, outA, outB, fw, n_out >> 2, n_blocks, lds_t, lds_r);
+    } else {
+#define SC_SMALL(KF, KS) mine = resident_small<F, KF, KS>(f, curA, curB, outA, outB, fw, n_out, n_blocks, la, lb, lacc, lsum)
+      switch (kf * 4 + ks) {
+        case 1 * 4 + 1: SC_SMALL(1, 1); break;
+        case 1 * 4 + 2: SC_SMALL(1, 2); break;
+        case 1 * 4 + 3: SC_SMALL(1, 3); break;
+        case 2 * 4 + 1: SC_SMALL(2, 1); break;
+        case 2 * 4 + 2: SC_SMALL(2, 2); break;
+        case 2 * 4 + 3: SC_SMALL(2, 3); break;
+        case 3 * 4 + 1: SC_SMALL(3, 1); break;
+        case 3 * 4 + 2: SC_SMALL(3, 2); break;
+        default: SC_SMALL(3, 3); break;
+      }
+#undef SC_SMALL
+    }
+    SC_STAMP(3);
+    // every wave drains its write-through table stores, then the block signals (Guideline 16, R1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    SC_STAMP(4);
+    if (ns == 3) finish_phase<F, 3>(f, o, n_blocks, mine, &lds_flag);
+    else if (ns == 9) finish_phase<F, 9>(f, o, n_blocks, mine, &lds_flag);
+    else finish_phase<F, 27>(f, o, n_blocks, mine, &lds_flag);
+    SC_STAMP(5);
+    if (n_blocks > 1) ticket_base += (unsigned)n_blocks;
+    curA = outA;
+    curB = outB;
+    __syncthreads();
+  }
 }
 
 // ------------------------------------------------------------------------------------
@@ -1161,6 +1637,94 @@ recombine_limbs_kernel(F f, const u64* __restrict__ limbs, size_t n, u64* __rest
     const ull2 l = reinterpret_cast<const ull2*>(limbs)[i];
     const u64 lo = f.reduce_word(l.x), hi = f.reduce_word(l.y);
     out[i] = f.add(lo, f.mul(f.mul(hi, c32), f.r_squared()));
+  }
+}
+
+// All-gather of both tables of a sharded prover over the peer mapping (the tail gather of SURVEY.md
+// section 8e): every rank copies its `len` words of A and B into slot `rank` of EVERY rank's arena with
+// system-scope write-through stores, drains them, and the last block then tells every peer (a tagged
+// granule in the peer's inbox) and waits until every peer has told it.  arena layout: [table][rank][len].
+struct PeerG {
+  u64* arena[kMaxPeers] = {};
+  size_t table_stride = 0;   // words between the two tables' regions
+};
+__device__ __forceinline__ void st16_sys(ull2* p, ull2 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
+}
+__global__ void __launch_bounds__(kBlock)
+peer_gather_kernel(const u64* __restrict__ A, const u64* __restrict__ B, size_t len, PeerG pg, PassOut out) {
+  __shared__ int lds_flag;
+  const PeerX& px = out.px;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (int q = 0; q < px.world; ++q) {
+    u64* dstA = pg.arena[q] + (size_t)px.rank * len;
+    u64* dstB = dstA + pg.table_stride;
+    if ((len & 1) == 0) {
+      const ull2* Ap = reinterpret_cast<const ull2*>(A);
+      const ull2* Bp = reinterpret_cast<const ull2*>(B);
+      for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len / 2; i += stride) {
+        st16_sys(reinterpret_cast<ull2*>(dstA) + i, Ap[i]);
+        st16_sys(reinterpret_cast<ull2*>(dstB) + i, Bp[i]);
+      }
+    } else {
+      for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += stride) {
+        __hip_atomic_store(dstA + i, A[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(dstB + i, B[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the block signals
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int last = 1;
+    if (gridDim.x > 1) {
+      const unsigned t = __hip_atomic_fetch_add(out.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = (t - out.ticket_base == gridDim.x - 1) ? 1 : 0;
+    }
+    lds_flag = last;
+  }
+  __syncthreads();
+  if (!lds_flag) return;
+  if (threadIdx.x < kWave) {
+    const int lane = threadIdx.x;
+    const size_t par = (size_t)(px.tag & 1u) * kMaxPeers * kInboxWords;
+    const u64 granule = ((u64)px.tag << 32) | 1u;
+    if (lane < px.world)
+      __hip_atomic_store(px.inbox[lane] + par + (size_t)px.rank * kInboxWords + kInboxGather, granule, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    int err = 0;
+    if (lane < px.world) {
+      const u64* w = px.inbox[px.rank] + par + (size_t)lane * kInboxWords + kInboxGather;
+      const unsigned long long t0 = wall_clock64();
+      unsigned spins = 0;
+      while ((unsigned)(__hip_atomic_load(w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >> 32) != px.tag) {
+        if ((++spins & 31) == 0 && wall_clock64() - t0 > px.spin_ticks) { err = kXchgTimeout; break; }
+        __builtin_amdgcn_s_sleep(1);
+      }
+    }
+    const int any = __any(err != 0) ? 1 : 0;
+    if (lane == 0 && out.mailbox)
+      __hip_atomic_store(out.mailbox + kMailboxErr, (u64)(any ? kXchgTimeout : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  publish_seq(out);
+}
+
+// Cross-rank sum of limbs that a small kernel left in device memory (the degenerate paths that do not end
+// in finish_pass): one workgroup of one wave.
+template <int NS>
+__global__ void peer_exchange_kernel(const u64* __restrict__ limbs, PassOut out) {
+  __shared__ u64 xl[2 * NS + 2];
+  if (threadIdx.x < 2 * NS) xl[threadIdx.x] = limbs[threadIdx.x];
+  exchange_and_publish<NS>(out, xl);
+}
+// out[i] = sum over `rows` rows of in[r * n + i]: plain u64 adds (the words are 32-bit limbs)
+__global__ void __launch_bounds__(kBlock)
+sum_limb_rows_kernel(const u64* __restrict__ in, int rows, size_t n, u64* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    u64 t = 0;
+    for (int r = 0; r < rows; ++r) t += in[(size_t)r * n + i];
+    out[i] = t;
   }
 }
 

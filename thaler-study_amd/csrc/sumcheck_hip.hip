@@ -79,7 +79,7 @@ bool load_rccl(std::string* why) {
   return true;
 }
 
-enum class Transport { kNone, kRccl, kHost };
+enum class Transport { kNone, kRccl, kHost, kPeer };
 
 }  // namespace
 
@@ -129,6 +129,21 @@ struct sc_ctx {
   u64* d_mailbox = nullptr;   // device alias of h_mailbox
   u64 mailbox_seq = 0;
   int use_mailbox = 1;
+  // resident prover kernel (kernels.hpp): command line the host writes and the kernel's block 0 polls
+  // (pinned, one 64-byte line), its device-side forward, and the sequence base of the next launch
+  u64* h_cmd = nullptr;
+  u64* d_cmd_host = nullptr;   // device alias of h_cmd
+  u64* d_cmd = nullptr;
+  u64 cmd_seq = 0;
+  int resident = 1;            // option "resident": serve the latency-bound passes from one resident launch
+  int resident_log = 25;       // largest input (log2 entries per table) the resident kernel starts from
+  int park_ms = 20;            // the resident kernel parks itself after this long without a command
+  double dbg_host_ns = 0.0;    // diagnostic: host time between a phase's sums and the next command (resident_stamps)
+  std::chrono::steady_clock::time_point dbg_t_collect;
+  int resident_stamps = 0;     // option "resident_stamps": block 0 records wall-clock stamps per phase (diagnostic)
+  int resident_blocks_cap = 0; // blocks of resident_kernel that are resident at once (0 = not asked yet)
+  struct sc_prover* live_resident = nullptr;   // prover whose resident kernel is on the stream
+  bool in_resident_owner = false;
 
   // device-buffer pool (free blocks by capacity in words; live blocks by pointer)
   std::multimap<size_t, u64*> pool_free;
@@ -141,6 +156,16 @@ struct sc_ctx {
   sc_allreduce_fn host_allreduce = nullptr;
   sc_allgather_fn host_allgather = nullptr;
   void* host_user = nullptr;
+  // peer transport (kernels.hpp, PeerX): this rank's region = inbox + two gather arenas, and every
+  // rank's region as this process maps it
+  u64* peer_region = nullptr;
+  size_t peer_region_words = 0;
+  bool peer_exported = false;
+  u64* peer_base[sc::kMaxPeers] = {};
+  bool peer_ipc_opened[sc::kMaxPeers] = {};
+  int arena_log = 17;          // a gather arena holds world * 2^arena_log words per table
+  unsigned xchg_tag = 0;       // exchange tag of the last sharded pass (the same on every rank)
+  int peer_spin_ms = 2000;     // bound of every in-kernel wait for a peer
 
   // kernel timing
   // pass-kernel timing (option "time_kernels"): a ring of event pairs, read back only when the
@@ -275,7 +300,12 @@ int new_table(sc_ctx* ctx, size_t len, sc_table** out) {
   return SC_OK;
 }
 
+void resident_retire(sc_ctx* ctx);   // defined with the prover
+
 int set_device(sc_ctx* ctx) {
+  // any other work on this context goes to the stream the resident kernel occupies: end it first (the
+  // prover it belongs to carries on with ordinary launches)
+  if (ctx->live_resident && !ctx->in_resident_owner) resident_retire(ctx);
   if (ctx->poisoned)
     return fail(ctx, SC_ERR_STATE, "context is unusable after an earlier HIP failure (%s); destroy it", ctx->err.c_str());
   SC_HIP(ctx, hipSetDevice(ctx->device));
@@ -471,6 +501,37 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
 #undef SC_PASS
 }
 
+constexpr size_t kInboxRegionWords = 2 * (size_t)sc::kMaxPeers * sc::kInboxWords;   // two parities
+
+// 32-bit digest of what a sharded pass folds: identical on every rank unless the ranks were fed
+// different challenges (FNV-1a over the words)
+unsigned challenge_digest(const u64* r, int kf, int ks, int log_in) {
+  u64 h = 0xcbf29ce484222325ull;
+  auto mix = [&h](u64 v) {
+    for (int i = 0; i < 8; ++i) {
+      h ^= (v >> (8 * i)) & 0xFF;
+      h *= 0x100000001b3ull;
+    }
+  };
+  mix((u64)kf | ((u64)ks << 8) | ((u64)log_in << 16));
+  for (int i = 0; i < kf; ++i) mix(r[i]);
+  return (unsigned)(h ^ (h >> 32));
+}
+
+// Exchange fields of a sharded launch on the peer transport.  The tag advances with every such launch,
+// in the same order on every rank.
+void fill_peer(sc_ctx* ctx, sc::PassOut* out, unsigned digest) {
+  sc::PeerX& px = out->px;
+  for (int q = 0; q < ctx->world; ++q) px.inbox[q] = ctx->peer_base[q];
+  px.world = ctx->world;
+  px.rank = ctx->rank;
+  ctx->xchg_tag += 1;
+  if (ctx->xchg_tag == 0) ctx->xchg_tag = 1;
+  px.tag = ctx->xchg_tag;
+  px.digest = digest;
+  px.spin_ticks = (u64)ctx->peer_spin_ms * 100000ull;
+}
+
 // Launch one pass over tables of 2^log_in entries.  The 2*NS split limbs end up in the
 // host mailbox (*from_mailbox = true; wait with collect_sums) or in ctx->d_sums when they
 // still have to be all-reduced on the device (RCCL transport).
@@ -482,7 +543,8 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   size_t n_units = (size_t)1 << (log_in - kf - ks);
   int grid = grid_for(ctx, (ks == 3 && kf > 0) ? n_units * 8 : n_units);
   grid = std::min(grid, pass_resident_blocks(ctx, kf, ks));
-  const bool mailbox = ctx->use_mailbox && !(across_ranks && ctx->transport == Transport::kRccl);
+  const bool peer = across_ranks && ctx->transport == Transport::kPeer;
+  const bool mailbox = (ctx->use_mailbox || peer) && !(across_ranks && ctx->transport == Transport::kRccl);
   sc::PassOut out;
   out.partials = ctx->d_partials;
   out.n_rows = (int)ctx->partial_rows;
@@ -491,6 +553,7 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   out.sums_dev = ctx->d_sums;
   out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
   out.seq = mailbox ? ctx->mailbox_seq + 1 : 0;
+  if (peer) fill_peer(ctx, &out, challenge_digest(r, kf, ks, log_in));
   SC_TRY(timer_begin(ctx, (ks == 3 && kf > 0) ? SC_KIND_TAIL_PASS : SC_KIND_PASS, kf, ks, log_in, (u64)16 << log_in,
                      kf > 0 ? (u64)16 << (log_in - kf) : 0));
   SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, fw, n_units, grid, log_in, out));
@@ -566,6 +629,37 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
   if (from_mailbox) {
     SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
     src = ctx->h_mailbox;
+    if (across_ranks && ctx->transport == Transport::kPeer) {
+      // the kernel exchanged the limbs with the peers itself; the mailbox holds the totals, or why not
+      const u64 err = __atomic_load_n(ctx->h_mailbox + sc::kMailboxErr, __ATOMIC_ACQUIRE);
+      if (err == (u64)sc::kXchgDigest)
+        return fail(ctx, SC_ERR_STATE, "the ranks of this sharded prover were given different challenges");
+      if (err != 0) {
+        poison(ctx);
+        return fail(ctx, SC_ERR_RCCL, "peer exchange: a rank's sums did not arrive within %d ms", ctx->peer_spin_ms);
+      }
+    }
+  } else if (across_ranks && ctx->transport == Transport::kPeer) {
+    // limbs left in d_sums by a small kernel: one wave exchanges them with the peers and publishes
+    sc::PassOut po;
+    po.partials = ctx->d_partials;
+    po.n_rows = (int)ctx->partial_rows;
+    po.ticket = ctx->d_ticket;
+    po.ticket_base = ctx->ticket_base;
+    po.sums_dev = ctx->d_sums;
+    po.mailbox = ctx->d_mailbox;
+    po.seq = ctx->mailbox_seq + 1;
+    fill_peer(ctx, &po, 0x5c5c5c5cu + (unsigned)ns);
+    const u64* limbs = ctx->d_sums;
+    switch (ns) {
+      case 1: hipLaunchKernelGGL((sc::peer_exchange_kernel<1>), dim3(1), dim3(sc::kWave), 0, ctx->stream, limbs, po); break;
+      case 3: hipLaunchKernelGGL((sc::peer_exchange_kernel<3>), dim3(1), dim3(sc::kWave), 0, ctx->stream, limbs, po); break;
+      case 9: hipLaunchKernelGGL((sc::peer_exchange_kernel<9>), dim3(1), dim3(sc::kWave), 0, ctx->stream, limbs, po); break;
+      default: hipLaunchKernelGGL((sc::peer_exchange_kernel<27>), dim3(1), dim3(sc::kWave), 0, ctx->stream, limbs, po); break;
+    }
+    SC_HIP(ctx, hipGetLastError());
+    ctx->mailbox_seq += 1;
+    return collect_sums(ctx, ns, true, true, out);
   } else {
     if (across_ranks && ctx->transport == Transport::kRccl) {
       ncclResult_t r = g_rccl.AllReduce(ctx->d_sums, ctx->d_sums, count, ncclUint64, ncclSum, ctx->comm,
@@ -602,6 +696,41 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
   return SC_OK;
 }
 
+// Peer transport: all-gather `len` words per rank of two device buffers (b may be null) into this rank's
+// arena; *fa / *fb point into the arena (world * len contiguous words each, rank order).  Two arenas are
+// used alternately (by the tag's parity), so a gathered table stays valid until the gather after next.
+int peer_gather(sc_ctx* ctx, const u64* a, const u64* b, size_t len, const u64** fa, const u64** fb) {
+  const size_t cap = (size_t)ctx->world << ctx->arena_log;   // words per table
+  if (len * ctx->world > cap)
+    return fail(ctx, SC_ERR_UNSUPPORTED, "peer gather of %zu words per rank exceeds the arena (arena_log = %d)", len, ctx->arena_log);
+  sc::PassOut out;
+  out.partials = ctx->d_partials;
+  out.n_rows = (int)ctx->partial_rows;
+  out.ticket = ctx->d_ticket;
+  out.ticket_base = ctx->ticket_base;
+  out.sums_dev = ctx->d_sums;
+  out.mailbox = ctx->d_mailbox;
+  out.seq = ctx->mailbox_seq + 1;
+  fill_peer(ctx, &out, 0);
+  const size_t arena_off = kInboxRegionWords + (size_t)(out.px.tag & 1u) * 2 * cap;
+  sc::PeerG pg;
+  for (int q = 0; q < ctx->world; ++q) pg.arena[q] = ctx->peer_base[q] + arena_off;
+  pg.table_stride = cap;
+  int grid = (int)std::min<size_t>(std::max<size_t>((len / 2 + sc::kBlock - 1) / sc::kBlock, 1), 256);
+  hipLaunchKernelGGL(sc::peer_gather_kernel, dim3(grid), dim3(sc::kBlock), 0, ctx->stream, a, b ? b : a, len, pg, out);
+  SC_HIP(ctx, hipGetLastError());
+  ctx->mailbox_seq += 1;
+  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
+  if (__atomic_load_n(ctx->h_mailbox + sc::kMailboxErr, __ATOMIC_ACQUIRE) != 0) {
+    poison(ctx);
+    return fail(ctx, SC_ERR_RCCL, "peer gather: a rank's tables did not arrive within %d ms", ctx->peer_spin_ms);
+  }
+  *fa = ctx->peer_base[ctx->rank] + arena_off;
+  if (fb) *fb = *fa + cap;
+  return SC_OK;
+}
+
 // All-gather `len` words per rank of a device buffer into a new pool buffer of len*world.
 int gather_table(sc_ctx* ctx, const u64* local, size_t len, u64** out_full) {
   u64* full = nullptr;
@@ -629,6 +758,15 @@ int gather_table(sc_ctx* ctx, const u64* local, size_t len, u64** out_full) {
 
 // Sum `count` u64 words of a device buffer across ranks, in place (values are 32-bit limbs).
 int allreduce_device(sc_ctx* ctx, u64* buf, size_t count) {
+  if (ctx->transport == Transport::kPeer) {
+    // gather every rank's vector into the arena, then sum the rows locally (plain u64 adds of limbs)
+    const u64* all = nullptr;
+    SC_TRY(peer_gather(ctx, buf, nullptr, count, &all, nullptr));
+    hipLaunchKernelGGL(sc::sum_limb_rows_kernel, dim3(grid_for(ctx, count)), dim3(sc::kBlock), 0, ctx->stream, all, ctx->world,
+                       count, buf);
+    SC_HIP(ctx, hipGetLastError());
+    return SC_OK;
+  }
   if (ctx->transport == Transport::kRccl) {
     ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclUint64, ncclSum, ctx->comm, ctx->stream);
     if (r != ncclSuccess)
@@ -943,6 +1081,11 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
   SC_CREATE_HIP(hipHostMalloc(&ctx->h_mailbox, 64 * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->h_mailbox, 0, 64 * sizeof(u64));
   SC_CREATE_HIP(hipHostGetDevicePointer((void**)&ctx->d_mailbox, ctx->h_mailbox, 0));
+  SC_CREATE_HIP(hipHostMalloc(&ctx->h_cmd, 64 * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(ctx->h_cmd, 0, 64 * sizeof(u64));
+  SC_CREATE_HIP(hipHostGetDevicePointer((void**)&ctx->d_cmd_host, ctx->h_cmd, 0));
+  SC_CREATE_HIP(hipMalloc(&ctx->d_cmd, (64 + 128) * sizeof(u64)));   // command line + diagnostic stamps
+  SC_CREATE_HIP(hipMemset(ctx->d_cmd, 0, (64 + 128) * sizeof(u64)));
   SC_CREATE_HIP(hipDeviceSynchronize());
   for (int i = 0; i < sc_ctx::kTimerRing; ++i) {
     SC_CREATE_HIP(hipEventCreate(&ctx->kt_ev[i][0]));
@@ -956,14 +1099,20 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
 extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
   if (!ctx) return SC_OK;
   (void)hipSetDevice(ctx->device);
+  if (ctx->live_resident) resident_retire(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
+  for (int q = 0; q < sc::kMaxPeers; ++q)
+    if (ctx->peer_ipc_opened[q] && ctx->peer_base[q]) (void)hipIpcCloseMemHandle(ctx->peer_base[q]);
+  if (ctx->peer_region) (void)hipFree(ctx->peer_region);
   for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
   for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
   if (ctx->h_sums) (void)hipHostFree(ctx->h_sums);
   if (ctx->h_mailbox) (void)hipHostFree(ctx->h_mailbox);
+  if (ctx->h_cmd) (void)hipHostFree(ctx->h_cmd);
+  if (ctx->d_cmd) (void)hipFree(ctx->d_cmd);
   if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
   for (int i = 0; i < sc_ctx::kTimerRing; ++i)
     for (int k = 0; k < 2; ++k)
@@ -1002,6 +1151,23 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
     ctx->time_kernels = value ? 1 : 0;  // recorded pairs stay in the ring until it fills or the totals are read
   } else if (k == "use_mailbox") {
     ctx->use_mailbox = value ? 1 : 0;
+  } else if (k == "arena_log") {
+    if (value < 4 || value > 26) return fail(ctx, SC_ERR_ARG, "arena_log must be in [4, 26]");
+    if (ctx->peer_region) return fail(ctx, SC_ERR_STATE, "arena_log must be set before sc_ctx_comm_peer_export");
+    ctx->arena_log = (int)value;
+  } else if (k == "peer_spin_ms") {
+    if (value < 1 || value > 600000) return fail(ctx, SC_ERR_ARG, "peer_spin_ms out of range");
+    ctx->peer_spin_ms = (int)value;
+  } else if (k == "resident") {
+    ctx->resident = value ? 1 : 0;
+  } else if (k == "resident_stamps") {
+    ctx->resident_stamps = value ? 1 : 0;
+  } else if (k == "resident_log") {
+    if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "resident_log out of range");
+    ctx->resident_log = (int)value;
+  } else if (k == "park_ms") {
+    if (value < 1 || value > 10000) return fail(ctx, SC_ERR_ARG, "park_ms must be in [1, 10000]");
+    ctx->park_ms = (int)value;
   } else if (k == "nt_load_log") {
     ctx->nt_load_log = (int)value;
   } else if (k == "nt_store_log") {
@@ -1023,8 +1189,24 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   else if (k == "max_blocks") *value = ctx->max_blocks;
   else if (k == "time_kernels") *value = ctx->time_kernels;
   else if (k == "use_mailbox") *value = ctx->use_mailbox;
+  else if (k == "arena_log") *value = ctx->arena_log;
+  else if (k == "peer_spin_ms") *value = ctx->peer_spin_ms;
+  else if (k == "resident") *value = ctx->resident;
+  else if (k == "resident_log") *value = ctx->resident_log;
+  else if (k == "resident_stamps") *value = ctx->resident_stamps;
+  else if (k == "resident_host_ns") *value = (int64_t)ctx->dbg_host_ns;
+  else if (k == "park_ms") *value = ctx->park_ms;
   else if (k == "nt_load_log") *value = ctx->nt_load_log;
   else if (k == "nt_store_log") *value = ctx->nt_store_log;
+  else if (k.rfind("resident_stamp_", 0) == 0) {
+    // diagnostic: stamp i of the last resident launch (after it has left the stream)
+    const int i = atoi(k.c_str() + 15);
+    if (i < 0 || i >= 128) return fail(ctx, SC_ERR_ARG, "stamp index out of range");
+    u64 v = 0;
+    if (hipMemcpy(&v, ctx->d_cmd + 64 + i, sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess)
+      return fail(ctx, SC_ERR_HIP, "reading a stamp failed");
+    *value = (int64_t)v;
+  }
   else return fail(ctx, SC_ERR_ARG, "unknown option '%s'", key);
   return SC_OK;
 }
@@ -1116,6 +1298,78 @@ extern "C" int sc_ctx_comm_init_host(sc_ctx* ctx, int rank, int world, sc_allred
   ctx->host_user = user;
   ctx->transport = Transport::kHost;
   return SC_OK;
+}
+
+extern "C" int sc_ctx_comm_peer_export(sc_ctx* ctx, int rank, int world, uint8_t handle[64]) {
+  if (!ctx || !handle) return SC_ERR_ARG;
+  SC_TRY(set_device(ctx));
+  if (world > sc::kMaxPeers) return fail(ctx, SC_ERR_ARG, "the peer transport serves up to %d ranks (one node)", sc::kMaxPeers);
+  SC_TRY(set_world(ctx, rank, world));
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
+  const size_t words = kInboxRegionWords + 2 * 2 * ((size_t)world << ctx->arena_log);   // inbox + two arenas of two tables
+  // fine-grained device memory: written by the peers over xGMI while kernels of this rank poll it
+  hipError_t e = hipExtMallocWithFlags((void**)&ctx->peer_region, words * sizeof(u64), hipDeviceMallocFinegrained);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    e = hipMalloc((void**)&ctx->peer_region, words * sizeof(u64));
+  }
+  if (e != hipSuccess) {
+    ctx->world = 1; ctx->rank = 0; ctx->log_world = 0;
+    return fail(ctx, SC_ERR_OOM, "peer region of %zu bytes: %s", words * sizeof(u64), hipGetErrorString(e));
+  }
+  ctx->peer_region_words = words;
+  e = hipMemset(ctx->peer_region, 0, kInboxRegionWords * sizeof(u64));
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  hipIpcMemHandle_t h;
+  if (e == hipSuccess) e = hipIpcGetMemHandle(&h, ctx->peer_region);
+  if (e != hipSuccess) {
+    (void)hipFree(ctx->peer_region);
+    ctx->peer_region = nullptr;
+    ctx->world = 1; ctx->rank = 0; ctx->log_world = 0;
+    return fail(ctx, SC_ERR_HIP, "exporting the peer region: %s", hipGetErrorString(e));
+  }
+  memcpy(handle, &h, 64);
+  ctx->peer_exported = true;
+  return SC_OK;
+}
+
+static int peer_finish_connect(sc_ctx* ctx) {
+  ctx->transport = Transport::kPeer;
+  return SC_OK;
+}
+
+extern "C" int sc_ctx_comm_peer_connect(sc_ctx* ctx, const uint8_t* handles) {
+  if (!ctx || !handles) return SC_ERR_ARG;
+  if (!ctx->peer_exported || ctx->transport != Transport::kNone)
+    return fail(ctx, SC_ERR_STATE, "sc_ctx_comm_peer_connect: call sc_ctx_comm_peer_export first (once)");
+  SC_TRY(set_device(ctx));
+  for (int q = 0; q < ctx->world; ++q) {
+    if (q == ctx->rank) {
+      ctx->peer_base[q] = ctx->peer_region;
+      continue;
+    }
+    hipIpcMemHandle_t h;
+    memcpy(&h, handles + 64 * (size_t)q, 64);
+    void* p = nullptr;
+    hipError_t e = hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess);
+    if (e != hipSuccess) return fail(ctx, SC_ERR_HIP, "mapping rank %d's peer region: %s", q, hipGetErrorString(e));
+    ctx->peer_base[q] = (u64*)p;
+    ctx->peer_ipc_opened[q] = true;
+  }
+  return peer_finish_connect(ctx);
+}
+
+extern "C" int sc_ctx_comm_peer_connect_local(sc_ctx* ctx, sc_ctx* const* peers) {
+  if (!ctx || !peers) return SC_ERR_ARG;
+  if (!ctx->peer_exported || ctx->transport != Transport::kNone)
+    return fail(ctx, SC_ERR_STATE, "sc_ctx_comm_peer_connect_local: call sc_ctx_comm_peer_export first (once)");
+  for (int q = 0; q < ctx->world; ++q) {
+    const sc_ctx* pq = (q == ctx->rank) ? ctx : peers[q];
+    if (!pq || !pq->peer_region || pq->world != ctx->world || pq->rank != q || pq->arena_log != ctx->arena_log)
+      return fail(ctx, SC_ERR_ARG, "peer %d is not an exported context of the same world", q);
+    ctx->peer_base[q] = pq->peer_region;
+  }
+  return peer_finish_connect(ctx);
 }
 
 extern "C" int sc_ctx_comm_rank(const sc_ctx* ctx, int* rank, int* world) {
@@ -1252,7 +1506,8 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
   const size_t n_chunks = ((size_t)1 << (nv - 7)) >> chunk_log;
   int grid = (int)std::min<size_t>((n_chunks + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
   if (grid < 1) grid = 1;
-  const bool mailbox = ctx->use_mailbox && !(across && ctx->transport == Transport::kRccl);
+  const bool peer = across && ctx->transport == Transport::kPeer;
+  const bool mailbox = (ctx->use_mailbox || peer) && !(across && ctx->transport == Transport::kRccl);
   sc::PassOut out;
   out.partials = ctx->d_partials;
   out.n_rows = (int)ctx->partial_rows;
@@ -1261,6 +1516,7 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
   out.sums_dev = ctx->d_sums;
   out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
   out.seq = mailbox ? ctx->mailbox_seq + 1 : 0;
+  if (peer) fill_peer(ctx, &out, challenge_digest(pt_le, std::min(nv, 3), 0, nv));
   const int nt = nv >= ctx->nt_load_log ? 1 : 0;
   SC_TRY(timer_begin(ctx, SC_KIND_EVALUATE, nv, 0, nv, (u64)8 << nv, 0));
   if (nt)
@@ -1558,6 +1814,16 @@ struct sc_prover {
   size_t cache_round = 0;
   u64 S[27];
   u64 c1 = 0;
+  // resident kernel serving this prover's remaining passes (kernels.hpp, resident_kernel)
+  struct {
+    bool live = false;
+    sc::ResidentPlan plan;
+    int next_phase = 0;         // first phase whose sums the host has not consumed yet
+    u64 seq0 = 0;               // mailbox sequence of phase 0
+    u64 cmd_base = 0;
+    unsigned ticket0 = 0;       // ticket base of phase 0
+    u64 *PA = nullptr, *PB = nullptr, *QA = nullptr, *QB = nullptr;
+  } res;
 };
 
 namespace {
@@ -1566,24 +1832,342 @@ namespace {
 // 22 0.204 / 0.198, 24 0.307 / 0.294, 26 0.75 / 0.68, 28 2.36 / 2.13
 constexpr int kFirstPass3Log = 18;
 
-int prover_pass(sc_prover* pr, size_t j) {
-  sc_ctx* ctx = pr->ctx;
-  const int kf = (int)pr->pending.size();
-  const size_t remaining = pr->num_vars - j;  // variables left including round j's
+// rounds a pass at round j serves (the schedule of DESIGN.md section 4), given the table size and what is pending
+int pass_rounds(const sc_ctx* ctx, size_t num_vars, size_t j, int kf, int cur_log) {
+  const size_t remaining = num_vars - j;  // variables left including round j's
   int ks = (ctx->vars_per_pass == 2 && remaining >= 2) ? 2 : 1;
   if (j == 0 && kf == 0) {
-    const int first = ctx->first_pass_vars ? ctx->first_pass_vars : (pr->cur_log >= kFirstPass3Log ? 3 : 2);
+    const int first = ctx->first_pass_vars ? ctx->first_pass_vars : (cur_log >= kFirstPass3Log ? 3 : 2);
     if (ctx->vars_per_pass == 2 && remaining >= 3 && first == 3) ks = 3;
     if (first < ks) ks = first;
   }
   // tail: once the input is small every pass is latency-bound, so serve three rounds with each
-  if (kf > 0 && ctx->vars_per_pass == 2 && ctx->tail_pass_vars == 3 && remaining >= 3 && pr->cur_log <= ctx->tail_pass_log)
+  if (kf > 0 && ctx->vars_per_pass == 2 && ctx->tail_pass_vars == 3 && remaining >= 3 && cur_log <= ctx->tail_pass_log)
     ks = 3;
+  return ks;
+}
+
+int resident_capacity(sc_ctx* ctx) {
+  if (ctx->resident_blocks_cap == 0) {
+    int per_cu = 0;
+    const void* fn = ctx->gold ? reinterpret_cast<const void*>(&sc::resident_kernel<sc::GoldilocksMont>)
+                               : reinterpret_cast<const void*>(&sc::resident_kernel<sc::MontGeneric>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, sc::kBlock, 0) != hipSuccess) {
+      (void)hipGetLastError();
+      per_cu = 0;
+    }
+    // the kernel needs every block of its grid on the chip at once; the occupancy query can over-report by
+    // one block per CU for SGPR-heavy kernels (MI355X_MICROARCH.md, residency), so never ask for more than
+    // two per CU and only when the query grants at least that
+    ctx->resident_blocks_cap = per_cu >= 2 ? 2 * ctx->num_cus : (per_cu == 1 ? 0 : -1);
+    if (ctx->resident_blocks_cap <= 0) ctx->resident_blocks_cap = -1;
+  }
+  return ctx->resident_blocks_cap;
+}
+
+// The resident kernel has left the stream, or is leaving it with nothing more to read (all phases done):
+// settle the context's counters from what the DEVICE executed, and the prover's buffers from what the
+// HOST consumed.  `executed` < 0: read it off the mailbox (only valid once the stream is idle).
+void resident_settle(sc_prover* pr, int executed) {
+  sc_ctx* ctx = pr->ctx;
+  const int n = pr->res.plan.n_phases;
+  if (executed < 0) {
+    const u64 last = __atomic_load_n(ctx->h_mailbox + sc::kMailboxSeq, __ATOMIC_ACQUIRE);
+    executed = (last >= pr->res.seq0 && last < pr->res.seq0 + (u64)n) ? (int)(last - pr->res.seq0) + 1 : 0;
+    if (executed < pr->res.next_phase) executed = pr->res.next_phase;
+  }
+  unsigned used = 0;
+  for (int q = 0; q < executed; ++q)
+    if (pr->res.plan.blocks[q] > 1) used += (unsigned)pr->res.plan.blocks[q];
+  ctx->ticket_base = pr->res.ticket0 + used;
+  ctx->mailbox_seq = pr->res.seq0 + (u64)executed - 1;
+  // tables: the outputs of the last phase the host consumed are the prover's current tables
+  if (pr->res.next_phase > 0) {
+    const int lp = pr->res.next_phase - 1;
+    u64* ca = (lp & 1) ? pr->res.QA : pr->res.PA;
+    u64* cb = (lp & 1) ? pr->res.QB : pr->res.PB;
+    if (pr->own_a != ca) pool_release(ctx, pr->own_a);
+    if (pr->own_b != cb) pool_release(ctx, pr->own_b);
+    pr->own_a = ca;
+    pr->own_b = cb;
+  }
+  u64** bufs[4] = {&pr->res.PA, &pr->res.PB, &pr->res.QA, &pr->res.QB};
+  for (u64** bp : bufs) {
+    if (*bp && *bp != pr->own_a && *bp != pr->own_b) pool_release(ctx, *bp);
+    *bp = nullptr;
+  }
+  pr->res.live = false;
+  if (ctx->live_resident == pr) ctx->live_resident = nullptr;
+}
+
+// End a live resident kernel early (another call needs the stream, or the prover is destroyed): the
+// abort command parks it before its next phase; the prover continues with ordinary launches.
+void resident_retire(sc_ctx* ctx) {
+  sc_prover* pr = ctx->live_resident;
+  if (!pr || !pr->res.live) {
+    ctx->live_resident = nullptr;
+    return;
+  }
+  // the kernel may be in any phase >= next_phase - 1; an abort word for EVERY later phase would be needed to
+  // stop it at once, so write the one it will look for next and let the park timeout cover the rest
+  for (int q = std::max(pr->res.next_phase, 1); q < pr->res.plan.n_phases; ++q) {
+    __atomic_store_n(ctx->h_cmd, sc::kCmdPark | (u64)q, __ATOMIC_RELEASE);   // block 0 acts on word 0 alone
+    if (hipStreamQuery(ctx->stream) == hipSuccess) break;
+    // give the kernel a moment to see it before trying the next phase's abort word
+    auto t0 = std::chrono::steady_clock::now();
+    while (hipStreamQuery(ctx->stream) == hipErrorNotReady &&
+           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 200e-6) {
+      __builtin_ia32_pause();
+    }
+    if (hipStreamQuery(ctx->stream) == hipSuccess) break;
+  }
+  (void)hipStreamSynchronize(ctx->stream);
+  resident_settle(pr, -1);
+}
+
+// consume phase p's sums from the mailbox; returns 1 if the kernel parked before phase p instead
+int resident_collect(sc_prover* pr, int p, int* parked) {
+  sc_ctx* ctx = pr->ctx;
+  const u64 seq = pr->res.seq0 + (u64)p;
+  const u64* flag = ctx->h_mailbox + sc::kMailboxSeq;
+  const u64* park = ctx->h_mailbox + sc::kMailboxParked;
+  unsigned spins = 0;
+  auto t0 = std::chrono::steady_clock::now();
+  *parked = 0;
+  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
+    if (__atomic_load_n(park, __ATOMIC_ACQUIRE) == (u64)p + 1) {
+      *parked = 1;
+      return SC_OK;
+    }
+    if ((++spins & 0x3FFF) == 0) {
+      hipError_t q = hipStreamQuery(ctx->stream);
+      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if ((q != hipSuccess && q != hipErrorNotReady) || (q == hipSuccess && el > 2.0) || el > 120.0) {
+        // a finished stream with neither word set can still be a park whose store we raced with
+        if (__atomic_load_n(park, __ATOMIC_ACQUIRE) == (u64)p + 1) {
+          *parked = 1;
+          return SC_OK;
+        }
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        poison(ctx);
+        return fail(ctx, SC_ERR_HIP, "resident kernel: phase %d never reported (%s)", p,
+                    q == hipSuccess || q == hipErrorNotReady ? "timed out" : hipGetErrorString(q));
+      }
+    }
+    __builtin_ia32_pause();
+  }
+  const int ks = pr->res.plan.ks[p];
+  const int ns = ks == 1 ? 3 : ks == 2 ? 9 : 27;
+  HostField hf(ctx->fp);
+  for (int s = 0; s < ns; ++s) pr->S[s] = hf.recombine(ctx->h_mailbox[2 * s], ctx->h_mailbox[2 * s + 1]);
+  return SC_OK;
+}
+
+// bookkeeping after phase p's sums arrived: the tables are the phase's outputs now
+void resident_advance(sc_prover* pr, int p, size_t j) {
+  u64* oa = (p & 1) ? pr->res.QA : pr->res.PA;
+  u64* ob = (p & 1) ? pr->res.QB : pr->res.PB;
+  // the previous current tables stay allocated while the kernel may still read them: own_* of the launch
+  // (phase 0's inputs) are released when the kernel has left the stream
+  pr->cur_a = oa;
+  pr->cur_b = ob;
+  pr->cur_log -= pr->res.plan.kf[p];
+  pr->pending.clear();
+  pr->cache_ks = pr->res.plan.ks[p];
+  pr->cache_round = j;
+  pr->res.next_phase = p + 1;
+}
+
+// Try to hand the rest of the proof to the resident kernel.  *started = false: not applicable here.
+int resident_start(sc_prover* pr, size_t j, bool* started) {
+  sc_ctx* ctx = pr->ctx;
+  *started = false;
+  const int kf0 = (int)pr->pending.size();
+  if (!ctx->resident || !ctx->use_mailbox || ctx->vars_per_pass != 2 || pr->sharded || kf0 < 1 || kf0 > 3 ||
+      pr->cur_log > ctx->resident_log || ctx->live_resident)
+    return SC_OK;
+  const int cap = resident_capacity(ctx);
+  if (cap < 1) return SC_OK;
+  sc::ResidentPlan plan;
+  memset(&plan, 0, sizeof(plan));
+  int cur_log = pr->cur_log, kf = kf0, n = 0;
+  size_t jj = j;
+  const int grid_cap = std::min(cap, (int)ctx->partial_rows);
+  while (jj < pr->num_vars) {
+    if (n == sc::kMaxResidentPhases) return SC_OK;
+    const int ks = pass_rounds(ctx, pr->num_vars, jj, kf, cur_log);
+    if (cur_log < kf + ks) return SC_OK;
+    plan.kf[n] = kf;
+    plan.ks[n] = ks;
+    plan.log_in[n] = cur_log;
+    const size_t n_out = (size_t)1 << (cur_log - kf);
+    // streaming body: the (2,2) pass on tables too large for one thread per output to keep up
+    plan.big[n] = (kf == 2 && ks == 2 && cur_log > ctx->tail_pass_log) ? 1 : 0;
+    const size_t want = plan.big[n] ? ((n_out / 4 + sc::kWave - 1) / sc::kWave + 3) / 4 : (n_out + sc::kBlock - 1) / sc::kBlock;
+    int blocks = (int)std::min<size_t>(std::max<size_t>(want, 1), (size_t)grid_cap);
+    if (n > 0) blocks = std::min(blocks, plan.blocks[n - 1]);
+    plan.blocks[n] = blocks;
+    cur_log -= kf;
+    kf = ks;
+    jj += ks;
+    ++n;
+  }
+  if (n < 2) return SC_OK;   // a single pass left: nothing to save
+  plan.n_phases = n;
+
+  u64 *PA = nullptr, *PB = nullptr, *QA = nullptr, *QB = nullptr;
+  const size_t lenP = (size_t)1 << (plan.log_in[0] - plan.kf[0]);
+  const size_t lenQ = (size_t)1 << (plan.log_in[1] - plan.kf[1]);
+  int rc = pool_alloc(ctx, lenP, &PA);
+  if (rc == SC_OK) rc = pool_alloc(ctx, lenP, &PB);
+  if (rc == SC_OK) rc = pool_alloc(ctx, lenQ, &QA);
+  if (rc == SC_OK) rc = pool_alloc(ctx, lenQ, &QB);
+  if (rc != SC_OK) {
+    pool_release(ctx, PA);
+    pool_release(ctx, PB);
+    pool_release(ctx, QA);
+    pool_release(ctx, QB);
+    return rc;
+  }
+  const sc::FoldW fw0 = make_fold_weights(ctx, pr->pending.data(), kf0);
+  sc::PassOut out;
+  out.partials = ctx->d_partials;
+  out.n_rows = (int)ctx->partial_rows;
+  out.ticket = ctx->d_ticket;
+  out.ticket_base = ctx->ticket_base;
+  out.sums_dev = ctx->d_sums;
+  out.mailbox = ctx->d_mailbox;
+  out.seq = ctx->mailbox_seq + 1;
+  sc::ResidentCtl ctl;
+  ctl.host_cmd = ctx->d_cmd_host;
+  ctl.dev_cmd = ctx->d_cmd;
+  ctl.cmd_base = ctx->cmd_seq;
+  ctl.park_ticks = (u64)ctx->park_ms * 100000ull;   // wall_clock64 runs at 100 MHz
+  ctl.stamps = ctx->resident_stamps ? ctx->d_cmd + 64 : nullptr;
+  __atomic_store_n(ctx->h_mailbox + sc::kMailboxParked, (u64)0, __ATOMIC_RELEASE);
+  u64 bytes_r = 0, bytes_w = 0;
+  int rounds = 0;
+  for (int q = 0; q < n; ++q) {
+    bytes_r += (u64)16 << plan.log_in[q];
+    bytes_w += (u64)16 << (plan.log_in[q] - plan.kf[q]);
+    rounds += plan.ks[q];
+  }
+  rc = timer_begin(ctx, SC_KIND_TAIL_RESIDENT, n, rounds, plan.log_in[0], bytes_r, bytes_w);
+  if (rc == SC_OK) {
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::resident_kernel<F>), dim3(plan.blocks[0]), dim3(sc::kBlock), 0,
+                                                    ctx->stream, f, pr->cur_a, pr->cur_b, PA, PB, QA, QB, fw0, plan, out, ctl));
+    hipError_t le = hipGetLastError();
+    if (le != hipSuccess) {
+      poison(ctx);
+      rc = fail(ctx, SC_ERR_HIP, "resident kernel launch: %s", hipGetErrorString(le));
+    }
+  }
+  if (rc == SC_OK) rc = timer_end(ctx);
+  if (rc != SC_OK) {
+    pool_release(ctx, PA);
+    pool_release(ctx, PB);
+    pool_release(ctx, QA);
+    pool_release(ctx, QB);
+    return rc;
+  }
+  pr->res.live = true;
+  pr->res.plan = plan;
+  pr->res.next_phase = 0;
+  pr->res.seq0 = out.seq;
+  pr->res.cmd_base = ctl.cmd_base;
+  pr->res.ticket0 = ctx->ticket_base;
+  pr->res.PA = PA;
+  pr->res.PB = PB;
+  pr->res.QA = QA;
+  pr->res.QB = QB;
+  ctx->cmd_seq += (u64)n;
+  ctx->live_resident = pr;
+  // until the kernel has left the stream the context's counters are the kernel's: park them past its range
+  unsigned total = 0;
+  for (int q = 0; q < n; ++q)
+    if (plan.blocks[q] > 1) total += (unsigned)plan.blocks[q];
+  ctx->ticket_base += total;
+  ctx->mailbox_seq += (u64)n;
+  *started = true;
+  return SC_OK;
+}
+
+// next phase of a live resident kernel (p >= 1): send the pending challenges, collect the sums.
+// *served = false: the kernel parked; the caller continues with an ordinary pass.
+int resident_next(sc_prover* pr, size_t j, bool* served) {
+  sc_ctx* ctx = pr->ctx;
+  *served = false;
+  const int p = pr->res.next_phase;
+  if (p >= pr->res.plan.n_phases || (int)pr->pending.size() != pr->res.plan.kf[p] ||
+      pass_rounds(ctx, pr->num_vars, j, pr->res.plan.kf[p], pr->cur_log) != pr->res.plan.ks[p]) {
+    // the caller left the planned schedule (an option changed mid-proof): fall back
+    resident_retire(ctx);
+    return SC_OK;
+  }
+  if (p > 0) {
+    // one 64-byte line: challenges and check word first, the sequence word last (release)
+    const u64 seq = pr->res.cmd_base + (u64)p;
+    u64 chk = seq;
+    for (size_t i = 0; i < 3; ++i) {
+      const u64 r = i < pr->pending.size() ? pr->pending[i] : 0;
+      ctx->h_cmd[1 + i] = r;
+      chk ^= r;
+    }
+    ctx->h_cmd[4] = chk;
+    __atomic_store_n(ctx->h_cmd, seq, __ATOMIC_RELEASE);
+    if (ctx->resident_stamps) ctx->dbg_host_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ctx->dbg_t_collect).count();
+  }
+  int parked = 0;
+  SC_TRY(resident_collect(pr, p, &parked));
+  if (parked) {
+    (void)hipStreamSynchronize(ctx->stream);
+    resident_settle(pr, -1);
+    return SC_OK;
+  }
+  resident_advance(pr, p, j);
+  if (ctx->resident_stamps) ctx->dbg_t_collect = std::chrono::steady_clock::now();
+  // last phase: the kernel has nothing left to read and is leaving the stream by itself
+  if (pr->res.next_phase == pr->res.plan.n_phases) resident_settle(pr, pr->res.plan.n_phases);
+  *served = true;
+  return SC_OK;
+}
+
+int prover_pass(sc_prover* pr, size_t j) {
+  sc_ctx* ctx = pr->ctx;
+  if (pr->res.live) {
+    bool served = false;
+    SC_TRY(resident_next(pr, j, &served));
+    if (served) return SC_OK;
+  } else {
+    bool started = false;
+    SC_TRY(resident_start(pr, j, &started));
+    if (started) {
+      bool served = false;
+      SC_TRY(resident_next(pr, j, &served));
+      if (served) return SC_OK;
+    }
+  }
+  const int kf = (int)pr->pending.size();
+  const int ks = pass_rounds(ctx, pr->num_vars, j, kf, pr->cur_log);
   if (kf > 3) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges", kf);
 
   // Sharded: pairs (2b, 2b+1) stay shard-local while the local table still has the kf+ks
   // variables this pass touches; below tail_log the latency of a collective per pass costs
   // more than finishing redundantly on every rank, so gather once and go on unsharded.
+  const int gather_log = ctx->transport == Transport::kPeer ? std::min(ctx->tail_log, ctx->arena_log) : ctx->tail_log;
+  if (pr->sharded && ctx->transport == Transport::kPeer && (pr->cur_log < kf + ks || pr->cur_log <= gather_log)) {
+    // the peers write their shards straight into this rank's arena; the gathered tables live there
+    const u64 *fa = nullptr, *fb = nullptr;
+    SC_TRY(peer_gather(ctx, pr->cur_a, pr->cur_b, (size_t)1 << pr->cur_log, &fa, &fb));
+    pool_release(ctx, pr->own_a);
+    pool_release(ctx, pr->own_b);
+    pr->own_a = nullptr;
+    pr->own_b = nullptr;
+    pr->cur_a = fa;
+    pr->cur_b = fb;
+    pr->cur_log += ctx->log_world;
+    pr->sharded = false;
+  }
   if (pr->sharded && (pr->cur_log < kf + ks || pr->cur_log <= ctx->tail_log)) {
     u64 *fa = nullptr, *fb = nullptr;
     size_t len = (size_t)1 << pr->cur_log;
@@ -1678,6 +2262,17 @@ void prover_answer(const sc_prover* pr, size_t j, u64 e[3]) {
   e[2] = eval2_from_inf(hf, h[0], h[1], h[2]);
 }
 
+// marks a call as coming from the prover that owns the context's live resident kernel (set_device()
+// retires the kernel for every other caller); nests
+struct ResidentOwner {
+  sc_ctx* ctx;
+  bool prev;
+  ResidentOwner(sc_ctx* c, const sc_prover* pr) : ctx(c), prev(c->in_resident_owner) {
+    c->in_resident_owner = prev || (c->live_resident != nullptr && c->live_resident == pr);
+  }
+  ~ResidentOwner() { ctx->in_resident_owner = prev; }
+};
+
 bool cache_covers(const sc_prover* pr, size_t j) {
   if (pr->cache_ks == 0 || j < pr->cache_round) return false;
   const size_t known = j - pr->cache_round;
@@ -1741,6 +2336,7 @@ extern "C" int sc_prover_round(sc_prover* pr, uint64_t r_prev, size_t j, uint64_
     return fail(ctx, SC_ERR_STATE, "sc_prover_round: expected round %zu, got %zu", pr->next_round, j);
   if (j >= pr->num_vars) return fail(ctx, SC_ERR_STATE, "sc_prover_round: all %zu rounds done", pr->num_vars);
   if (r_prev >= ctx->fp.p && j != 0) return fail(ctx, SC_ERR_ARG, "sc_prover_round: challenge is not reduced");
+  ResidentOwner own(ctx, pr);   // this call may talk to the prover's own resident kernel
   SC_TRY(set_device(ctx));
   if (j != 0) pr->pending.push_back(r_prev);  // sum-check-protocol/src/lib.rs:106-109
   if (!cache_covers(pr, j)) {
@@ -1757,6 +2353,10 @@ extern "C" int sc_prover_round(sc_prover* pr, uint64_t r_prev, size_t j, uint64_
 
 extern "C" int sc_prover_destroy(sc_prover* pr) {
   if (!pr) return SC_OK;
+  if (pr->res.live && pr->ctx->live_resident == pr) {
+    (void)hipSetDevice(pr->ctx->device);
+    resident_retire(pr->ctx);
+  }
   pool_release(pr->ctx, pr->own_a);
   pool_release(pr->ctx, pr->own_b);
   delete pr;
@@ -2320,6 +2920,7 @@ namespace {
 // Fold the challenges the sub-prover has not applied yet plus `r_last`; hand back its tables.
 int prover_finish(sc_prover* pr, u64 r_last, u64** a_out, u64** b_out, size_t* len_out) {
   sc_ctx* ctx = pr->ctx;
+  if (pr->res.live) resident_retire(ctx);   // the tables must be at rest
   std::vector<u64> rs(pr->pending);   // the sub-prover's own state is left untouched
   rs.push_back(r_last);
   const size_t len = (size_t)1 << pr->cur_log;
@@ -2391,6 +2992,7 @@ extern "C" int sc_tri_prover_round(sc_tri_prover* tp, uint64_t r_prev, size_t j,
   if (j != tp->next_round) return fail(ctx, SC_ERR_STATE, "sc_tri_prover_round: expected round %zu, got %zu", tp->next_round, j);
   if (j >= 3 * k) return fail(ctx, SC_ERR_STATE, "sc_tri_prover_round: all %zu rounds done", 3 * k);
   if (j != 0 && r_prev >= ctx->fp.p) return fail(ctx, SC_ERR_ARG, "sc_tri_prover_round: challenge is not reduced");
+  ResidentOwner own(ctx, tp->sub);
   SC_TRY(set_device(ctx));
   if (j != 0) tp->r.push_back(r_prev);
   // a failed round leaves the challenge list as it was, so the round can be retried

@@ -108,6 +108,23 @@ class Context:
         self._keep += [ar, ag]
         self.check(self.lib.sc_ctx_comm_init_host(self.h, rank, world, ar, ag, None))
 
+    def comm_peer_export(self, rank, world):
+        """allocate this rank's peer region; returns its 64-byte HIP IPC handle"""
+        buf = (ctypes.c_uint8 * 64)()
+        self.check(self.lib.sc_ctx_comm_peer_export(self.h, rank, world, buf))
+        return bytes(buf)
+
+    def comm_peer_connect(self, handles):
+        """handles: the world 64-byte handles in rank order (other processes' regions are mapped over IPC)"""
+        blob = b"".join(bytes(h) for h in handles)
+        buf = (ctypes.c_uint8 * len(blob)).from_buffer_copy(blob)
+        self.check(self.lib.sc_ctx_comm_peer_connect(self.h, buf))
+
+    def comm_peer_connect_local(self, peers):
+        """peers: the world Context objects of this process, in rank order"""
+        arr = (voidp * len(peers))(*[p.h for p in peers])
+        self.check(self.lib.sc_ctx_comm_peer_connect_local(self.h, arr))
+
     def rank_world(self):
         r, w = ctypes.c_int(), ctypes.c_int()
         self.check(self.lib.sc_ctx_comm_rank(self.h, ctypes.byref(r), ctypes.byref(w)))

@@ -98,7 +98,20 @@ def attach_rccl(ctx, rank, world, group=None):
     ctx.comm_init_rccl(uid, rank, world)
 
 
+def attach_peer(ctx, rank, world, group=None):
+    """peer transport: export this rank's region, all-gather the IPC handles over the control plane
+    (torch.distributed, any backend that moves Python objects), map the peers' regions"""
+    import torch.distributed as dist
+    handle = ctx.comm_peer_export(rank, world)
+    if world == 1:
+        handles = [handle]
+    else:
+        handles = [None] * world
+        dist.all_gather_object(handles, handle, group=group)
+    ctx.comm_peer_connect(handles)
+
+
 def attach_default(ctx, rank, world, group=None):
     """the data-plane transport a multi-GPU run uses unless told otherwise; returns its name"""
-    attach_rccl(ctx, rank, world, group)
-    return "rccl"
+    attach_peer(ctx, rank, world, group)
+    return "peer"
