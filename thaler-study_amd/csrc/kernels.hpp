@@ -705,7 +705,7 @@ small_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u6
 // ordinary launches from the tables the last finished phase left (a caller that takes seconds
 // between rounds must not pin the GPU, and a lost command must not hang it).
 constexpr int kMaxResidentPhases = 16;
-constexpr u64 kCmdPark = 0x8000000000000000ull;   // dev_cmd sequence word: "parked", phase in the low bits
+constexpr u64 kCmdPark = 0x8000000000000000ull;   // command sequence word | this bit: "park before this phase" (host abort / timeout)
 constexpr int kMailboxParked = 61;                // host mailbox word: 0, or 1 + the phase the kernel parked before
 constexpr int kCmdWords = 8;                      // one 64-byte line: [0] = sequence, [1..3] = challenges
 struct ResidentPlan {
@@ -969,7 +969,7 @@ resident_kernel(F f, const u64* __restrict__ A0, const u64* __restrict__ B0, u64
       // it with one load instruction (one PCIe / L2 round trip) and the check word rejects a torn read.
       if (threadIdx.x < kWave) {
         const int lane = threadIdx.x;
-        const u64 want = ctl.cmd_base + (u64)p, park = kCmdPark | (u64)p;
+        const u64 want = ctl.cmd_base + (u64)p, park = kCmdPark | want;   // unique per launch AND phase
         const unsigned long long t0 = wall_clock64();
         unsigned spins = 0;
         u64 mine = 0, seq = 0;

@@ -135,8 +135,9 @@ struct sc_ctx {
   u64* d_cmd_host = nullptr;   // device alias of h_cmd
   u64* d_cmd = nullptr;
   u64 cmd_seq = 0;
-  int resident = 1;            // option "resident": serve the latency-bound passes from one resident launch
-  int resident_log = 25;       // largest input (log2 entries per table) the resident kernel starts from
+  int resident = 0;            // option "resident": serve the latency-bound passes from one resident launch
+                               // (off by default: measured equal to launches on one GPU)
+  int resident_log = 19;       // largest input (log2 entries per table) the resident kernel starts from
   int park_ms = 20;            // the resident kernel parks itself after this long without a command
   double dbg_host_ns = 0.0;    // diagnostic: host time between a phase's sums and the next command (resident_stamps)
   std::chrono::steady_clock::time_point dbg_t_collect;
@@ -1911,7 +1912,7 @@ void resident_retire(sc_ctx* ctx) {
   // the kernel may be in any phase >= next_phase - 1; an abort word for EVERY later phase would be needed to
   // stop it at once, so write the one it will look for next and let the park timeout cover the rest
   for (int q = std::max(pr->res.next_phase, 1); q < pr->res.plan.n_phases; ++q) {
-    __atomic_store_n(ctx->h_cmd, sc::kCmdPark | (u64)q, __ATOMIC_RELEASE);   // block 0 acts on word 0 alone
+    __atomic_store_n(ctx->h_cmd, sc::kCmdPark | (pr->res.cmd_base + (u64)q), __ATOMIC_RELEASE);   // block 0 acts on word 0 alone
     if (hipStreamQuery(ctx->stream) == hipSuccess) break;
     // give the kernel a moment to see it before trying the next phase's abort word
     auto t0 = std::chrono::steady_clock::now();
