@@ -241,3 +241,82 @@ def test_wiring_collisions_and_errors():
     with pytest.raises(pkg.SumcheckHipError) as ei:
         eng.round_evals(F.one, 2)                                # out of order
     assert ei.value.code == 5
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("transport", ["host", "peer"])
+def test_w_prover_sharded(world, transport):
+    """the dense W prover on a sharded context (BASELINE config 5 names gkr on 8 GPUs): every rank holds its rows of c
+    of add_i / mul_i (top index bits = rank) and the whole W tables; P and L are summed across ranks, add(r_b,.) /
+    mul(r_b,.) gathered; round polynomials bit-exact vs the oracle on every rank.  The sparse prover is replicated."""
+    import threading
+    from test_gpu_sharded import Loopback
+    if transport == "peer" and world > 2:
+        pytest.skip("threads of one process: see test_virtual_ranks_peer_transport")
+    pkg = load_package()
+    p = GOLD
+    o = oracle(p)
+    F0 = pkg.Field(p)
+    gp = pkg.gkr_protocol
+    rng = random.Random(77)
+    for ks in ([3, 3], [5, 4], [6, 7], [4, 9]):
+        layers = random_circuit(rng, ks)
+        circuit = make_circuit(pkg, layers, 1 << ks[-1])
+        inputs = [F0.from_int(rng.randrange(p)) for _ in range(1 << ks[-1])]
+        evaluation = circuit.evaluate(F0, inputs)
+        k_i, k_next = ks[0], ks[1]
+        r_i = [F0.from_int(rng.randrange(p)) for _ in range(k_i)]
+        oadd, omul = o.wiring_fixed(layers[0], k_next, r_i)
+        ow = np.array(evaluation[1], dtype=np.uint64)
+        ch = [F0.from_int(rng.randrange(p)) for _ in range(2 * k_next)]
+        ref = o.w_prove(oadd, omul, ow, ow, ch)
+        assert ref["status"] == 0
+        lb = Loopback(world)
+        ctxs, errors, results = [None] * world, [], [None] * world
+
+        def body(rank):
+            try:
+                ctx = pkg.Context(pkg.Field(p))
+                if transport == "peer":
+                    ctx.set_option("peer_spin_ms", 20000)
+                    ctx.comm_peer_export(rank, world)
+                    ctxs[rank] = ctx
+                    lb.barrier.wait()
+                    ctx.comm_peer_connect_local(ctxs)
+                    lb.barrier.wait()
+                else:
+                    ar, ag = lb.collectives(rank)
+                    ctx.comm_init_host(rank, world, ar, ag)
+                n_loc = oadd.size // world
+                DM = pkg.DenseMultilinearExtension
+                add_t = DM.from_evaluations_vec(ctx, 2 * k_next - (world.bit_length() - 1), oadd[rank * n_loc:(rank + 1) * n_loc])
+                mul_t = DM.from_evaluations_vec(ctx, 2 * k_next - (world.bit_length() - 1), omul[rank * n_loc:(rank + 1) * n_loc])
+                w_t = DM.from_evaluations_vec(ctx, k_next, ow)
+                eng = gp.W(add_t, mul_t, w_t, w_t).native_prover()
+                seng = gp.SparseLayerProver(ctx, circuit, evaluation, 0, r_i)
+                got = [(eng.c1(), seng.c1())]
+                for j in range(2 * k_next):
+                    rp = ch[j - 1] if j else F0.one
+                    got.append((eng.round_evals(rp, j), seng.round_evals(rp, j)))
+                results[rank] = got
+                if transport == "peer":
+                    lb.barrier.wait()
+                del eng, seng, add_t, mul_t, w_t
+                ctx.close()
+            except Exception as e:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                errors.append(e)
+                lb.barrier.abort()
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+        for got in results:
+            assert got[0] == (ref["c_1"], ref["c_1"]), ks
+            for j in range(2 * k_next):
+                e = [int(x) for x in ref["evals"][j]]
+                assert got[1 + j] == (e, e), (ks, j)

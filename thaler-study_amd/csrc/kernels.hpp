@@ -1478,6 +1478,122 @@ gkr_wiring_scatter_kernel(F f, const u64* __restrict__ eq, const int* __restrict
 }
 
 // ------------------------------------------------------------------------------------
+// Two-phase form of the W sumcheck (the linear-time GKR prover of Thaler's book, section 4.6.5 / "Libra"):
+// with the c variables summed out,
+//     sum_c f(b, c) = W(b) * P(b) + L(b),   P(b) = sum_c add(b,c) + mul(b,c) W(c),   L(b) = sum_c add(b,c) W(c)
+// so the rounds over the b variables are a product sumcheck on the 2^kb-entry tables (P, W_b) plus a linear
+// one on L, and once b is fixed at r_b, with w* = W(r_b),
+//     f(r_b, c) = W(c) * Q(c) + w* add(r_b, c),   Q(c) = add(r_b, c) + w* mul(r_b, c)
+// - the same shape on 2^kc-entry tables.  Both are exact identities of the polynomial the reference sums
+// (gkr-protocol/src/round_polynomial.rs:78-90 walks all 4^k evaluations four times per round), so every
+// round polynomial is the reference's.  add and mul are read twice per LAYER (once for P and L, once to
+// fix b) instead of twice per round.
+
+// P[b], L[b] as above for one chunk of rows (= values of c) per blockIdx.y; index of add/mul = c * M + b.
+// Lanes own 16-byte pieces of b: coalesced.  w[c] = W(c).
+template <class F, bool NT>
+__global__ void __launch_bounds__(kBlock)
+gkr_phase1_kernel(F f, const u64* __restrict__ add, const u64* __restrict__ mul, const u64* __restrict__ w, size_t rows,
+                  size_t rows_per_chunk, size_t M, u64* __restrict__ partialP, u64* __restrict__ partialL) {
+  const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(add);
+  const ull2* __restrict__ Mp = reinterpret_cast<const ull2*>(mul);
+  ull2* __restrict__ Pp = reinterpret_cast<ull2*>(partialP);
+  ull2* __restrict__ Lp = reinterpret_cast<ull2*>(partialL);
+  const size_t mp = M / 2;
+  const size_t i0 = (size_t)blockIdx.y * rows_per_chunk;
+  const size_t i1 = (i0 + rows_per_chunk < rows) ? i0 + rows_per_chunk : rows;
+  for (size_t pc = (size_t)blockIdx.x * kBlock + threadIdx.x; pc < mp; pc += (size_t)gridDim.x * kBlock) {
+    typename F::Acc p0, p1, l0, l1;
+    f.acc_zero(p0); f.acc_zero(p1); f.acc_zero(l0); f.acc_zero(l1);
+    u64 s0 = 0, s1 = 0;   // sum_c add: plain modular adds
+    size_t i = i0;
+    for (; i + 2 <= i1; i += 2) {   // fixed-count inner loop (acc_mac is inline asm: no runtime unrolling)
+      ull2 a[2], m[2];
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        a[k] = ld16<NT>(Ap + (i + k) * mp + pc);
+        m[k] = ld16<NT>(Mp + (i + k) * mp + pc);
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const u64 wi = w[i + k];
+        s0 = f.add(s0, a[k].x); s1 = f.add(s1, a[k].y);
+        f.acc_mac(p0, m[k].x, wi); f.acc_mac(p1, m[k].y, wi);
+        f.acc_mac(l0, a[k].x, wi); f.acc_mac(l1, a[k].y, wi);
+      }
+    }
+    for (; i < i1; ++i) {
+      const ull2 a = ld16<NT>(Ap + i * mp + pc), m = ld16<NT>(Mp + i * mp + pc);
+      const u64 wi = w[i];
+      s0 = f.add(s0, a.x); s1 = f.add(s1, a.y);
+      f.acc_mac(p0, m.x, wi); f.acc_mac(p1, m.y, wi);
+      f.acc_mac(l0, a.x, wi); f.acc_mac(l1, a.y, wi);
+    }
+    ull2 op = {f.add(s0, f.acc_get(p0)), f.add(s1, f.acc_get(p1))};
+    ull2 ol = {f.acc_get(l0), f.acc_get(l1)};
+    Pp[(size_t)blockIdx.y * mp + pc] = op;
+    Lp[(size_t)blockIdx.y * mp + pc] = ol;
+  }
+}
+
+// The phase's pair of tables for the product prover, with the linear term riding on one more variable s
+// (the highest index bit, never reached by the k rounds that are run):
+//   TA = [ X + sY * Y | sZ * Z ],  TB = [ V | 1 ]       (n entries each half)
+// phase b: X = P, sY = 0, Z = L, sZ = 1, V = W_b;  phase c: X = add_r, Y = mul_r, sY = w*, Z = add_r, sZ = w*, V = W_c.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+gkr_combine_kernel(F f, const u64* __restrict__ X, const u64* __restrict__ Y, u64 sY, const u64* __restrict__ Z, u64 sZ,
+                   const u64* __restrict__ V, size_t n, u64* __restrict__ TA, u64* __restrict__ TB) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    TA[i] = f.add(X[i], f.mul(sY, Y[i]));
+    TA[n + i] = f.mul(sZ, Z[i]);
+    TB[i] = V[i];
+    TB[n + i] = f.one();
+  }
+}
+
+// slot += w (mod p): there is no modular atomic add, so a compare-and-swap loop
+template <class F>
+__device__ __forceinline__ void atomic_add_mod(const F& f, u64* slot, u64 w) {
+  unsigned long long old = __hip_atomic_load((unsigned long long*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  while (true) {
+    const unsigned long long want = f.add((u64)old, w);
+    if (__hip_atomic_compare_exchange_strong((unsigned long long*)slot, &old, want, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_AGENT))
+      break;
+  }
+}
+// The same P and L straight from the gate list (add_i / mul_i have one non-zero per gate): gate a with
+// inputs (b, c) = (in0, in1) and weight v = eq(r_i, a) adds v to P[b] and v W(c) to L[b] if it is an add gate,
+// v W(c) to P[b] if it is a mul gate.  Outputs start zeroed.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+gkr_sparse_phase1_kernel(F f, const u64* __restrict__ val, const int* __restrict__ gate_type, const unsigned* __restrict__ in0,
+                         const unsigned* __restrict__ in1, size_t n_gates, const u64* __restrict__ w, u64* __restrict__ P,
+                         u64* __restrict__ L) {
+  for (size_t a = (size_t)blockIdx.x * kBlock + threadIdx.x; a < n_gates; a += (size_t)gridDim.x * kBlock) {
+    const u64 v = val[a], vw = f.mul(v, w[in1[a]]);
+    if (gate_type[a] == 0) {
+      atomic_add_mod(f, P + in0[a], v);
+      atomic_add_mod(f, L + in0[a], vw);
+    } else {
+      atomic_add_mod(f, P + in0[a], vw);
+    }
+  }
+}
+// add(r_b, c) and mul(r_b, c) from the gate list: gate a adds eq(r_i, a) eq(r_b, in0) at c = in1 of its type's table
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+gkr_sparse_phase2_kernel(F f, const u64* __restrict__ val, const int* __restrict__ gate_type, const unsigned* __restrict__ in0,
+                         const unsigned* __restrict__ in1, size_t n_gates, const u64* __restrict__ eqb, u64* __restrict__ add_r,
+                         u64* __restrict__ mul_r) {
+  for (size_t a = (size_t)blockIdx.x * kBlock + threadIdx.x; a < n_gates; a += (size_t)gridDim.x * kBlock) {
+    const u64 v = f.mul(val[a], eqb[in0[a]]);
+    atomic_add_mod(f, (gate_type[a] == 0 ? add_r : mul_r) + in1[a], v);
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // triangle_counting::G (triangle-counting/src/lib.rs:22-166): g(X,Y,Z) = f(X,Y) f(Y,Z) f(X,Z).
 
 // P[(z << k) | x] = sum_y f[(y << k) | x] * f[(z << k) | y]: the square of the adjacency MLE's
@@ -1545,75 +1661,6 @@ tri_to_evaluations_kernel(F f, const u64* __restrict__ f1, const u64* __restrict
   for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
     const size_t z = o & (((size_t)1 << zv) - 1), y = (o >> zv) & (((size_t)1 << yv) - 1), x = o >> (zv + yv);
     out[o] = f.mul(f.mul(f1[(y << xv) | x], f2[(z << yv) | y]), f3[(z << xv) | x]);
-  }
-}
-
-// Sparse form of the W sumcheck.  add_i(r_i,.,.) and mul_i(r_i,.,.) have one non-zero per
-// gate (2^k_i of the 2^(2 k_next) entries), and W is LINEAR in them, so a round only has to
-// visit the gates: entry e carries idx_e = (in1 << k_next) | in0, its type and its current
-// value val_e (eq(r_i, a) times the factors of the challenges folded so far).  Per round:
-//   - apply the previous challenge r: val_e *= (bit ? r : 1 - r), bit = bit (shift-1) of idx_e;
-//   - with cur = idx_e >> shift: the entry sits at position `bit = cur & 1` of pair q = cur >> 1,
-//     S(t) = x(t) + y for an add gate, x(t) * y for a mul gate (x, y as in gkr_sums_kernel);
-//     it adds val*S(0) to H(0) if bit = 0, val*S(1) to H(1) if bit = 1, and -/+ val*(S(1)-S(0)) to
-//     H(inf).  Entries that fall into the same pair need no merging (linearity).
-// O(gates) per round instead of O(4^k_next): the dense tables are never built.
-template <class F>
-__global__ void __launch_bounds__(kBlock)
-gkr_sparse_round_kernel(F f, const unsigned* __restrict__ idx, const int* __restrict__ gate_type, u64* __restrict__ val,
-                        size_t n_entries, int shift, u64 r_prev, const u64* __restrict__ V, int logV,
-                        const u64* __restrict__ Fx, PassOut out) {
-  __shared__ u64 lds[(kBlock / kWave) * 3];
-  __shared__ int lds_flag;
-  const ull2* __restrict__ Vp = reinterpret_cast<const ull2*>(V);
-  const size_t vmask = (((size_t)1 << logV) >> 1) - 1;
-  const u64 one_minus_r = f.sub(f.one(), r_prev);
-  typename F::Acc acc[3];
-#pragma unroll
-  for (int s = 0; s < 3; ++s) f.acc_zero(acc[s]);
-  for (size_t e = (size_t)blockIdx.x * kBlock + threadIdx.x; e < n_entries; e += (size_t)gridDim.x * kBlock) {
-    const unsigned id = idx[e];
-    u64 v = val[e];
-    if (shift > 0) {
-      v = f.mul(v, ((id >> (shift - 1)) & 1) ? r_prev : one_minus_r);
-      val[e] = v;
-    }
-    const size_t cur = (size_t)(id >> shift);
-    const int bit = (int)(cur & 1);
-    const size_t q = cur >> 1;
-    const ull2 x = Vp[q & vmask];
-    const u64 y = Fx[(2 * q) >> logV];
-    u64 s0, s1;
-    if (gate_type[e] == 0) {
-      s0 = f.add(x.x, y);
-      s1 = f.add(x.y, y);
-    } else {
-      s0 = f.mul(x.x, y);
-      s1 = f.mul(x.y, y);
-    }
-    const u64 ds = f.sub(s1, s0);
-    if (bit == 0) {
-      f.acc_mac(acc[0], v, s0);
-      f.acc_mac(acc[2], v, f.sub(0, ds));   // coefficient of t^2 in val (1-t) (s0 + t ds)
-    } else {
-      f.acc_mac(acc[1], v, s1);
-      f.acc_mac(acc[2], v, ds);
-    }
-  }
-  u64 res[3];
-#pragma unroll
-  for (int s = 0; s < 3; ++s) res[s] = f.acc_get(acc[s]);
-  block_reduce<F, 3>(f, res, lds);
-  finish_pass<F, 3>(f, out, res[0], &lds_flag);
-}
-
-// entries of the sparse form from the gate list: idx = (in1 << k_next) | in0, val = eq[a]
-__global__ void __launch_bounds__(kBlock)
-gkr_sparse_init_kernel(const u64* __restrict__ eq, const unsigned* __restrict__ in0, const unsigned* __restrict__ in1,
-                       size_t n_gates, int k_next, unsigned* __restrict__ idx, u64* __restrict__ val) {
-  for (size_t a = (size_t)blockIdx.x * kBlock + threadIdx.x; a < n_gates; a += (size_t)gridDim.x * kBlock) {
-    idx[a] = (in1[a] << k_next) | in0[a];
-    val[a] = eq[a];
   }
 }
 

@@ -2282,7 +2282,9 @@ bool cache_covers(const sc_prover* pr, size_t j) {
 
 }  // namespace
 
-extern "C" int sc_prover_create(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_prover** out) {
+// `replicated`: on a sharded context, treat a and b as whole tables held identically by every rank (the
+// small tables of the GKR phases): no exchange, every rank proves the same thing
+static int prover_create_impl(sc_ctx* ctx, const sc_table* a, const sc_table* b, bool replicated, sc_prover** out) {
   if (!ctx || !out) return SC_ERR_ARG;
   SC_TRY(check_pair(ctx, a, b, "sc_prover_create"));
   SC_TRY(set_device(ctx));
@@ -2292,8 +2294,8 @@ extern "C" int sc_prover_create(sc_ctx* ctx, const sc_table* a, const sc_table* 
   pr->a0 = pr->cur_a = a->d;
   pr->b0 = pr->cur_b = b->d;
   pr->cur_log = log2_of(a->len);
-  pr->sharded = is_sharded(ctx);
-  pr->num_vars = (size_t)pr->cur_log + ctx->log_world;
+  pr->sharded = is_sharded(ctx) && !replicated;
+  pr->num_vars = (size_t)pr->cur_log + (pr->sharded ? ctx->log_world : 0);
   HostField hf(ctx->fp);
   if (pr->num_vars == 0) {
     // no variable: c_1 is the single product, no rounds follow
@@ -2316,6 +2318,10 @@ extern "C" int sc_prover_create(sc_ctx* ctx, const sc_table* a, const sc_table* 
   pr->c1 = hf.add(e[0], e[1]);
   *out = pr;
   return SC_OK;
+}
+
+extern "C" int sc_prover_create(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_prover** out) {
+  return prover_create_impl(ctx, a, b, false, out);
 }
 
 extern "C" int sc_prover_c1(const sc_prover* pr, uint64_t* out) {
@@ -2568,41 +2574,238 @@ extern "C" int sc_gkr_w_evaluate(sc_ctx* ctx, const sc_table* add, const sc_tabl
   return SC_OK;
 }
 
-// One variable per pass: fold add, mul and the small table that owns the variable, then sum.
+// The W prover in its two-phase form (kernels.hpp, "Two-phase form of the W sumcheck"): the rounds over
+// the b variables are ONE product-of-two-tables proof on [P | L] x [W_b | 1], the rounds over the c
+// variables one on [Q | w* add_r] x [W_c | 1]; both run on the pass engine of sc_prover.  add and mul are
+// streamed twice per layer (dense form) or the gate list is scattered twice (sparse form).
 struct sc_gkr_prover {
   sc_ctx* ctx = nullptr;
-  const u64 *add = nullptr, *mul = nullptr, *w_b = nullptr, *w_c = nullptr;  // current views
-  u64 *own_add = nullptr, *own_mul = nullptr, *own_wb = nullptr, *own_wc = nullptr;
-  int kb = 0, kc = 0;
+  // dense form: borrowed tables, index (c << kb) | b (this rank's rows of c on a sharded context)
+  const u64 *add = nullptr, *mul = nullptr;
+  size_t add_len = 0;
+  // both forms: W_b and W_c, whole on every rank
+  const u64 *w_b = nullptr, *w_c = nullptr;
+  int kb = 0, kc = 0;   // variables of b / c when the prover was created
+  // sparse form: the gate list on the device and eq(r_i, a)
+  bool sparse = false;
+  size_t n_gates = 0;
+  int* sp_type = nullptr;
+  unsigned *sp_in0 = nullptr, *sp_in1 = nullptr;
+  u64* sp_val = nullptr;
+  u64* sp_words = nullptr;   // pool block backing sp_type / sp_in0 / sp_in1
   size_t num_vars = 0, next_round = 0;
   u64 c1 = 0;
-  u64 first[3];
-  // sparse form (sc_gkr_prover_create_sparse): one entry per gate
-  bool sparse = false;
-  size_t n_entries = 0;
-  unsigned* sp_idx = nullptr;
-  int* sp_type = nullptr;
-  u64* sp_val = nullptr;
-  u64* sp_words = nullptr;  // pool block backing sp_idx / sp_type
+  std::vector<u64> r;        // challenges received
+  // current phase
+  sc_prover* sub = nullptr;
+  sc_table ta, tb;
+  u64 *TA = nullptr, *TB = nullptr;
 };
 
 namespace {
 
-// one round of the sparse prover: folds the gate values with r_prev (shift > 0) and sums
-int gkr_sparse_round(sc_gkr_prover* pr, int shift, u64 r_prev, u64 e[3]) {
-  sc_ctx* ctx = pr->ctx;
-  const u64* V = pr->kb >= 1 ? pr->w_b : pr->w_c;
-  const int logV = pr->kb >= 1 ? pr->kb : pr->kc;
-  const u64* Fx = pr->kb >= 1 ? pr->w_c : pr->w_b;
-  const int grid = grid_for_wide(ctx, pr->n_entries);
-  sc::PassOut out = next_pass_out(ctx, grid);
-  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_sparse_round_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
-                                                  f, (const unsigned*)pr->sp_idx, (const int*)pr->sp_type, pr->sp_val,
-                                                  pr->n_entries, shift, r_prev, V, logV, Fx, out));
-  SC_TRY(commit_pass_out(ctx, out, grid));
-  SC_TRY(collect_sums(ctx, 3, false, ctx->use_mailbox != 0, e));
+// value of a whole (unsharded) device table at an LE point, on this rank alone
+int evaluate_replicated(sc_ctx* ctx, const u64* d, size_t len, const u64* pt, u64* out) {
+  if (len == 1) {
+    SC_HIP(ctx, hipMemcpyAsync(out, d, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SC_OK;
+  }
   HostField hf(ctx->fp);
-  e[2] = eval2_from_inf(hf, e[0], e[1], e[2]);
+  bool mb = false;
+  SC_TRY(evaluate_local(ctx, d, len, pt, hf.one(), false, &mb));
+  return collect_sums(ctx, 1, false, mb, out);
+}
+
+// P and L of the b phase (dense form): one streaming pass over add and mul
+int gkr_dense_phase1(sc_gkr_prover* pr, u64* P, u64* L) {
+  sc_ctx* ctx = pr->ctx;
+  const size_t M = (size_t)1 << pr->kb;
+  const size_t rows = pr->add_len / M;   // this rank's values of c
+  const u64* w = pr->w_c + (is_sharded(ctx) ? (size_t)ctx->rank * rows : 0);
+  const size_t mp = M / 2;
+  size_t chunks = 1;
+  if (mp < ((size_t)1 << 16)) {
+    chunks = (((size_t)1 << 16) + mp - 1) / mp;
+    if (chunks > rows) chunks = rows;
+    if (chunks > 256) chunks = 256;
+  }
+  const size_t rows_per_chunk = (rows + chunks - 1) / chunks;
+  chunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+  if (rows_per_chunk > sc::GoldilocksMont::kAccMaxTerms)
+    return fail(ctx, SC_ERR_UNSUPPORTED, "gkr: %zu rows per chunk exceed the lazy accumulator's capacity", rows_per_chunk);
+  u64 *pP = P, *pL = L;
+  if (chunks > 1) {
+    SC_TRY(pool_alloc(ctx, chunks * M, &pP));
+    int rc = pool_alloc(ctx, chunks * M, &pL);
+    if (rc != SC_OK) {
+      pool_release(ctx, pP);
+      return rc;
+    }
+  }
+  size_t gx = (mp + sc::kBlock - 1) / sc::kBlock;
+  if (gx > 1024) gx = 1024;
+  const int nt = pr->add_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
+  int rc = timer_begin(ctx, SC_KIND_GKR, pr->kc, 0, log2_of(pr->add_len), (u64)16 * pr->add_len + 8 * rows, (u64)16 * M);
+  if (rc == SC_OK) {
+    if (nt)
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_phase1_kernel<F, true>), dim3((unsigned)gx, (unsigned)chunks),
+                                                      dim3(sc::kBlock), 0, ctx->stream, f, pr->add, pr->mul, w, rows, rows_per_chunk, M, pP, pL));
+    else
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_phase1_kernel<F, false>), dim3((unsigned)gx, (unsigned)chunks),
+                                                      dim3(sc::kBlock), 0, ctx->stream, f, pr->add, pr->mul, w, rows, rows_per_chunk, M, pP, pL));
+    if (chunks > 1) {
+      const int grid = grid_for(ctx, M);
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::sum_rows_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                      (const u64*)pP, chunks, M, P));
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::sum_rows_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                      (const u64*)pL, chunks, M, L));
+    }
+    if (hipGetLastError() != hipSuccess) {
+      poison(ctx);
+      rc = fail(ctx, SC_ERR_HIP, "gkr phase-1 launch failed");
+    }
+  }
+  if (rc == SC_OK) rc = timer_end(ctx);
+  if (chunks > 1) {
+    pool_release(ctx, pP);
+    pool_release(ctx, pL);
+  }
+  return rc;
+}
+
+// sum a vector of residues over the ranks of a sharded context (split limbs, exact), in place
+int allreduce_residues(sc_ctx* ctx, u64* v, size_t n) {
+  if (!is_sharded(ctx) || ctx->world == 1) return SC_OK;
+  u64* limbs = nullptr;
+  SC_TRY(pool_alloc(ctx, 2 * n, &limbs));
+  hipLaunchKernelGGL(sc::split_limbs_kernel, dim3(grid_for(ctx, n)), dim3(sc::kBlock), 0, ctx->stream, (const u64*)v, n, limbs);
+  int rc = allreduce_device(ctx, limbs, 2 * n);
+  if (rc == SC_OK) {
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::recombine_limbs_kernel<F>), dim3(grid_for(ctx, n)), dim3(sc::kBlock), 0,
+                                                    ctx->stream, f, (const u64*)limbs, n, v));
+    if (hipGetLastError() != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "recombine_limbs_kernel launch failed");
+  }
+  pool_release(ctx, limbs);
+  return rc;
+}
+
+// Build the phase's tables and start its product prover.  which = 0: b variables; 1: c variables (b fixed at
+// pr->r[0 .. kb)).
+int gkr_start_phase(sc_gkr_prover* pr, int which) {
+  sc_ctx* ctx = pr->ctx;
+  HostField hf(ctx->fp);
+  if (pr->sub) sc_prover_destroy(pr->sub);
+  pr->sub = nullptr;
+  pool_release(ctx, pr->TA);
+  pool_release(ctx, pr->TB);
+  pr->TA = pr->TB = nullptr;
+  const int kv = which == 0 ? pr->kb : pr->kc;   // variables of this phase
+  const size_t n = (size_t)1 << kv;
+  u64 *X = nullptr, *Y = nullptr;   // P, L  or  add_r, mul_r
+  u64 wstar = 0;
+  int rc = SC_OK;
+  const bool sharded_dense = !pr->sparse && is_sharded(ctx) && ctx->world > 1;
+  if (which == 0) {
+    rc = pool_alloc(ctx, n, &X);
+    if (rc == SC_OK) rc = pool_alloc(ctx, n, &Y);
+    if (rc == SC_OK && pr->sparse) {
+      hipError_t e = hipMemsetAsync(X, 0, n * sizeof(u64), ctx->stream);
+      if (e == hipSuccess) e = hipMemsetAsync(Y, 0, n * sizeof(u64), ctx->stream);
+      if (e == hipSuccess) {
+        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_sparse_phase1_kernel<F>), dim3(grid_for_wide(ctx, pr->n_gates)),
+                                                        dim3(sc::kBlock), 0, ctx->stream, f, (const u64*)pr->sp_val,
+                                                        (const int*)pr->sp_type, (const unsigned*)pr->sp_in0,
+                                                        (const unsigned*)pr->sp_in1, pr->n_gates, pr->w_c, X, Y));
+        e = hipGetLastError();
+      }
+      if (e != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "gkr sparse phase 1: %s", hipGetErrorString(e));
+    } else if (rc == SC_OK) {
+      rc = gkr_dense_phase1(pr, X, Y);
+      // sharded: every rank summed its own rows of c; P and L are the sums over the ranks
+      if (rc == SC_OK && sharded_dense) rc = allreduce_residues(ctx, X, n);
+      if (rc == SC_OK && sharded_dense) rc = allreduce_residues(ctx, Y, n);
+    }
+  } else {
+    // w* = W_b(r_b)
+    rc = evaluate_replicated(ctx, pr->w_b, (size_t)1 << pr->kb, pr->r.data(), &wstar);
+    if (rc == SC_OK && pr->sparse) {
+      u64* eqb = nullptr;
+      rc = build_eq_table(ctx, pr->r.data(), pr->kb, &eqb);
+      if (rc == SC_OK) rc = pool_alloc(ctx, n, &X);
+      if (rc == SC_OK) rc = pool_alloc(ctx, n, &Y);
+      if (rc == SC_OK) {
+        hipError_t e = hipMemsetAsync(X, 0, n * sizeof(u64), ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(Y, 0, n * sizeof(u64), ctx->stream);
+        if (e == hipSuccess) {
+          SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_sparse_phase2_kernel<F>), dim3(grid_for_wide(ctx, pr->n_gates)),
+                                                          dim3(sc::kBlock), 0, ctx->stream, f, (const u64*)pr->sp_val,
+                                                          (const int*)pr->sp_type, (const unsigned*)pr->sp_in0,
+                                                          (const unsigned*)pr->sp_in1, pr->n_gates, (const u64*)eqb, X, Y));
+          e = hipGetLastError();
+        }
+        if (e != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "gkr sparse phase 2: %s", hipGetErrorString(e));
+      }
+      pool_release(ctx, eqb);
+    } else if (rc == SC_OK) {
+      // add(r_b, .) and mul(r_b, .): fix the kb low variables of both tables (one streaming pass each)
+      size_t la = 0, lm = 0;
+      rc = fold_chain(ctx, pr->add, pr->add_len, pr->r.data(), (size_t)pr->kb, SC_ORDER_LE, &X, &la);
+      if (rc == SC_OK) rc = fold_chain(ctx, pr->mul, pr->add_len, pr->r.data(), (size_t)pr->kb, SC_ORDER_LE, &Y, &lm);
+      if (rc == SC_OK && sharded_dense) {
+        // every rank holds its rows of c: gather the whole 2^kc-entry tables
+        if (ctx->transport == Transport::kPeer) {
+          const u64 *fa = nullptr, *fb = nullptr;
+          u64 *gx = nullptr, *gy = nullptr;
+          rc = peer_gather(ctx, X, Y, la, &fa, &fb);
+          if (rc == SC_OK) rc = pool_alloc(ctx, n, &gx);
+          if (rc == SC_OK) rc = pool_alloc(ctx, n, &gy);
+          if (rc == SC_OK) {
+            hipError_t e = hipMemcpyAsync(gx, fa, n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipMemcpyAsync(gy, fb, n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream);
+            if (e != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "gkr gather copy: %s", hipGetErrorString(e));
+          }
+          pool_release(ctx, X);
+          pool_release(ctx, Y);
+          X = gx;
+          Y = gy;
+        } else {
+          u64 *gx = nullptr, *gy = nullptr;
+          rc = gather_table(ctx, X, la, &gx);
+          if (rc == SC_OK) rc = gather_table(ctx, Y, lm, &gy);
+          pool_release(ctx, X);
+          pool_release(ctx, Y);
+          X = gx;
+          Y = gy;
+        }
+      }
+    }
+  }
+  if (rc == SC_OK) rc = pool_alloc(ctx, 2 * n, &pr->TA);
+  if (rc == SC_OK) rc = pool_alloc(ctx, 2 * n, &pr->TB);
+  if (rc == SC_OK) {
+    const u64 sY = which == 0 ? 0 : wstar, sZ = which == 0 ? hf.one() : wstar;
+    const u64* Z = which == 0 ? Y : X;
+    const u64* V = which == 0 ? pr->w_b : pr->w_c;
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_combine_kernel<F>), dim3(grid_for_wide(ctx, n)), dim3(sc::kBlock), 0,
+                                                    ctx->stream, f, (const u64*)X, (const u64*)(which == 0 ? X : Y), sY, Z, sZ, V, n,
+                                                    pr->TA, pr->TB));
+    if (hipGetLastError() != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "gkr_combine_kernel launch failed");
+  }
+  pool_release(ctx, X);   // stream-ordered: the combine kernel is ahead of any reuse
+  pool_release(ctx, Y);
+  if (rc != SC_OK) return rc;
+  pr->ta.d = pr->TA;
+  pr->ta.len = 2 * n;
+  pr->tb.d = pr->TB;
+  pr->tb.len = 2 * n;
+  return prover_create_impl(ctx, &pr->ta, &pr->tb, true, &pr->sub);
+}
+
+int gkr_prover_begin(sc_gkr_prover* pr) {
+  pr->num_vars = (size_t)(pr->kb + pr->kc);
+  SC_TRY(gkr_start_phase(pr, pr->kb >= 1 ? 0 : 1));
+  pr->c1 = pr->sub->c1;   // sum of [X | lin] . [V | 1] = sum_b W(b) P(b) + L(b) = sum of f
   return SC_OK;
 }
 
@@ -2613,8 +2816,7 @@ extern "C" int sc_gkr_prover_create_sparse(sc_ctx* ctx, const int32_t* gate_type
                                            sc_gkr_prover** out) {
   if (!ctx || !gate_type || !in0 || !in1 || (k_i && !r_i) || !out) return SC_ERR_ARG;
   SC_TRY(check_table(ctx, w_next, "sc_gkr_prover_create_sparse"));
-  if (is_sharded(ctx)) return fail(ctx, SC_ERR_UNSUPPORTED, "gkr prover on a sharded context");
-  if (k_i > 30 || k_next < 1 || k_next > 15 || w_next->len != ((size_t)1 << k_next))
+  if (k_i > 30 || k_next < 1 || k_next > 26 || w_next->len != ((size_t)1 << k_next))
     return fail(ctx, SC_ERR_ARG, "sc_gkr_prover_create_sparse: bad layer sizes");
   SC_TRY(set_device(ctx));
   const size_t n_gates = (size_t)1 << k_i, n_next = (size_t)1 << k_next;
@@ -2625,41 +2827,26 @@ extern "C" int sc_gkr_prover_create_sparse(sc_ctx* ctx, const int32_t* gate_type
   if (!pr) return fail(ctx, SC_ERR_OOM, "host allocation failed");
   pr->ctx = ctx;
   pr->sparse = true;
-  pr->n_entries = n_gates;
-  pr->w_b = pr->w_c = w_next->d;
+  pr->n_gates = n_gates;
+  pr->w_b = pr->w_c = w_next->d;   // on a sharded context: the whole table, on every rank
   pr->kb = pr->kc = (int)k_next;
-  pr->num_vars = 2 * k_next;
-  u64 *eq = nullptr, *tmp = nullptr;
-  int rc = build_eq_table(ctx, r_i, (int)k_i, &eq);
-  if (rc == SC_OK) rc = pool_alloc(ctx, n_gates + 1, &pr->sp_words);   // idx (u32) | type (i32)
-  if (rc == SC_OK) rc = pool_alloc(ctx, n_gates, &pr->sp_val);
-  if (rc == SC_OK) rc = pool_alloc(ctx, n_gates + 1, &tmp);             // in0 | in1 staging
+  int rc = pool_alloc(ctx, (3 * n_gates * 4 + 7) / 8 + 1, &pr->sp_words);   // type | in0 | in1 as 32-bit words
+  if (rc == SC_OK) rc = build_eq_table(ctx, r_i, (int)k_i, &pr->sp_val);  // eq(r_i, a): the gate's weight
   if (rc == SC_OK) {
-    pr->sp_idx = (unsigned*)pr->sp_words;
-    pr->sp_type = (int*)pr->sp_words + n_gates;
-    unsigned* d_in0 = (unsigned*)tmp;
-    unsigned* d_in1 = (unsigned*)tmp + n_gates;
+    pr->sp_type = (int*)pr->sp_words;
+    pr->sp_in0 = (unsigned*)pr->sp_words + n_gates;
+    pr->sp_in1 = (unsigned*)pr->sp_words + 2 * n_gates;
     hipError_t e = hipMemcpyAsync(pr->sp_type, gate_type, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_in0, in0, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipMemcpyAsync(d_in1, in1, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) {
-      hipLaunchKernelGGL(sc::gkr_sparse_init_kernel, dim3(grid_for_wide(ctx, n_gates)), dim3(sc::kBlock), 0, ctx->stream,
-                         (const u64*)eq, (const unsigned*)d_in0, (const unsigned*)d_in1, n_gates, (int)k_next, pr->sp_idx,
-                         pr->sp_val);
-      e = hipGetLastError();
-    }
+    if (e == hipSuccess) e = hipMemcpyAsync(pr->sp_in0, in0, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(pr->sp_in1, in1, n_gates * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);   // host arrays may go away after return
     if (e != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "sc_gkr_prover_create_sparse: %s", hipGetErrorString(e));
   }
-  pool_release(ctx, eq);
-  pool_release(ctx, tmp);
-  if (rc == SC_OK) rc = gkr_sparse_round(pr, 0, 0, pr->first);
+  if (rc == SC_OK) rc = gkr_prover_begin(pr);
   if (rc != SC_OK) {
     sc_gkr_prover_destroy(pr);
     return rc;
   }
-  HostField hf(ctx->fp);
-  pr->c1 = hf.add(pr->first[0], pr->first[1]);
   *out = pr;
   return SC_OK;
 }
@@ -2667,27 +2854,33 @@ extern "C" int sc_gkr_prover_create_sparse(sc_ctx* ctx, const int32_t* gate_type
 extern "C" int sc_gkr_prover_create(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
                                     const sc_table* w_c, sc_gkr_prover** out) {
   if (!ctx || !out) return SC_ERR_ARG;
-  WView w;
-  SC_TRY(check_w(ctx, add, mul, w_b, w_c, &w));
+  SC_TRY(check_table(ctx, add, "gkr W"));
+  SC_TRY(check_table(ctx, mul, "gkr W"));
+  SC_TRY(check_table(ctx, w_b, "gkr W"));
+  SC_TRY(check_table(ctx, w_c, "gkr W"));
   SC_TRY(set_device(ctx));
-  if (w.kb + w.kc < 1) return fail(ctx, SC_ERR_ARG, "sc_gkr_prover_create: W has no variables");
+  const int kb = log2_of(w_b->len), kc = log2_of(w_c->len);
+  // sharded: add and mul are this rank's rows of c (top log2(world) bits of the index = rank); W_b and W_c whole
+  if (add->len != mul->len || add->len * (size_t)ctx->world != ((size_t)1 << (kb + kc)))
+    return fail(ctx, SC_ERR_ARG, "gkr W: add/mul must have num_vars(w_b) + num_vars(w_c) variables");
+  if (kb + kc < 1) return fail(ctx, SC_ERR_ARG, "sc_gkr_prover_create: W has no variables");
+  if (ctx->world > 1 && (kc < ctx->log_world || kb < 1))
+    return fail(ctx, SC_ERR_UNSUPPORTED, "sharded gkr W needs at least log2(world) variables of c and one of b");
   sc_gkr_prover* pr = new (std::nothrow) sc_gkr_prover;
   if (!pr) return fail(ctx, SC_ERR_OOM, "host allocation failed");
   pr->ctx = ctx;
-  pr->add = w.add;
-  pr->mul = w.mul;
-  pr->w_b = w.w_b;
-  pr->w_c = w.w_c;
-  pr->kb = w.kb;
-  pr->kc = w.kc;
-  pr->num_vars = (size_t)(w.kb + w.kc);
-  int rc = w_round_sums(ctx, w, pr->first);   // c_1 = H(0) + H(1) of round 0
+  pr->add = add->d;
+  pr->mul = mul->d;
+  pr->add_len = add->len;
+  pr->w_b = w_b->d;
+  pr->w_c = w_c->d;
+  pr->kb = kb;
+  pr->kc = kc;
+  int rc = gkr_prover_begin(pr);
   if (rc != SC_OK) {
-    delete pr;
+    sc_gkr_prover_destroy(pr);
     return rc;
   }
-  HostField hf(ctx->fp);
-  pr->c1 = hf.add(pr->first[0], pr->first[1]);
   *out = pr;
   return SC_OK;
 }
@@ -2703,78 +2896,39 @@ extern "C" int sc_gkr_prover_round(sc_gkr_prover* pr, uint64_t r_prev, size_t j,
   sc_ctx* ctx = pr->ctx;
   if (j != pr->next_round) return fail(ctx, SC_ERR_STATE, "sc_gkr_prover_round: expected round %zu, got %zu", pr->next_round, j);
   if (j >= pr->num_vars) return fail(ctx, SC_ERR_STATE, "sc_gkr_prover_round: all %zu rounds done", pr->num_vars);
+  if (j != 0 && r_prev >= ctx->fp.p) return fail(ctx, SC_ERR_ARG, "sc_gkr_prover_round: challenge is not reduced");
+  ResidentOwner own(ctx, pr->sub);
   SC_TRY(set_device(ctx));
-  if (j == 0) {
-    memcpy(out_e, pr->first, sizeof(pr->first));
-    pr->next_round = 1;
-    return SC_OK;
-  }
-  if (r_prev >= ctx->fp.p) return fail(ctx, SC_ERR_ARG, "sc_gkr_prover_round: challenge is not reduced");
-  if (pr->sparse) {
-    // fold the small table that owns variable j-1; the gate values are folded inside the kernel
-    const bool in_b = pr->kb >= 1;
-    u64* nw = nullptr;
-    size_t l3 = 0;
-    SC_TRY(fold_chain(ctx, in_b ? pr->w_b : pr->w_c, (size_t)1 << (in_b ? pr->kb : pr->kc), &r_prev, 1, SC_ORDER_LE, &nw, &l3));
-    if (in_b) {
-      pool_release(ctx, pr->own_wb);
-      pr->own_wb = nw;
-      pr->w_b = nw;
-      pr->kb -= 1;
-    } else {
-      pool_release(ctx, pr->own_wc);
-      pr->own_wc = nw;
-      pr->w_c = nw;
-      pr->kc -= 1;
+  HostField hf(ctx->fp);
+  if (j != 0) pr->r.push_back(r_prev);
+  size_t local_j = j;
+  bool phase_start = (j == 0);
+  if (pr->kb >= 1 && j >= (size_t)pr->kb) {
+    local_j = j - (size_t)pr->kb;
+    if (local_j == 0) {
+      // b is fixed at r[0 .. kb): build the c phase
+      const int rc = gkr_start_phase(pr, 1);
+      if (rc != SC_OK) {
+        pr->r.pop_back();
+        return rc;
+      }
+      phase_start = true;
     }
-    SC_TRY(gkr_sparse_round(pr, (int)j, r_prev, out_e));
-    pr->next_round = j + 1;
-    return SC_OK;
   }
-  // W::fix_variables(&[r_prev]) (round_polynomial.rs:59-76)
-  const size_t len = (size_t)1 << (pr->kb + pr->kc);
-  u64 *na = nullptr, *nm = nullptr, *nw = nullptr;
-  size_t l1 = 0, l2 = 0, l3 = 0;
-  int rc = fold_chain(ctx, pr->add, len, &r_prev, 1, SC_ORDER_LE, &na, &l1);
-  if (rc == SC_OK) rc = fold_chain(ctx, pr->mul, len, &r_prev, 1, SC_ORDER_LE, &nm, &l2);
-  const bool in_b = pr->kb >= 1;
-  if (rc == SC_OK)
-    rc = fold_chain(ctx, in_b ? pr->w_b : pr->w_c, (size_t)1 << (in_b ? pr->kb : pr->kc), &r_prev, 1, SC_ORDER_LE, &nw, &l3);
+  const int rc = sc_prover_round(pr->sub, phase_start ? hf.one() : r_prev, local_j, out_e);
   if (rc != SC_OK) {
-    pool_release(ctx, na);
-    pool_release(ctx, nm);
-    pool_release(ctx, nw);
+    if (j != 0) pr->r.pop_back();
     return rc;
   }
-  pool_release(ctx, pr->own_add);
-  pool_release(ctx, pr->own_mul);
-  pr->own_add = na;
-  pr->own_mul = nm;
-  pr->add = na;
-  pr->mul = nm;
-  if (in_b) {
-    pool_release(ctx, pr->own_wb);
-    pr->own_wb = nw;
-    pr->w_b = nw;
-    pr->kb -= 1;
-  } else {
-    pool_release(ctx, pr->own_wc);
-    pr->own_wc = nw;
-    pr->w_c = nw;
-    pr->kc -= 1;
-  }
-  WView w{pr->add, pr->mul, pr->w_b, pr->w_c, pr->kb, pr->kc};
-  SC_TRY(w_round_sums(ctx, w, out_e));
   pr->next_round = j + 1;
   return SC_OK;
 }
 
 extern "C" int sc_gkr_prover_destroy(sc_gkr_prover* pr) {
   if (!pr) return SC_OK;
-  pool_release(pr->ctx, pr->own_add);
-  pool_release(pr->ctx, pr->own_mul);
-  pool_release(pr->ctx, pr->own_wb);
-  pool_release(pr->ctx, pr->own_wc);
+  if (pr->sub) sc_prover_destroy(pr->sub);
+  pool_release(pr->ctx, pr->TA);
+  pool_release(pr->ctx, pr->TB);
   pool_release(pr->ctx, pr->sp_words);
   pool_release(pr->ctx, pr->sp_val);
   delete pr;
