@@ -1614,6 +1614,66 @@ matsq_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P) {
   }
 }
 
+// The same square, LDS-tiled, for n >= 64: a block of 256 threads owns a 64 x 64 tile of P and walks y in
+// steps of 32; per step it stages A[y][x0..x0+64) and, transposed, Bt[y][z0..z0+64) = f[(z << k) | y] in LDS
+// (16 KiB each), and every thread accumulates a 4 x 4 patch: 4 ds_read_b128 per 16 lazy multiply-adds
+// instead of 2 global loads per multiply-add, so the kernel runs at the VALU rate of the products
+// (15 instructions each) rather than at the L1 rate of the naive form.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+matsq_tiled_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P) {
+  constexpr int TS = 64, KT = 32;
+  __shared__ ull2 lds_a[KT * TS / 2];   // A[yy][xx], 16 KiB
+  __shared__ u64 lds_b[KT * TS];        // Bt[yy][zz], 16 KiB
+  const size_t n = (size_t)1 << k;
+  const int tiles = (int)(n / TS);
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  for (int tile = blockIdx.x; tile < tiles * tiles; tile += gridDim.x) {
+    const size_t x0 = (size_t)(tile % tiles) * TS, z0 = (size_t)(tile / tiles) * TS;
+    typename F::Acc acc[4][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) f.acc_zero(acc[j][i]);
+    for (size_t y0 = 0; y0 < n; y0 += KT) {
+      __syncthreads();   // the previous step's reads are done
+      // A tile: 32 rows of 64 entries; thread t loads 16-byte pieces (row t/32 + 8i, piece t%32)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = (threadIdx.x >> 5) + 8 * i, pc = threadIdx.x & 31;
+        lds_a[row * (TS / 2) + pc] = reinterpret_cast<const ull2*>(T + ((y0 + row) << k) + x0)[pc];
+      }
+      // B tile: rows z0 + zz hold 32 consecutive y; thread t loads piece t%16 of row t/16 + 16i and
+      // stores it transposed
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int zz = (threadIdx.x >> 4) + 16 * i, pc = threadIdx.x & 15;
+        const ull2 v = reinterpret_cast<const ull2*>(T + ((z0 + zz) << k) + y0)[pc];
+        lds_b[(2 * pc) * TS + zz] = v.x;
+        lds_b[(2 * pc + 1) * TS + zz] = v.y;
+      }
+      __syncthreads();
+      for (int yy = 0; yy < KT; ++yy) {
+        const ull2 a01 = lds_a[yy * (TS / 2) + 2 * tx], a23 = lds_a[yy * (TS / 2) + 2 * tx + 1];
+        const ull2 b01 = reinterpret_cast<const ull2*>(lds_b + yy * TS)[2 * ty],
+                   b23 = reinterpret_cast<const ull2*>(lds_b + yy * TS)[2 * ty + 1];
+        const u64 a[4] = {a01.x, a01.y, a23.x, a23.y}, b[4] = {b01.x, b01.y, b23.x, b23.y};
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i) f.acc_mac(acc[j][i], a[i], b[j]);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      ull2 o0 = {f.acc_get(acc[j][0]), f.acc_get(acc[j][1])}, o1 = {f.acc_get(acc[j][2]), f.acc_get(acc[j][3])};
+      ull2* dst = reinterpret_cast<ull2*>(P + ((z0 + 4 * ty + j) << k) + x0 + 4 * tx);
+      dst[0] = o0;
+      dst[1] = o1;
+    }
+  }
+}
+
 // Round sums H(0), H(1), H(inf) of G in ANY state (xv, yv, zv variables left), by walking every
 // remaining (x, y, z) like the reference does: the generic SumCheckPolynomial::to_univariate.
 // Two of the three copies hold the current variable (pairs p, q), the third a constant c.

@@ -3119,9 +3119,22 @@ extern "C" int sc_tri_prover_create(sc_ctx* ctx, const sc_table* adj, size_t var
   tp->k = (int)var_len;
   int rc = pool_alloc(ctx, adj->len, &tp->P);
   if (rc == SC_OK) {
-    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::matsq_kernel<F>), dim3(grid_for_wide(ctx, adj->len)), dim3(sc::kBlock), 0,
-                                                    ctx->stream, f, (const u64*)adj->d, tp->k, tp->P));
-    if (hipGetLastError() != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "matsq_kernel launch failed");
+    const u64 n3 = (u64)1 << (3 * var_len);
+    rc = timer_begin(ctx, SC_KIND_MATSQ, tp->k, 0, log2_of(adj->len), (u64)8 * adj->len, (u64)8 * adj->len);
+    (void)n3;
+    if (rc == SC_OK) {
+      if (var_len >= 6) {
+        const size_t tiles = (adj->len >> 12);   // 64 x 64 output tiles
+        const int grid = (int)std::min<size_t>(tiles, (size_t)4 * ctx->num_cus);
+        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::matsq_tiled_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                        (const u64*)adj->d, tp->k, tp->P));
+      } else {
+        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::matsq_kernel<F>), dim3(grid_for_wide(ctx, adj->len)), dim3(sc::kBlock),
+                                                        0, ctx->stream, f, (const u64*)adj->d, tp->k, tp->P));
+      }
+      if (hipGetLastError() != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "matsq kernel launch failed");
+    }
+    if (rc == SC_OK) rc = timer_end(ctx);
   }
   // x phase: sum_{x,z} P(x,z) f3(x,z), both indexed (z << k) | x
   if (rc == SC_OK) rc = tri_start_phase(tp, tp->P, tp->adj, adj->len);
