@@ -381,11 +381,11 @@ def run_mle(args, pkg, torch, dist, rank, world, local_rank):
         outs += [t.fix_variables(pt[:k]) for k in ks]
         return outs
 
+    ctx.set_option("time_kernels", 1)     # five launches per step, each hundreds of microseconds: probe cost is negligible
     for _ in range(args.warmup):
         step()
     ctx.launch_log(reset=True)
     ctx.kernel_time(reset=True)
-    ctx.set_option("time_kernels", 1)     # five launches per step, each hundreds of microseconds: probe cost is negligible
     step_ms = []
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -398,6 +398,8 @@ def run_mle(args, pkg, torch, dist, rank, world, local_rank):
     ctx.set_option("time_kernels", 0)
     n_launch, kernel_ms = ctx.kernel_time(reset=True)
     log = ctx.launch_log(reset=True)
+    if os.environ.get("SC_BENCH_DEBUG"):
+        sys.stderr.write("step_ms: %s\n" % " ".join("%.3f" % x for x in step_ms))
 
     muladds = 2 * (2**n - 1) + sum(2**n - 2**(n - k) for k in ks)
     alg_bytes = 2 * 8 * 2**n + sum(8 * 2**n + 8 * 2**(n - k) for k in ks)
