@@ -21,6 +21,19 @@ pub struct sc_field {
     pub r2_mod_p: u64,
 }
 
+/// One timed launch (`sc_ctx_launch_log`); `kind` is one of the `SC_KIND_*` values of the header.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct sc_launch_record {
+    pub kind: i32,
+    pub kf: i32,
+    pub ks: i32,
+    pub log_in: i32,
+    pub bytes_read: u64,
+    pub bytes_written: u64,
+    pub ms: f64,
+}
+
 #[repr(C)]
 pub struct sc_ctx {
     _private: [u8; 0],
@@ -61,6 +74,13 @@ extern "C" {
     pub fn sc_ctx_synchronize(ctx: *mut sc_ctx) -> c_int;
     pub fn sc_ctx_stream(ctx: *const sc_ctx) -> *mut c_void;
     pub fn sc_ctx_kernel_time(ctx: *mut sc_ctx, out: *mut f64, reset: c_int) -> c_int;
+    pub fn sc_ctx_launch_log(
+        ctx: *mut sc_ctx,
+        out: *mut sc_launch_record,
+        cap: usize,
+        n_out: *mut usize,
+        reset: c_int,
+    ) -> c_int;
 
     pub fn sc_comm_unique_id(id: *mut u8) -> c_int;
     pub fn sc_ctx_comm_init_rccl(ctx: *mut sc_ctx, id: *const u8, rank: c_int, world: c_int) -> c_int;
@@ -72,6 +92,9 @@ extern "C" {
         allgather: sc_allgather_fn,
         user: *mut c_void,
     ) -> c_int;
+    pub fn sc_ctx_comm_peer_export(ctx: *mut sc_ctx, rank: c_int, world: c_int, handle: *mut u8) -> c_int;
+    pub fn sc_ctx_comm_peer_connect(ctx: *mut sc_ctx, handles: *const u8) -> c_int;
+    pub fn sc_ctx_comm_peer_connect_local(ctx: *mut sc_ctx, peers: *const *mut sc_ctx) -> c_int;
     pub fn sc_ctx_comm_rank(ctx: *const sc_ctx, rank: *mut c_int, world: *mut c_int) -> c_int;
 
     pub fn sc_table_upload(ctx: *mut sc_ctx, host: *const u64, len: usize, out: *mut *mut sc_table) -> c_int;
@@ -220,6 +243,17 @@ extern "C" {
         mul: *const sc_table,
         w_b: *const sc_table,
         w_c: *const sc_table,
+        out: *mut *mut sc_gkr_prover,
+    ) -> c_int;
+    pub fn sc_gkr_prover_create_sparse(
+        ctx: *mut sc_ctx,
+        gate_type: *const i32,
+        in0: *const u32,
+        in1: *const u32,
+        k_i: usize,
+        k_next: usize,
+        r_i: *const u64,
+        w_next: *const sc_table,
         out: *mut *mut sc_gkr_prover,
     ) -> c_int;
     pub fn sc_gkr_prover_c1(pr: *const sc_gkr_prover, out: *mut u64) -> c_int;

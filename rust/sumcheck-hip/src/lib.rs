@@ -258,3 +258,372 @@ impl<T: MontConfig<1>> sum_check_protocol::RoundEngine<F64<T>> for ProverEngine<
         round_poly::<T>(e)
     }
 }
+
+// =====================================================================================
+// gkr_protocol::round_polynomial::W and triangle_counting::G on the device
+// =====================================================================================
+
+impl<T: MontConfig<1>> DeviceMle<T> {
+    fn from_raw(ctx: &Context<T>, h: *mut sys::sc_table) -> Self {
+        Self { ctx: ctx.clone(), h }
+    }
+    /// `restrict_poly(b, c, &mle)` (gkr-protocol/src/lib.rs:291-321): the MLE on the line l(0) = b, l(1) = c.
+    pub fn restrict_to_line(&self, b: &[F64<T>], c: &[F64<T>]) -> SparsePolynomial<F64<T>> {
+        let k = self.num_vars();
+        assert_eq!(b.len(), k);
+        assert_eq!(c.len(), k);
+        let (bw, cw) = (words::<T>(b), words::<T>(c));
+        let mut out = vec![0u64; k + 1];
+        let rc = unsafe {
+            sys::sc_table_restrict_to_line(self.ctx.raw(), self.h, bw.as_ptr(), cw.as_ptr(), k, out.as_mut_ptr())
+        };
+        self.ctx.check(rc, "sc_table_restrict_to_line");
+        SparsePolynomial::from_coefficients_vec(out.iter().enumerate().map(|(d, w)| (d, from_word::<T>(*w))).collect())
+    }
+}
+
+/// `line(b, c)` (gkr-protocol/src/lib.rs:278-289) - host arithmetic only.
+pub fn line<T: MontConfig<1>>(b: &[F64<T>], c: &[F64<T>]) -> Vec<SparsePolynomial<F64<T>>> {
+    std::iter::zip(b, c)
+        .map(|(b, c)| SparsePolynomial::from_coefficients_slice(&[(0, *b), (1, *c - b)]))
+        .collect()
+}
+
+/// One gate of a layered circuit as the wiring predicate sees it (gkr-protocol/src/circuit.rs:17-31).
+#[derive(Clone, Copy)]
+pub struct WiringGate {
+    pub is_mul: bool,
+    pub inputs: [u32; 2],
+}
+
+/// `add_i(r_i, ., .)` and `mul_i(r_i, ., .)` of `Prover::start_round` / `Circuit::{add,mul}_i_ext`
+/// (gkr-protocol/src/lib.rs:388-416, circuit.rs:156-213) straight from layer i's gate list.
+pub fn gkr_wiring<T: MontConfig<1>>(
+    ctx: &Context<T>,
+    gates: &[WiringGate],
+    k_next: usize,
+    r_i: &[F64<T>],
+) -> (DeviceMle<T>, DeviceMle<T>) {
+    let k_i = gates.len().trailing_zeros() as usize;
+    assert_eq!(gates.len(), 1 << k_i);
+    assert_eq!(r_i.len(), k_i);
+    let ty: Vec<i32> = gates.iter().map(|g| g.is_mul as i32).collect();
+    let i0: Vec<u32> = gates.iter().map(|g| g.inputs[0]).collect();
+    let i1: Vec<u32> = gates.iter().map(|g| g.inputs[1]).collect();
+    let r = words::<T>(r_i);
+    let (mut ha, mut hm) = (ptr::null_mut(), ptr::null_mut());
+    let rc = unsafe {
+        sys::sc_gkr_wiring(ctx.raw(), ty.as_ptr(), i0.as_ptr(), i1.as_ptr(), k_i, k_next, r.as_ptr(), &mut ha, &mut hm)
+    };
+    ctx.check(rc, "sc_gkr_wiring");
+    (DeviceMle::from_raw(ctx, ha), DeviceMle::from_raw(ctx, hm))
+}
+
+/// GPU-backed `gkr_protocol::round_polynomial::W` (round_polynomial.rs:23-44); same field names.
+pub struct GpuW<T: MontConfig<1>> {
+    add_i: Rc<DeviceMle<T>>,
+    mul_i: Rc<DeviceMle<T>>,
+    w_b: Rc<DeviceMle<T>>,
+    w_c: Rc<DeviceMle<T>>,
+}
+impl<T: MontConfig<1>> Clone for GpuW<T> {
+    fn clone(&self) -> Self {
+        Self { add_i: self.add_i.clone(), mul_i: self.mul_i.clone(), w_b: self.w_b.clone(), w_c: self.w_c.clone() }
+    }
+}
+impl<T: MontConfig<1>> GpuW<T> {
+    /// `W::new` (round_polynomial.rs:31-43)
+    pub fn new(add_i: DeviceMle<T>, mul_i: DeviceMle<T>, w_b: Rc<DeviceMle<T>>, w_c: Rc<DeviceMle<T>>) -> Self {
+        Self { add_i: Rc::new(add_i), mul_i: Rc::new(mul_i), w_b, w_c }
+    }
+    fn ctx(&self) -> &Context<T> {
+        &self.add_i.ctx
+    }
+    fn handles(&self) -> (*mut sys::sc_table, *mut sys::sc_table, *mut sys::sc_table, *mut sys::sc_table) {
+        (self.add_i.h, self.mul_i.h, self.w_b.h, self.w_c.h)
+    }
+}
+impl<T: MontConfig<1>> SumCheckPolynomial<F64<T>> for GpuW<T> {
+    fn evaluate(&self, point: &[F64<T>]) -> Option<F64<T>> {
+        if point.len() != self.num_vars() {
+            return None;
+        }
+        let (a, m, b, c) = self.handles();
+        let pt = words::<T>(point);
+        let mut out = 0u64;
+        let rc = unsafe { sys::sc_gkr_w_evaluate(self.ctx().raw(), a, m, b, c, pt.as_ptr(), pt.len(), &mut out) };
+        self.ctx().check(rc, "sc_gkr_w_evaluate");
+        Some(from_word::<T>(out))
+    }
+    fn fix_variables(&self, partial_point: &[F64<T>]) -> Self {
+        let (a, m, b, c) = self.handles();
+        let r = words::<T>(partial_point);
+        let mut h = [ptr::null_mut(); 4];
+        let rc = unsafe {
+            sys::sc_gkr_w_fix_variables(
+                self.ctx().raw(), a, m, b, c, r.as_ptr(), r.len(), &mut h[0], &mut h[1], &mut h[2], &mut h[3],
+            )
+        };
+        self.ctx().check(rc, "sc_gkr_w_fix_variables");
+        let t = |x| Rc::new(DeviceMle::from_raw(self.ctx(), x));
+        Self { add_i: t(h[0]), mul_i: t(h[1]), w_b: t(h[2]), w_c: t(h[3]) }
+    }
+    fn to_univariate(&self) -> SparsePolynomial<F64<T>> {
+        let (a, m, b, c) = self.handles();
+        let mut e = [0u64; 3];
+        let rc = unsafe { sys::sc_gkr_w_round_sums(self.ctx().raw(), a, m, b, c, e.as_mut_ptr()) };
+        self.ctx().check(rc, "sc_gkr_w_round_sums");
+        round_poly::<T>(e)
+    }
+    fn num_vars(&self) -> usize {
+        self.add_i.num_vars()
+    }
+    fn to_evaluations(&self) -> Vec<F64<T>> {
+        let (a, m, b, c) = self.handles();
+        let mut h = ptr::null_mut();
+        let rc = unsafe { sys::sc_gkr_w_to_evaluations(self.ctx().raw(), a, m, b, c, &mut h) };
+        self.ctx().check(rc, "sc_gkr_w_to_evaluations");
+        DeviceMle::from_raw(self.ctx(), h).to_evaluations()
+    }
+    fn native_engine(&self) -> Option<Box<dyn sum_check_protocol::RoundEngine<F64<T>>>> {
+        Some(Box::new(WEngine::new(self)))
+    }
+}
+
+/// `sc_gkr_prover`: the two-phase W prover behind `SumCheckProver<F, W<F>>::round`.
+pub struct WEngine<T: MontConfig<1>> {
+    w: GpuW<T>,
+    h: *mut sys::sc_gkr_prover,
+}
+impl<T: MontConfig<1>> WEngine<T> {
+    pub fn new(w: &GpuW<T>) -> Self {
+        let (a, m, b, c) = w.handles();
+        let mut h = ptr::null_mut();
+        let rc = unsafe { sys::sc_gkr_prover_create(w.ctx().raw(), a, m, b, c, &mut h) };
+        w.ctx().check(rc, "sc_gkr_prover_create");
+        Self { w: w.clone(), h }
+    }
+    /// the same prover from layer i's gate list (`sc_gkr_prover_create_sparse`): the dense predicate tables are never built
+    pub fn from_gates(ctx: &Context<T>, gates: &[WiringGate], k_next: usize, r_i: &[F64<T>], w_next: Rc<DeviceMle<T>>) -> SparseWEngine<T> {
+        let k_i = gates.len().trailing_zeros() as usize;
+        let ty: Vec<i32> = gates.iter().map(|g| g.is_mul as i32).collect();
+        let i0: Vec<u32> = gates.iter().map(|g| g.inputs[0]).collect();
+        let i1: Vec<u32> = gates.iter().map(|g| g.inputs[1]).collect();
+        let r = words::<T>(r_i);
+        let mut h = ptr::null_mut();
+        let rc = unsafe {
+            sys::sc_gkr_prover_create_sparse(
+                ctx.raw(), ty.as_ptr(), i0.as_ptr(), i1.as_ptr(), k_i, k_next, r.as_ptr(), w_next.h, &mut h,
+            )
+        };
+        ctx.check(rc, "sc_gkr_prover_create_sparse");
+        SparseWEngine { w_next, h }
+    }
+}
+impl<T: MontConfig<1>> Drop for WEngine<T> {
+    fn drop(&mut self) {
+        unsafe { sys::sc_gkr_prover_destroy(self.h) };
+    }
+}
+fn gkr_c1<T: MontConfig<1>>(ctx: &Context<T>, h: *mut sys::sc_gkr_prover) -> F64<T> {
+    let mut out = 0u64;
+    let rc = unsafe { sys::sc_gkr_prover_c1(h, &mut out) };
+    ctx.check(rc, "sc_gkr_prover_c1");
+    from_word::<T>(out)
+}
+fn gkr_round<T: MontConfig<1>>(ctx: &Context<T>, h: *mut sys::sc_gkr_prover, r_prev: F64<T>, j: usize) -> SparsePolynomial<F64<T>> {
+    let mut e = [0u64; 3];
+    let rc = unsafe { sys::sc_gkr_prover_round(h, word::<T>(&r_prev), j, e.as_mut_ptr()) };
+    ctx.check(rc, "sc_gkr_prover_round");
+    round_poly::<T>(e)
+}
+impl<T: MontConfig<1>> sum_check_protocol::RoundEngine<F64<T>> for WEngine<T> {
+    fn c_1(&self) -> F64<T> {
+        gkr_c1(self.w.ctx(), self.h)
+    }
+    fn round(&mut self, r_prev: F64<T>, j: usize) -> SparsePolynomial<F64<T>> {
+        gkr_round(self.w.ctx(), self.h, r_prev, j)
+    }
+}
+pub struct SparseWEngine<T: MontConfig<1>> {
+    w_next: Rc<DeviceMle<T>>,
+    h: *mut sys::sc_gkr_prover,
+}
+impl<T: MontConfig<1>> Drop for SparseWEngine<T> {
+    fn drop(&mut self) {
+        unsafe { sys::sc_gkr_prover_destroy(self.h) };
+    }
+}
+impl<T: MontConfig<1>> sum_check_protocol::RoundEngine<F64<T>> for SparseWEngine<T> {
+    fn c_1(&self) -> F64<T> {
+        gkr_c1(&self.w_next.ctx, self.h)
+    }
+    fn round(&mut self, r_prev: F64<T>, j: usize) -> SparsePolynomial<F64<T>> {
+        gkr_round(&self.w_next.ctx, self.h, r_prev, j)
+    }
+}
+
+/// GPU-backed `triangle_counting::G` (triangle-counting/src/lib.rs:22-27); same field names.
+pub struct GpuTriangleG<T: MontConfig<1>> {
+    f_a_1: Rc<DeviceMle<T>>,
+    f_a_2: Rc<DeviceMle<T>>,
+    f_a_3: Rc<DeviceMle<T>>,
+    var_len: usize,
+}
+impl<T: MontConfig<1>> Clone for GpuTriangleG<T> {
+    fn clone(&self) -> Self {
+        Self { f_a_1: self.f_a_1.clone(), f_a_2: self.f_a_2.clone(), f_a_3: self.f_a_3.clone(), var_len: self.var_len }
+    }
+}
+impl<T: MontConfig<1>> GpuTriangleG<T> {
+    /// `G::new_adj_matrix` (:32-51): `matrix` row-major, 2^(num_vars/2) vertices.
+    pub fn new_adj_matrix(ctx: &Context<T>, num_vars: usize, matrix: &[bool]) -> Self {
+        use ark_ff::{One, Zero};
+        let evals = matrix.iter().map(|e| if *e { F64::<T>::one() } else { F64::<T>::zero() }).collect();
+        let g = Rc::new(DeviceMle::from_evaluations_vec(ctx, num_vars, evals));
+        Self { f_a_1: g.clone(), f_a_2: g.clone(), f_a_3: g, var_len: num_vars / 2 }
+    }
+    fn ctx(&self) -> &Context<T> {
+        &self.f_a_1.ctx
+    }
+    fn x_vars_num(&self) -> usize {
+        self.f_a_1.num_vars().saturating_sub(self.var_len) // :53-55
+    }
+    fn y_vars_num(&self) -> usize {
+        self.f_a_2.num_vars().saturating_sub(self.var_len) // :57-59
+    }
+    fn z_vars_num(&self) -> usize {
+        self.f_a_3.num_vars().min(self.var_len) // :61-67
+    }
+}
+impl<T: MontConfig<1>> SumCheckPolynomial<F64<T>> for GpuTriangleG<T> {
+    fn evaluate(&self, point: &[F64<T>]) -> Option<F64<T>> {
+        if point.len() != self.num_vars() {
+            return None;
+        }
+        let pt = words::<T>(point);
+        let mut out = 0u64;
+        let rc = unsafe {
+            sys::sc_tri_evaluate(self.ctx().raw(), self.f_a_1.h, self.f_a_2.h, self.f_a_3.h, self.var_len, pt.as_ptr(), pt.len(), &mut out)
+        };
+        self.ctx().check(rc, "sc_tri_evaluate");
+        Some(from_word::<T>(out))
+    }
+    fn fix_variables(&self, partial_point: &[F64<T>]) -> Self {
+        let r = words::<T>(partial_point);
+        let mut h = [ptr::null_mut(); 3];
+        let rc = unsafe {
+            sys::sc_tri_fix_variables(
+                self.ctx().raw(), self.f_a_1.h, self.f_a_2.h, self.f_a_3.h, self.var_len, r.as_ptr(), r.len(),
+                &mut h[0], &mut h[1], &mut h[2],
+            )
+        };
+        self.ctx().check(rc, "sc_tri_fix_variables");
+        let t = |x| Rc::new(DeviceMle::from_raw(self.ctx(), x));
+        Self { f_a_1: t(h[0]), f_a_2: t(h[1]), f_a_3: t(h[2]), var_len: self.var_len }
+    }
+    fn to_univariate(&self) -> SparsePolynomial<F64<T>> {
+        let mut e = [0u64; 3];
+        let rc = unsafe {
+            sys::sc_tri_round_sums(self.ctx().raw(), self.f_a_1.h, self.f_a_2.h, self.f_a_3.h, self.var_len, e.as_mut_ptr())
+        };
+        self.ctx().check(rc, "sc_tri_round_sums");
+        round_poly::<T>(e)
+    }
+    fn num_vars(&self) -> usize {
+        self.x_vars_num() + self.y_vars_num() + self.z_vars_num()
+    }
+    fn to_evaluations(&self) -> Vec<F64<T>> {
+        let mut h = ptr::null_mut();
+        let rc = unsafe {
+            sys::sc_tri_to_evaluations(self.ctx().raw(), self.f_a_1.h, self.f_a_2.h, self.f_a_3.h, self.var_len, &mut h)
+        };
+        self.ctx().check(rc, "sc_tri_to_evaluations");
+        DeviceMle::from_raw(self.ctx(), h).to_evaluations()
+    }
+    /// The fast engine applies to the polynomial as `new_adj_matrix` builds it (three views of one table,
+    /// nothing fixed yet); any other state goes through the generic path.
+    fn native_engine(&self) -> Option<Box<dyn sum_check_protocol::RoundEngine<F64<T>>>> {
+        let fresh = Rc::ptr_eq(&self.f_a_1, &self.f_a_2)
+            && Rc::ptr_eq(&self.f_a_2, &self.f_a_3)
+            && self.var_len >= 1
+            && self.f_a_1.num_vars() == 2 * self.var_len;
+        if !fresh {
+            return None;
+        }
+        let mut h = ptr::null_mut();
+        let rc = unsafe { sys::sc_tri_prover_create(self.ctx().raw(), self.f_a_1.h, self.var_len, &mut h) };
+        self.ctx().check(rc, "sc_tri_prover_create");
+        Some(Box::new(TriEngine { adj: self.f_a_1.clone(), h }))
+    }
+}
+/// `sc_tri_prover`: one n^3 pass + three product-of-two-tables sumchecks.
+pub struct TriEngine<T: MontConfig<1>> {
+    adj: Rc<DeviceMle<T>>,
+    h: *mut sys::sc_tri_prover,
+}
+impl<T: MontConfig<1>> Drop for TriEngine<T> {
+    fn drop(&mut self) {
+        unsafe { sys::sc_tri_prover_destroy(self.h) };
+    }
+}
+impl<T: MontConfig<1>> sum_check_protocol::RoundEngine<F64<T>> for TriEngine<T> {
+    fn c_1(&self) -> F64<T> {
+        let mut out = 0u64;
+        let rc = unsafe { sys::sc_tri_prover_c1(self.h, &mut out) };
+        self.adj.ctx.check(rc, "sc_tri_prover_c1");
+        from_word::<T>(out)
+    }
+    fn round(&mut self, r_prev: F64<T>, j: usize) -> SparsePolynomial<F64<T>> {
+        let mut e = [0u64; 3];
+        let rc = unsafe { sys::sc_tri_prover_round(self.h, word::<T>(&r_prev), j, e.as_mut_ptr()) };
+        self.adj.ctx.check(rc, "sc_tri_prover_round");
+        round_poly::<T>(e)
+    }
+}
+
+// =====================================================================================
+// multilinear_extensions::{vsbw_, cti_}multilinear_from_evaluations (multilinear-extensions/src/lib.rs:6, :29)
+// =====================================================================================
+
+impl<T: MontConfig<1>> Context<T> {
+    /// A per-thread default context on device 0 for the free functions below, which keep the reference's
+    /// signatures (no context argument).  One per thread and field type, created on first use.
+    pub fn thread_default() -> Self {
+        use std::any::{Any, TypeId};
+        use std::cell::RefCell;
+        use std::collections::HashMap;
+        thread_local! {
+            static CTXS: RefCell<HashMap<TypeId, Box<dyn Any>>> = RefCell::new(HashMap::new());
+        }
+        CTXS.with(|m| {
+            let mut m = m.borrow_mut();
+            m.entry(TypeId::of::<T>())
+                .or_insert_with(|| Box::new(Context::<T>::new(0)))
+                .downcast_ref::<Context<T>>()
+                .expect("context of this field type")
+                .clone()
+        })
+    }
+}
+
+/// BE evaluation of a table: r[0] pairs with the most significant index bit.
+fn evaluate_be<T: MontConfig<1>>(evals: &[F64<T>], r: &[F64<T>]) -> F64<T> {
+    assert_eq!(evals.len(), 1usize << r.len());
+    let ctx = Context::<T>::thread_default();
+    let t = DeviceMle::from_evaluations_vec(&ctx, r.len(), evals.to_vec());
+    let pt = words::<T>(r);
+    let mut out = 0u64;
+    let rc = unsafe { sys::sc_table_evaluate(ctx.raw(), t.h, pt.as_ptr(), pt.len(), sys::SC_ORDER_BE, &mut out) };
+    ctx.check(rc, "sc_table_evaluate");
+    from_word::<T>(out)
+}
+/// `multilinear_extensions::vsbw_multilinear_from_evaluations(evals, r)` (:6-24)
+pub fn vsbw_multilinear_from_evaluations<T: MontConfig<1>>(evals: &[F64<T>], r: &[F64<T>]) -> F64<T> {
+    evaluate_be::<T>(evals, r)
+}
+/// `multilinear_extensions::cti_multilinear_from_evaluations(evals, r)` (:29-48): the same polynomial,
+/// the same value - one streaming pass instead of O(n 2^n) Lagrange products.
+pub fn cti_multilinear_from_evaluations<T: MontConfig<1>>(evals: &[F64<T>], r: &[F64<T>]) -> F64<T> {
+    evaluate_be::<T>(evals, r)
+}

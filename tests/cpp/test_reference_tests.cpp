@@ -4,11 +4,15 @@
 //   matrix-multiplication/src/lib.rs:202-243   matrix_test_from_book
 //   matrix-multiplication/src/lib.rs:245-303   example_from_book
 //   matrix-multiplication/src/lib.rs:315-374   randomized_test (2^2..2^5, every (i,j))
+//   triangle-counting/src/lib.rs:232-317       test_simple_matrix, randomized_test (2..64 vertices)
+//   gkr-protocol/src/lib.rs:507-702            test_restrict_poly, protocol_test_from_book, three_layer_protocol_test
 #include <cstdio>
 #include <cstdlib>
 #include <random>
 
+#include "../../thaler-study_amd/host/gkr_protocol.hpp"
 #include "../../thaler-study_amd/host/matrix_multiplication.hpp"
+#include "../../thaler-study_amd/host/triangle_counting.hpp"
 
 using namespace sum_check_protocol;
 using matrix_multiplication::G;
@@ -60,6 +64,123 @@ static void run_protocol(const Field& f, const G& g, F c_1_expected, bool check_
     VerifierRoundResult res = verifier.round(g_j, rng);
     if (res.kind == VerifierRoundResult::JthRound) r_j = res.r;
     else REQUIRE(res.ok);
+  }
+}
+
+static void run_generic(const Field& f, const SumCheckPolynomial& g, RngF& rng, F* c_1_out) {
+  Prover prover(g.clone());
+  F c_1 = prover.c_1();
+  size_t num_vars = g.num_vars();
+  F r_j = f.one();
+  Verifier verifier(num_vars, g.clone(), f);
+  verifier.set_c_1(c_1);
+  bool final_seen = false;
+  for (size_t j = 0; j < num_vars; ++j) {
+    VerifierRoundResult res = verifier.round(prover.round(r_j, j), rng);
+    if (res.kind == VerifierRoundResult::JthRound) r_j = res.r;
+    else { REQUIRE(res.ok); final_seen = true; }
+  }
+  REQUIRE(final_seen);
+  if (c_1_out) *c_1_out = c_1;
+}
+
+static void triangle_tests() {
+  {  // triangle-counting/src/lib.rs:232-266 test_simple_matrix
+    Field f(389);
+    Context ctx(f);
+    StdRng rng(f, 1);
+    std::vector<bool> adj = {false, true, true, false, true, false, true, false, true, true, false, false, false, false, false, false};
+    triangle_counting::G g = triangle_counting::G::new_adj_matrix(ctx, 4, adj);
+    F c_1 = 0;
+    run_generic(f, g, rng, &c_1);
+    REQUIRE(f.to_int(c_1) == 6);
+    std::printf("ok triangle_counting::test_simple_matrix\n");
+  }
+  {  // :268-317 randomized_test
+    Field f(1572869);
+    Context ctx(f);
+    StdRng rng(f, 2);
+    std::mt19937_64 gen(11);
+    for (size_t k = 1; k <= 6; ++k) {
+      size_t n = (size_t)1 << k;
+      std::vector<std::vector<bool>> m(n, std::vector<bool>(n, false));
+      for (size_t i = 0; i < n; ++i)
+        for (size_t j = i + 1; j < n; ++j) m[i][j] = m[j][i] = (gen() & 1) != 0;
+      uint64_t tri = 0;
+      for (size_t x = 0; x < n; ++x)
+        for (size_t y = 0; y < n; ++y)
+          for (size_t z = 0; z < n; ++z) tri += (m[x][y] && m[y][z] && m[x][z]) ? 1 : 0;
+      std::vector<bool> flat;
+      for (auto& row : m) flat.insert(flat.end(), row.begin(), row.end());
+      triangle_counting::G g = triangle_counting::G::new_adj_matrix(ctx, 2 * k, flat);
+      F c_1 = 0;
+      run_generic(f, g, rng, &c_1);
+      REQUIRE(f.to_int(c_1) == tri);   // 6 * triangle count = ordered triples
+      if (k <= 3) {                    // the generic trait path (fix_variables -> to_univariate) agrees
+        struct NoEngine : triangle_counting::G { using G::G; NoEngine(const G& g) : G(g) {} std::unique_ptr<RoundEngine> native_engine() const override { return nullptr; }
+          std::unique_ptr<SumCheckPolynomial> clone() const override { return std::make_unique<NoEngine>(*this); } };
+        F c_2 = 0;
+        run_generic(f, NoEngine(g), rng, &c_2);
+        REQUIRE(c_2 == c_1);
+      }
+    }
+    std::printf("ok triangle_counting::randomized_test\n");
+  }
+}
+
+static void gkr_tests() {
+  using namespace gkr_protocol;
+  Field f(389);
+  Context ctx(f);
+  {  // gkr-protocol/src/lib.rs:507-548 test_restrict_poly
+    std::vector<F> b = {f.from_int(2), f.from_int(4)}, c = {f.from_int(3), f.from_int(2)};
+    auto mle = sumcheck_hip::DeviceMle::from_evaluations_vec(ctx, 2, {f.from_int(0), f.from_int(0), f.from_int(2), f.from_int(5)});
+    SparsePolynomial q = restrict_poly(b, c, *mle);
+    uint64_t dense[3] = {0, 0, 0};
+    for (auto& t : q.coeffs) dense[t.first] = f.to_int(t.second);
+    REQUIRE(dense[0] == 32 && dense[1] == 385 && dense[2] == 383);   // -6t^2 - 4t + 32
+    std::printf("ok gkr_protocol::test_restrict_poly\n");
+  }
+  auto G2 = [](GateType t, size_t a, size_t b) { return Gate{t, {a, b}}; };
+  Circuit book{{{G2(GateType::Mul, 0, 1), G2(GateType::Mul, 2, 3)},
+                {G2(GateType::Mul, 0, 0), G2(GateType::Mul, 1, 1), G2(GateType::Mul, 1, 2), G2(GateType::Mul, 3, 3)}}, 4};
+  Circuit three{{{G2(GateType::Add, 0, 1), G2(GateType::Add, 2, 3)},
+                 {G2(GateType::Add, 0, 1), G2(GateType::Add, 2, 3), G2(GateType::Add, 4, 5), G2(GateType::Add, 6, 7)}}, 8};
+  struct Case { const char* name; Circuit* c; std::vector<uint64_t> input; std::vector<uint64_t> outputs; };
+  Case cases[2] = {{"protocol_test_from_book", &book, {3, 2, 3, 1}, {36, 6}}, {"three_layer_protocol_test", &three, {0, 1, 0, 1, 0, 1, 0, 1}, {2, 2}}};
+  for (Case& cs : cases) {
+    for (uint64_t seed = 0; seed < 4; ++seed) {
+      StdRng rng(f, 100 + seed);
+      const Circuit& circuit = *cs.c;
+      std::vector<F> input;
+      for (uint64_t v : cs.input) input.push_back(f.from_int(v));
+      gkr_protocol::Prover prover(ctx, circuit, input);
+      ProverMessage begin = prover.start_protocol();                               // :587-596
+      REQUIRE(begin.circuit_outputs.size() == cs.outputs.size());
+      for (size_t i = 0; i < cs.outputs.size(); ++i) REQUIRE(f.to_int(begin.circuit_outputs[i]) == cs.outputs[i]);
+      gkr_protocol::Verifier verifier(ctx, circuit);
+      VerifierMessage vm = verifier.receive_prover_msg(begin, rng);
+      REQUIRE(vm.kind == VerifierMessage::R);
+      std::vector<F> r_i = vm.r;
+      for (size_t i = 0; i < circuit.layers.size(); ++i) {                         // :608-621
+        ProverMessage msg = prover.start_round(i, r_i);
+        size_t num_vars = 2 * *circuit.num_vars_at(i + 1);
+        verifier.receive_prover_msg(msg, rng);
+        for (size_t j = 0; j + 1 < num_vars; ++j) {
+          VerifierMessage v2 = verifier.receive_prover_msg(prover.round_msg(j), rng);
+          prover.receive_verifier_msg(v2);
+        }
+        prover.receive_verifier_msg(verifier.final_random_point(rng));
+        VerifierMessage v3 = verifier.receive_prover_msg(prover.round_msg(num_vars - 1), rng);
+        REQUIRE(v3.kind == VerifierMessage::R);
+        r_i = v3.r;
+      }
+      REQUIRE(verifier.check_input(input));                                        // :623
+      std::vector<F> bad = input;
+      bad[0] = f.add(bad[0], f.one());
+      REQUIRE(!verifier.check_input(bad));
+    }
+    std::printf("ok gkr_protocol::%s\n", cs.name);
   }
 }
 
@@ -139,6 +260,8 @@ int main() {
     REQUIRE(threw);
     std::printf("ok verifier error paths\n");
   }
+  triangle_tests();
+  gkr_tests();
   std::printf("ALL OK\n");
   return 0;
 }

@@ -68,3 +68,43 @@ def test_fails_loudly_without_gpu():
     with pytest.raises(pkg.SumcheckHipError) as ei:
         pkg.Context(pkg.Field(pkg.GOLDILOCKS))
     assert ei.value.code == 2 and "no CPU path" in str(ei.value)
+
+
+def test_rust_sys_crate_declares_the_same_abi():
+    """rust/sumcheck-hip-sys is source only (no Rust toolchain here): at least its declarations must be exactly
+    the header's entry points, and every FFI name the safe crate calls must be declared"""
+    sys_rs = open(os.path.join(ROOT, "rust", "sumcheck-hip-sys", "src", "lib.rs")).read()
+    declared = sorted(set(re.findall(r"pub fn (sc_[a-z0-9_]+)\s*\(", sys_rs)))
+    assert declared == header_functions(), set(declared) ^ set(header_functions())
+    safe = open(os.path.join(ROOT, "rust", "sumcheck-hip", "src", "lib.rs")).read()
+    used = set(re.findall(r"sys::(sc_[a-z0-9_]+)\s*\(", safe))
+    assert used and used <= set(declared), used - set(declared)
+    # every method of the SumCheckPolynomial trait is implemented for the three device-backed polynomials
+    for ty in ("GpuG", "GpuW", "GpuTriangleG"):
+        m = re.search(r"impl<T: MontConfig<1>> SumCheckPolynomial<F64<T>> for %s<T> \{(.*?)\n\}\n" % ty, safe, flags=re.S)
+        assert m, ty
+        for meth in ("fn evaluate", "fn fix_variables", "fn to_univariate", "fn num_vars", "fn to_evaluations", "fn native_engine"):
+            assert meth in m.group(1), (ty, meth)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/sum-check-protocol"), reason="the reference tree is only present in the build container")
+def test_round_engine_patch_applies_to_the_reference(tmp_path):
+    """rust/patches/sum-check-protocol-round-engine.patch is the ONLY edit the reference needs: it must apply
+    cleanly to sum-check-protocol/src/lib.rs and leave every other line untouched"""
+    import shutil
+    dst = tmp_path / "sum-check-protocol" / "src"
+    dst.mkdir(parents=True)
+    shutil.copy("/root/reference/sum-check-protocol/src/lib.rs", dst / "lib.rs")
+    patch = os.path.join(ROOT, "rust", "patches", "sum-check-protocol-round-engine.patch")
+    out = subprocess.run(["patch", "-p1", "-i", patch], cwd=tmp_path, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    new = (dst / "lib.rs").read_text().splitlines()
+    old = open("/root/reference/sum-check-protocol/src/lib.rs").read().splitlines()
+    import difflib
+    removed = [l for l in difflib.unified_diff(old, new, lineterm="", n=0) if l.startswith("-") and not l.startswith("---")]
+    # the only lines that go away: the struct's closing brace moves, and Prover::new's one-line c_1
+    assert len(removed) <= 4, removed
+    text = "\n".join(new)
+    for needle in ("pub trait RoundEngine<F: Field>", "fn hypercube_sum(&self) -> F", "fn native_engine(&self) -> Option<Box<dyn RoundEngine<F>>>",
+                   "engine: Option<Box<dyn RoundEngine<F>>>"):
+        assert needle in text
