@@ -125,24 +125,86 @@ def setup_transport(args, pkg, ctx_factory, rank, world, dist):
             ar, ag = D.torch_collectives()
             ctx.comm_init_host(rank, world, ar, ag)
             return ctx, "host(gloo)"
-        # data plane inside the library.  A rank that cannot create its communicator makes EVERY rank
-        # exit non-zero: a scaling run must never silently measure another transport
-        # (SC_BENCH_TRANSPORT=host requests the host transport explicitly).
-        ok, err = 1, ""
-        try:
-            if os.environ.get("SC_BENCH_FAIL_TRANSPORT_RANK") in (str(rank), "all"):
-                raise RuntimeError("injected transport failure (SC_BENCH_FAIL_TRANSPORT_RANK)")   # test hook
-            if want == "rccl":
-                D.attach_rccl(ctx, rank, world)
-                transport = "rccl"
+        # data plane inside the library.  Default: the peer transport (in-kernel exchange through IPC-mapped
+        # inboxes, no collective launch), validated by a small sharded proof before anything is timed; if
+        # that self-test fails on any rank every rank switches to RCCL and the line says so.  A rank that
+        # cannot create the transport it was asked for makes EVERY rank exit non-zero: a scaling run must
+        # never silently measure another transport (SC_BENCH_TRANSPORT=host requests the host transport).
+        def agree(ok):
+            flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return int(flag.item()) == 1
+
+        def self_test(c, ok):
+            """a small sharded proof through the transport; every rank executes the same collectives whatever
+            happens locally, so a one-sided failure cannot leave the others waiting in a rendezvous"""
+            mine, why = None, ""
+            if ok:
+                try:
+                    mm, syn = pkg.matrix_multiplication, pkg.synthetic
+                    nt = 16
+                    start, length = D.shard_range(nt, rank, world)
+                    a, b = syn.tables(c, length.bit_length() - 1, start=start)
+                    g = mm.G(a, b)
+                    c1, evals, ch = mm.prove(c, g, syn.SEED_R)
+                    problem = check_identities(c.field, c1, evals, ch, g.evaluate([int(x) for x in ch]))
+                    if problem:
+                        raise RuntimeError("sharded self-test: " + problem)
+                    mine = (c1, evals.tobytes())
+                except Exception as e:  # pragma: no cover - depends on the node
+                    why = str(e)
+            seen = [None] * world
+            dist.all_gather_object(seen, mine)
+            if mine is None or any(x != seen[0] for x in seen):
+                return False, why or "ranks disagree on the self-test transcript"
+            return True, ""
+
+        err = ""
+        if os.environ.get("SC_BENCH_FAIL_TRANSPORT_RANK") in (str(rank), "all"):
+            ok, err = False, "injected transport failure (SC_BENCH_FAIL_TRANSPORT_RANK)"   # test hook
+            if not agree(ok):
+                raise SystemExit("bench.py: data-plane transport init failed on some rank: %s; set SC_BENCH_TRANSPORT=host "
+                                 "to run over the host (gloo) transport on purpose" % err)
+        if want in ("", "peer"):
+            ok, handle = True, None
+            try:
+                ctx.set_option("peer_spin_ms", 5000)
+                handle = ctx.comm_peer_export(rank, world)
+            except Exception as e:  # pragma: no cover - depends on the node
+                ok, err = False, str(e)
+            handles = [None] * world
+            dist.all_gather_object(handles, handle)
+            if ok and all(h is not None for h in handles):
+                try:
+                    ctx.comm_peer_connect(handles)
+                except Exception as e:  # pragma: no cover
+                    ok, err = False, str(e)
             else:
-                transport = D.attach_default(ctx, rank, world)
+                ok = False
+            ok, why = self_test(ctx, ok)
+            err = err or why
+            if not ok:
+                sys.stderr.write("rank %d: peer transport failed (%s)\n" % (rank, err))
+            if agree(ok):
+                return ctx, "peer"
+            if want == "peer":
+                raise SystemExit("bench.py: the peer transport failed on some rank%s" % ((": " + err) if err else ""))
+            ctx.close()
+            ctx = ctx_factory()
+            transport = "rccl (peer transport self-test failed on some rank%s)" % ((": " + err[:120]) if err else "")
+        else:
+            transport = "rccl"
+        ok = True
+        try:
+            D.attach_rccl(ctx, rank, world)
         except Exception as e:  # pragma: no cover - depends on the node
-            ok, err = 0, str(e)
-            sys.stderr.write("rank %d: transport init failed (%s)\n" % (rank, e))
-        flag = torch.tensor([ok], dtype=torch.int64)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) != 1:
+            ok, err = False, str(e)
+        if agree(ok):
+            ok, why = self_test(ctx, True)
+            err = err or why
+            ok = agree(ok)
+        if not ok:
+            sys.stderr.write("rank %d: RCCL transport failed (%s)\n" % (rank, err))
             raise SystemExit("bench.py: data-plane transport init failed on some rank%s; set SC_BENCH_TRANSPORT=host "
                              "to run over the host (gloo) transport on purpose" % ((": " + err) if err else ""))
     return ctx, transport
