@@ -130,3 +130,68 @@ def test_larger_graph_identities():
     rng = pkg.sum_check_protocol.FieldRng(F, random.Random(5))
     c_1 = run_protocol(pkg, g, rng)
     assert F.to_int(c_1) == 6 * tri
+
+
+@pytest.mark.parametrize("world,transport", [(2, "host"), (4, "host"), (2, "peer")])
+def test_triangle_prover_sharded(world, transport):
+    """the triangle engine on a sharded context: every rank holds its rows of the adjacency table, computes its
+    rows of the matrix square (the n^3 work, split across ranks), the square is gathered and the product sumchecks
+    run replicated; c_1 and every round polynomial equal the oracle's on every rank"""
+    import threading
+    from test_gpu_sharded import Loopback
+    pkg = load_package()
+    p = 1572869
+    o = oracle(p)
+    F0 = pkg.Field(p)
+    rng = random.Random(9)
+    for k in (2, 3, 6, 7):
+        nv = 1 << k
+        m = random_adj(rng, nv)
+        flat = np.array([F0.one if x else F0.zero for row in m for x in row], dtype=np.uint64)
+        ch = [F0.from_int(rng.randrange(p)) for _ in range(3 * k)]
+        ref = o.tri_prove(flat, k, ch)
+        lb = Loopback(world)
+        ctxs, errors, results = [None] * world, [], [None] * world
+
+        def body(rank):
+            try:
+                ctx = pkg.Context(pkg.Field(p))
+                if transport == "peer":
+                    ctx.set_option("peer_spin_ms", 20000)
+                    ctx.comm_peer_export(rank, world)
+                    ctxs[rank] = ctx
+                    lb.barrier.wait()
+                    ctx.comm_peer_connect_local(ctxs)
+                    lb.barrier.wait()
+                else:
+                    ar, ag = lb.collectives(rank)
+                    ctx.comm_init_host(rank, world, ar, ag)
+                n_loc = flat.size // world
+                shard = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2 * k - (world.bit_length() - 1), flat[rank * n_loc:(rank + 1) * n_loc])
+                g = pkg.triangle_counting.G(shard, shard, shard, k)
+                eng = pkg.triangle_counting._NativeTriProver(g)
+                got = [eng.c1()]
+                for j in range(3 * k):
+                    got.append(eng.round_evals(ch[j - 1] if j else F0.one, j))
+                results[rank] = got
+                if transport == "peer":
+                    lb.barrier.wait()
+                del eng, g, shard
+                ctx.close()
+            except Exception as e:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                errors.append(e)
+                lb.barrier.abort()
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=300)
+        assert not errors, errors
+        assert F0.to_int(ref["c_1"]) == 6 * triangle_count(m)
+        for got in results:
+            assert got[0] == ref["c_1"], k
+            for j in range(3 * k):
+                assert got[1 + j] == [int(x) for x in ref["evals"][j]], (k, j)

@@ -1603,9 +1603,9 @@ gkr_sparse_phase2_kernel(F f, const u64* __restrict__ val, const int* __restrict
 // Consecutive lanes own consecutive x: the column read is coalesced, the row read a broadcast.
 template <class F>
 __global__ void __launch_bounds__(kBlock)
-matsq_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P) {
-  const size_t n = (size_t)1 << k, total = n * n;
-  for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
+matsq_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P, size_t z_begin, size_t z_rows) {
+  const size_t n = (size_t)1 << k, first = z_begin * n, total = (z_begin + z_rows) * n;   // rows z_begin .. of P
+  for (size_t o = first + (size_t)blockIdx.x * kBlock + threadIdx.x; o < total; o += (size_t)gridDim.x * kBlock) {
     const size_t z = o >> k, x = o & (n - 1);
     typename F::Acc acc;
     f.acc_zero(acc);
@@ -1621,15 +1621,15 @@ matsq_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P) {
 // (15 instructions each) rather than at the L1 rate of the naive form.
 template <class F>
 __global__ void __launch_bounds__(kBlock)
-matsq_tiled_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P) {
+matsq_tiled_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P, size_t z_begin, size_t z_rows) {
   constexpr int TS = 64, KT = 32;
   __shared__ ull2 lds_a[KT * TS / 2];   // A[yy][xx], 16 KiB
   __shared__ u64 lds_b[KT * TS];        // Bt[yy][zz], 16 KiB
   const size_t n = (size_t)1 << k;
-  const int tiles = (int)(n / TS);
+  const int tiles = (int)(n / TS), tiles_z = (int)(z_rows / TS);   // rows z_begin .. z_begin + z_rows of P (a rank's share)
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  for (int tile = blockIdx.x; tile < tiles * tiles; tile += gridDim.x) {
-    const size_t x0 = (size_t)(tile % tiles) * TS, z0 = (size_t)(tile / tiles) * TS;
+  for (int tile = blockIdx.x; tile < tiles * tiles_z; tile += gridDim.x) {
+    const size_t x0 = (size_t)(tile % tiles) * TS, z0 = z_begin + (size_t)(tile / tiles) * TS;
     typename F::Acc acc[4][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j)

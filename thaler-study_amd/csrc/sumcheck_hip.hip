@@ -3071,6 +3071,7 @@ struct sc_tri_prover {
   sc_prover* sub = nullptr;  // current phase's engine
   sc_table ta, tb;           // views handed to sc_prover_create
   u64 *P = nullptr, *f3r = nullptr, *f1y = nullptr, *Q = nullptr, *f2r = nullptr;  // pool buffers
+  u64* adj_full = nullptr;   // sharded contexts: the gathered adjacency table
   u64 scale = 0;             // f1(r_x, r_y) in the z phase
   u64 c1 = 0;
 };
@@ -3105,44 +3106,83 @@ int tri_start_phase(sc_tri_prover* tp, const u64* a, const u64* b, size_t len) {
   tp->tb.len = len;
   if (tp->sub) sc_prover_destroy(tp->sub);
   tp->sub = nullptr;
-  return sc_prover_create(tp->ctx, &tp->ta, &tp->tb, &tp->sub);
+  return prover_create_impl(tp->ctx, &tp->ta, &tp->tb, /*replicated=*/true, &tp->sub);   // whole tables on every rank
 }
 
 }  // namespace
 
+// All-gather `len` words per rank into a pool buffer of len * world words (any transport)
+static int gather_to_pool(sc_ctx* ctx, const u64* local, size_t len, u64** out_full) {
+  if (ctx->transport == Transport::kPeer) {
+    const u64* fa = nullptr;
+    SC_TRY(peer_gather(ctx, local, nullptr, len, &fa, nullptr));
+    u64* full = nullptr;
+    SC_TRY(pool_alloc(ctx, len * ctx->world, &full));
+    hipError_t e = hipMemcpyAsync(full, fa, len * ctx->world * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream);
+    if (e != hipSuccess) {
+      pool_release(ctx, full);
+      return fail(ctx, SC_ERR_HIP, "gather copy: %s", hipGetErrorString(e));
+    }
+    *out_full = full;
+    return SC_OK;
+  }
+  return gather_table(ctx, local, len, out_full);
+}
+
+// On a sharded context `adj` is this rank's rows of the adjacency table (top log2(world) bits of the row index
+// = rank).  The n^3 work - the matrix square - is split by rows of P across the ranks; the adjacency table and
+// P are gathered (n^2 words each) and the three product sumchecks on 2^(2k)- and 2^k-entry tables run
+// replicated on every rank with no further exchange.
 extern "C" int sc_tri_prover_create(sc_ctx* ctx, const sc_table* adj, size_t var_len, sc_tri_prover** out) {
   if (!ctx || !out) return SC_ERR_ARG;
   SC_TRY(check_table(ctx, adj, "sc_tri_prover_create"));
-  if (is_sharded(ctx)) return fail(ctx, SC_ERR_UNSUPPORTED, "triangle prover on a sharded context");
-  if (var_len < 1 || var_len > 15 || adj->len != ((size_t)1 << (2 * var_len)))
-    return fail(ctx, SC_ERR_ARG, "sc_tri_prover_create: adjacency table must have 2^(2*var_len) entries");
+  const bool sharded = is_sharded(ctx) && ctx->world > 1;
+  const size_t full_len = (size_t)1 << (2 * var_len);
+  if (var_len < 1 || var_len > 15 || adj->len * (size_t)(sharded ? ctx->world : 1) != full_len)
+    return fail(ctx, SC_ERR_ARG, "sc_tri_prover_create: adjacency table must have 2^(2*var_len) entries (over all ranks)");
+  if (sharded && var_len < (size_t)ctx->log_world)
+    return fail(ctx, SC_ERR_ARG, "sc_tri_prover_create: fewer rows than ranks");
   SC_TRY(set_device(ctx));
   sc_tri_prover* tp = new (std::nothrow) sc_tri_prover;
   if (!tp) return fail(ctx, SC_ERR_OOM, "host allocation failed");
   tp->ctx = ctx;
   tp->adj = adj->d;
   tp->k = (int)var_len;
-  int rc = pool_alloc(ctx, adj->len, &tp->P);
+  int rc = SC_OK;
+  if (sharded) {
+    rc = gather_to_pool(ctx, adj->d, adj->len, &tp->adj_full);
+    tp->adj = tp->adj_full;
+  }
+  const size_t n = (size_t)1 << var_len;
+  const size_t z_rows = sharded ? n / ctx->world : n, z_begin = sharded ? (size_t)ctx->rank * z_rows : 0;
+  if (rc == SC_OK) rc = pool_alloc(ctx, full_len, &tp->P);
   if (rc == SC_OK) {
-    const u64 n3 = (u64)1 << (3 * var_len);
-    rc = timer_begin(ctx, SC_KIND_MATSQ, tp->k, 0, log2_of(adj->len), (u64)8 * adj->len, (u64)8 * adj->len);
-    (void)n3;
+    rc = timer_begin(ctx, SC_KIND_MATSQ, tp->k, 0, (int)(2 * var_len), (u64)8 * full_len, (u64)8 * z_rows * n);
     if (rc == SC_OK) {
-      if (var_len >= 6) {
-        const size_t tiles = (adj->len >> 12);   // 64 x 64 output tiles
+      if (var_len >= 6 && z_rows >= 64) {
+        const size_t tiles = (z_rows / 64) * (n / 64);   // 64 x 64 output tiles of this rank's rows
         const int grid = (int)std::min<size_t>(tiles, (size_t)4 * ctx->num_cus);
         SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::matsq_tiled_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
-                                                        (const u64*)adj->d, tp->k, tp->P));
+                                                        tp->adj, tp->k, tp->P, z_begin, z_rows));
       } else {
-        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::matsq_kernel<F>), dim3(grid_for_wide(ctx, adj->len)), dim3(sc::kBlock),
-                                                        0, ctx->stream, f, (const u64*)adj->d, tp->k, tp->P));
+        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::matsq_kernel<F>), dim3(grid_for_wide(ctx, z_rows * n)), dim3(sc::kBlock),
+                                                        0, ctx->stream, f, tp->adj, tp->k, tp->P, z_begin, z_rows));
       }
       if (hipGetLastError() != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "matsq kernel launch failed");
     }
     if (rc == SC_OK) rc = timer_end(ctx);
   }
+  if (rc == SC_OK && sharded) {
+    // every rank computed its rows of P: gather the whole square
+    u64* full = nullptr;
+    rc = gather_to_pool(ctx, tp->P + z_begin * n, z_rows * n, &full);
+    if (rc == SC_OK) {
+      pool_release(ctx, tp->P);
+      tp->P = full;
+    }
+  }
   // x phase: sum_{x,z} P(x,z) f3(x,z), both indexed (z << k) | x
-  if (rc == SC_OK) rc = tri_start_phase(tp, tp->P, tp->adj, adj->len);
+  if (rc == SC_OK) rc = tri_start_phase(tp, tp->P, tp->adj, full_len);
   if (rc != SC_OK) {
     sc_tri_prover_destroy(tp);
     return rc;
@@ -3235,6 +3275,7 @@ extern "C" int sc_tri_prover_destroy(sc_tri_prover* tp) {
   pool_release(tp->ctx, tp->f1y);
   pool_release(tp->ctx, tp->Q);
   pool_release(tp->ctx, tp->f2r);
+  pool_release(tp->ctx, tp->adj_full);
   delete tp;
   return SC_OK;
 }
