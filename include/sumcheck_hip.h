@@ -240,7 +240,10 @@ int sc_prove(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_draw_fn draw,
  *   f(b,c) = add_i(r_i,b,c) (W(b) + W(c)) + mul_i(r_i,b,c) W(b) W(c)
  * (gkr-protocol/src/round_polynomial.rs:13-44).  add/mul: tables of kb+kc variables indexed
  * (c << kb) | b; w_b: kb variables, w_c: kc variables (kb = kc = k_{i+1} when the sumcheck
- * starts; b variables are fixed first).  Not available on sharded contexts yet. */
+ * starts; b variables are fixed first).
+ * Sharded contexts: the prover (sc_gkr_prover_*) is available - add/mul are this rank's rows of c (top
+ * log2(world) index bits = rank), w_b and w_c whole on every rank; the generic trait methods (sc_gkr_w_*) and
+ * sc_gkr_wiring are single-rank only. */
 
 /* add_i(r_i,.,.) and mul_i(r_i,.,.) of Prover::start_round (gkr-protocol/src/lib.rs:388-416)
  * straight from the gate list of layer i (2^k_i gates: type 0 = add, 1 = mul; inputs index
@@ -265,7 +268,10 @@ int sc_gkr_w_fix_variables(sc_ctx* ctx, const sc_table* add, const sc_table* mul
 int sc_gkr_w_evaluate(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
                       const sc_table* w_c, const uint64_t* point, size_t n, uint64_t* out);
 /* SumCheckProver<F, W<F>> (gkr-protocol/src/lib.rs:418-456 drives it): same contract as
- * sc_prover_*: create computes c_1, rounds in order, r_prev ignored at j = 0. */
+ * sc_prover_*: create computes c_1, rounds in order, r_prev ignored at j = 0.  Two-phase linear-time form:
+ * add and mul are streamed twice per LAYER (once for P(b) = sum_c add + mul W(c) and L(b) = sum_c add W(c), once
+ * to fix b), the 2k rounds themselves run on 2^(k+1)-entry tables; round polynomials identical to the
+ * reference's per-round walk. */
 typedef struct sc_gkr_prover sc_gkr_prover;
 int sc_gkr_prover_create(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b,
                          const sc_table* w_c, sc_gkr_prover** out);
@@ -292,7 +298,9 @@ int sc_table_restrict_to_line(sc_ctx* ctx, const sc_table* t, const uint64_t* b,
  *   g(X,Y,Z) = f(X,Y) f(Y,Z) f(X,Z)   (triangle-counting/src/lib.rs:10-27)
  * three copies f1, f2, f3 of the adjacency MLE (2*var_len variables each before any fixing,
  * idx(i,j,nv) = (i << nv) | j, :168-172).  Variable counts of a partially fixed G follow
- * :53-67.  Not available on sharded contexts yet. */
+ * :53-67.  Sharded contexts: the prover (sc_tri_prover_*) is available - adj is this rank's rows of the
+ * adjacency table; the matrix square is split across the ranks, everything else runs replicated.  The generic
+ * trait methods (sc_tri_*) are single-rank only. */
 
 /* G::to_evaluations (:138-165), order x outer, z inner */
 int sc_tri_to_evaluations(sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const sc_table* f3, size_t var_len,
