@@ -748,6 +748,10 @@ int gather_table(sc_ctx* ctx, const u64* local, size_t len, u64** out_full) {
       return fail(ctx, SC_ERR_RCCL, "ncclAllGather: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     }
   } else {
+    if (!ctx->host_allgather) {
+      pool_release(ctx, full);
+      return fail(ctx, SC_ERR_STATE, "gather_table: no host collectives installed on this context");
+    }
     std::vector<u64> send(len), recv(len * ctx->world);
     SC_HIP(ctx, hipMemcpyAsync(send.data(), local, len * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -779,6 +783,7 @@ int allreduce_device(sc_ctx* ctx, u64* buf, size_t count) {
       return fail(ctx, SC_ERR_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?");
     return SC_OK;
   }
+  if (!ctx->host_allreduce) return fail(ctx, SC_ERR_STATE, "allreduce_device: no host collectives installed on this context");
   std::vector<u64> host(count);
   SC_HIP(ctx, hipMemcpyAsync(host.data(), buf, count * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
   SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1310,6 +1315,7 @@ extern "C" int sc_ctx_comm_peer_export(sc_ctx* ctx, int rank, int world, uint8_t
   if (!ctx || !handle) return SC_ERR_ARG;
   SC_TRY(set_device(ctx));
   if (world > sc::kMaxPeers) return fail(ctx, SC_ERR_ARG, "the peer transport serves up to %d ranks (one node)", sc::kMaxPeers);
+  if (ctx->peer_region) return fail(ctx, SC_ERR_STATE, "sc_ctx_comm_peer_export: already exported");
   SC_TRY(set_world(ctx, rank, world));
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
   const size_t words = kInboxRegionWords + 2 * 2 * ((size_t)world << ctx->arena_log);   // inbox + two arenas of two tables
@@ -2174,7 +2180,7 @@ int prover_pass(sc_prover* pr, size_t j) {
     pr->cur_log += ctx->log_world;
     pr->sharded = false;
   }
-  if (pr->sharded && (pr->cur_log < kf + ks || pr->cur_log <= ctx->tail_log)) {
+  if (pr->sharded && ctx->transport != Transport::kPeer && (pr->cur_log < kf + ks || pr->cur_log <= ctx->tail_log)) {
     u64 *fa = nullptr, *fb = nullptr;
     size_t len = (size_t)1 << pr->cur_log;
     SC_TRY(gather_table(ctx, pr->cur_a, len, &fa));
