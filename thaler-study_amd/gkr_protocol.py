@@ -159,13 +159,23 @@ class W(SumCheckPolynomial):
         return _NativeWProver(self)
 
 
+def _gate_arrays(layer):
+    """the gate list as three contiguous arrays (type 0 = add, 1 = mul; the two input labels), cached on the layer"""
+    cached = getattr(layer, "_arrays", None)
+    if cached is None:
+        gt = np.fromiter((0 if g.ttype == GateType.Add else 1 for g in layer.layer), dtype=np.int32, count=len(layer.layer))
+        i0 = np.fromiter((g.inputs[0] for g in layer.layer), dtype=np.uint32, count=len(layer.layer))
+        i1 = np.fromiter((g.inputs[1] for g in layer.layer), dtype=np.uint32, count=len(layer.layer))
+        cached = layer._arrays = (gt, i0, i1)
+    gt, i0, i1 = cached
+    return (gt.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), i0.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)),
+            i1.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
+
+
 def wiring(ctx, circuit, i, r_i):
     """add_i(r_i,.,.) and mul_i(r_i,.,.) as device tables (gkr-protocol/src/lib.rs:388-416)"""
-    layer = circuit.layers[i].layer
     k_i, k_next = circuit.num_vars_at(i), circuit.num_vars_at(i + 1)
-    gt = (ctypes.c_int32 * len(layer))(*[0 if g.ttype == GateType.Add else 1 for g in layer])
-    i0 = (ctypes.c_uint32 * len(layer))(*[g.inputs[0] for g in layer])
-    i1 = (ctypes.c_uint32 * len(layer))(*[g.inputs[1] for g in layer])
+    gt, i0, i1 = _gate_arrays(circuit.layers[i])
     r = _words(r_i)
     assert r.size == k_i
     ha, hm = voidp(), voidp()
@@ -179,11 +189,8 @@ class SparseLayerProver(_NativeWProver):
 
     def __init__(self, ctx, circuit, evaluation, i, r_i):
         self.ctx = ctx
-        layer = circuit.layers[i].layer
         k_i, k_next = circuit.num_vars_at(i), circuit.num_vars_at(i + 1)
-        gt = (ctypes.c_int32 * len(layer))(*[0 if g.ttype == GateType.Add else 1 for g in layer])
-        i0 = (ctypes.c_uint32 * len(layer))(*[g.inputs[0] for g in layer])
-        i1 = (ctypes.c_uint32 * len(layer))(*[g.inputs[1] for g in layer])
+        gt, i0, i1 = _gate_arrays(circuit.layers[i])
         r = _words(r_i)
         assert r.size == k_i
         self._w_next = DenseMultilinearExtension.from_evaluations_vec(ctx, k_next, np.array(evaluation[i + 1], dtype=np.uint64))
