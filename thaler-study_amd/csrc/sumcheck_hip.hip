@@ -1320,12 +1320,12 @@ extern "C" int sc_ctx_comm_peer_export(sc_ctx* ctx, int rank, int world, uint8_t
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
   const size_t words = kInboxRegionWords + 2 * 2 * ((size_t)world << ctx->arena_log);   // inbox + two arenas of two tables
   // fine-grained device memory: written by the peers over xGMI while kernels of this rank poll it
+  // (no coarse-grained fallback: a peer's stores into ordinary device memory are not guaranteed to be seen by
+  // this device's caches across launches; a caller without fine-grained memory uses another transport)
   hipError_t e = hipExtMallocWithFlags((void**)&ctx->peer_region, words * sizeof(u64), hipDeviceMallocFinegrained);
   if (e != hipSuccess) {
     (void)hipGetLastError();
-    e = hipMalloc((void**)&ctx->peer_region, words * sizeof(u64));
-  }
-  if (e != hipSuccess) {
+    ctx->peer_region = nullptr;
     ctx->world = 1; ctx->rank = 0; ctx->log_world = 0;
     return fail(ctx, SC_ERR_OOM, "peer region of %zu bytes: %s", words * sizeof(u64), hipGetErrorString(e));
   }
