@@ -561,7 +561,7 @@ def run_mle(args, pkg, torch, dist, rank, world, local_rank):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", choices=["prover", "mle"], default=os.environ.get("SC_BENCH_WORKLOAD", "prover"))
     ap.add_argument("--num-vars", type=int, default=int(os.environ.get("SC_BENCH_N", "0")),
