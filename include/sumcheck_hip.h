@@ -90,7 +90,9 @@ const char* sc_last_error(const sc_ctx* ctx);
  *   "resident"         serve the latency-bound passes of a proof from ONE resident launch whose phases the
  *                      host steers through a pinned command line (default 0: measured equal to launches on
  *                      one GPU); "resident_log": largest table it starts from (default 19);
- *                      "park_ms": it leaves the GPU after this long without a command (default 20)
+ *                      "park_ms": it leaves the GPU after this long without a command (default 20);
+ *                      "resident_stamps" = 1 records block 0's wall-clock stamps per phase (diagnostic: read
+ *                      back with sc_ctx_get_option "resident_stamp_<i>", host think time "resident_host_ns")
  *   "arena_log"        peer transport: a gather arena holds world * 2^arena_log words per table (default 17;
  *                      set before sc_ctx_comm_peer_export); "peer_spin_ms": bound of in-kernel waits for peers
  *   "time_kernels"     HIP-event timing of pass kernels (see sc_ctx_kernel_time)
