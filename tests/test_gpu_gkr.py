@@ -320,3 +320,42 @@ def test_w_prover_sharded(world, transport):
             for j in range(2 * k_next):
                 e = [int(x) for x in ref["evals"][j]]
                 assert got[1 + j] == (e, e), (ks, j)
+
+
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+def test_w_prover_general_shapes(p):
+    """the two-phase W prover on DENSE random add/mul tables (not wiring-shaped) with any split of the variables
+    between b and c - including none on one side, and a W that already had variables fixed - against the
+    independent big-integer restatement of W (oracle/pyref.py w_transcript)"""
+    pkg = load_package()
+    ctx = pkg.Context(pkg.Field(p))
+    F = ctx.field
+    gp = pkg.gkr_protocol
+    DM = pkg.DenseMultilinearExtension
+    rng = random.Random(p % 1013)
+    for kb, kc in [(1, 1), (3, 5), (5, 2), (0, 4), (4, 0), (1, 6), (6, 1), (2, 2)]:
+        n = kb + kc
+        add = [rng.randrange(p) for _ in range(1 << n)]
+        mul = [rng.randrange(p) for _ in range(1 << n)]
+        wb = [rng.randrange(p) for _ in range(1 << kb)]
+        wc = [rng.randrange(p) for _ in range(1 << kc)]
+        ch = [rng.randrange(p) for _ in range(n)]
+        ref = pyref.w_transcript(add, mul, wb, wc, ch, p)
+        w = gp.W(DM.from_evaluations_vec(ctx, n, F.from_ints(add)), DM.from_evaluations_vec(ctx, n, F.from_ints(mul)),
+                 DM.from_evaluations_vec(ctx, kb, F.from_ints(wb)), DM.from_evaluations_vec(ctx, kc, F.from_ints(wc)))
+        eng = w.native_prover()
+        assert F.to_int(eng.c1()) == ref["c_1"], (kb, kc)
+        for j in range(n):
+            e = eng.round_evals(F.from_int(ch[j - 1]) if j else F.one, j)
+            assert [F.to_int(x) for x in e] == ref["evals"][j], (kb, kc, j)
+        assert F.to_int(w.evaluate(F.from_ints(ch).tolist())) == ref["final_eval"]
+        # a W with its first t variables already fixed (t inside b, at the boundary, inside c): the engine
+        # starts from that state and its rounds are the tail of the full transcript
+        for t in sorted({1, kb, min(kb + 1, n - 1)} - {0, n}):
+            if t >= n:
+                continue
+            w2 = w.fix_variables(F.from_ints(ch[:t]).tolist())
+            eng2 = w2.native_prover()
+            for j in range(n - t):
+                e = eng2.round_evals(F.from_int(ch[t + j - 1]) if j else F.one, j)
+                assert [F.to_int(x) for x in e] == ref["evals"][t + j], (kb, kc, t, j)

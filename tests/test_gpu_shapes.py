@@ -92,3 +92,30 @@ def test_g_new_config5_shape():
     ofa, ofb = np.ascontiguousarray(fa), np.ascontiguousarray(fb)
     ref = o.prove(ofa, ofb, ch)
     assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+
+
+def test_mle_config2_properties_n28():
+    """BASELINE configs[1] at the large shape (one 2^28-entry table): size-independent properties of evaluate and
+    fix_variables - the BE evaluate (vsbw_/cti_multilinear_from_evaluations) is the LE evaluate at the reversed point;
+    fixing k variables and evaluating the rest is the full evaluate, for LE prefixes and BE prefixes; a boolean
+    point reads the entry back; relabel(0, 14, 14) is the matrix transpose"""
+    pkg = load_package()
+    F = pkg.Field(GOLD)
+    o = oracle(GOLD)
+    ctx = pkg.Context(F)
+    n = 28
+    t = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
+    pt = [int(o.challenge(pyref.SEED_PT, j)) for j in range(n)]
+    v_le = t.evaluate(pt)
+    assert t.evaluate(pt[::-1], pkg.ORDER_BE) == v_le
+    for k in (1, 2, 3, 7, 8, 14, 17, 20, 27):
+        assert t.fix_variables(pt[:k]).evaluate(pt[k:]) == v_le, k
+    rev = pt[::-1]
+    for k in (1, 2, 5, 14):
+        assert t.fix_variables(rev[:k], pkg.ORDER_BE).evaluate(rev[k:], pkg.ORDER_BE) == v_le, ("BE", k)
+    for idx in (0, 1, 12345678, (1 << n) - 1):
+        bits = [F.one if (idx >> i) & 1 else F.zero for i in range(n)]
+        assert t.evaluate(bits) == int(o.generate_range(pyref.SEED_A, idx, 1)[0])
+    tr = t.relabel(0, 14, 14)
+    swapped = pt[14:] + pt[:14]
+    assert tr.evaluate(swapped) == v_le
