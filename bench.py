@@ -225,6 +225,16 @@ def cpu_sample_size(requested):
     return 28 if avail_gib > 48 else (27 if avail_gib > 20 else 26)
 
 
+def context_options():
+    """SC_BENCH_OPTIONS="first_ring=0,ring_log=24": library options for A/B runs (reported in config.options)"""
+    out = []
+    for item in os.environ.get("SC_BENCH_OPTIONS", "").split(","):
+        if item.strip():
+            k, v = item.split("=")
+            out.append((k.strip(), int(v)))
+    return out
+
+
 def run_prover(args, pkg, torch, dist, rank, world, local_rank):
     import numpy as np
     mm, D, syn = pkg.matrix_multiplication, pkg.distributed, pkg.synthetic
@@ -238,6 +248,8 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
     def make_ctx():
         c = pkg.Context(F, device=local_rank)
         c.set_option("vars_per_pass", args.vars_per_pass)
+        for k, v in context_options():
+            c.set_option(k, v)
         return c
 
     ctx, transport = setup_transport(args, pkg, make_ctx, rank, world, dist)
@@ -344,7 +356,7 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                 "tail_pass_vars": ctx.get_option("tail_pass_vars"),
                 "parallelism": "hypercube-shard x%d" % world,
                 "parity_gate": "verifier identities at n=%d ok" % n,
-                "transport": transport,
+                "transport": transport, "options": dict(context_options()),
                 "ms_per_step_median_unsampled": statistics.median(unsampled) if unsampled else None,
             },
             "roofline": {

@@ -448,6 +448,32 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
   publish_seq(o);
 }
 
+// Per-thread accumulators of NS cells -> block sums: thread s ends up with the block's sum of cell s.
+// Nine sums at a time (a 27-cell grid would otherwise hold 27 residues next to the accumulators they come
+// from).  lds: kWaves * min(NS, 9) words of scratch.
+template <class F, int NS>
+__device__ __forceinline__ u64 reduce_cells(const F& f, const typename F::Acc (&acc)[NS], u64* lds) {
+  constexpr int CH = (NS < 9) ? NS : 9;
+  u64 mine = 0;
+#pragma unroll
+  for (int c0 = 0; c0 < NS; c0 += CH) {
+    u64 res[CH];
+#pragma unroll
+    for (int s = 0; s < CH; ++s) res[s] = f.acc_get(acc[c0 + s]);
+    if (c0 > 0) __syncthreads();  // the previous chunk's scratch has been read
+    block_reduce<F, CH>(f, res, lds);
+    if ((int)threadIdx.x >= c0 && (int)threadIdx.x < c0 + CH) mine = res[0];
+    if constexpr (NS > CH) {
+      // block_reduce leaves chunk sum s in thread s; hand it to thread c0 + s
+      __syncthreads();
+      if (threadIdx.x < CH) lds[threadIdx.x] = res[0];
+      __syncthreads();
+      if ((int)threadIdx.x >= c0 && (int)threadIdx.x < c0 + CH) mine = lds[threadIdx.x - c0];
+    }
+  }
+  return mine;
+}
+
 // NT: bit 0 = nontemporal loads, bit 1 = nontemporal stores (see ld16 / st16)
 template <class F, int KF, int KS, int NT>
 __global__ void __launch_bounds__(kBlock)
@@ -577,26 +603,7 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     }
   }
 
-  // reduce nine sums at a time (a 27-cell grid would otherwise hold 27 residues next to the
-  // accumulators they come from); thread s ends up with sum s
-  constexpr int CH = (NS < 9) ? NS : 9;
-  u64 mine = 0;
-#pragma unroll
-  for (int c0 = 0; c0 < NS; c0 += CH) {
-    u64 res[CH];
-#pragma unroll
-    for (int s = 0; s < CH; ++s) res[s] = f.acc_get(acc[c0 + s]);
-    if (c0 > 0) __syncthreads();  // the previous chunk's scratch has been read
-    block_reduce<F, CH>(f, res, lds);
-    if ((int)threadIdx.x >= c0 && (int)threadIdx.x < c0 + CH) mine = res[0];
-    if constexpr (NS > CH) {
-      // block_reduce leaves chunk sum s in thread s; hand it to thread c0 + s
-      __syncthreads();
-      if (threadIdx.x < CH) lds[threadIdx.x] = res[0];
-      __syncthreads();
-      if ((int)threadIdx.x >= c0 && (int)threadIdx.x < c0 + CH) mine = lds[threadIdx.x - c0];
-    }
-  }
+  const u64 mine = reduce_cells<F, NS>(f, acc, lds);
   finish_pass<F, NS>(f, out, mine, &lds_flag);
 }
 
