@@ -66,6 +66,8 @@ def kernel_name(rec):
         return "sc::pass_kernel<GoldilocksMont,%d,%d> on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
     if k == "tail_pass":
         return "sc::small_pass3_kernel<GoldilocksMont,%d> on 2^%d-entry tables" % (rec["kf"], rec["log_in"])
+    if k == "grid_pass":
+        return "sc::grid_pass_kernel<GoldilocksMont> (kf=%d, ks=%d) on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
     if k == "tail_resident":
         return "sc::tail_resident_kernel<GoldilocksMont> from 2^%d-entry tables (%d rounds)" % (rec["log_in"], rec["ks"])
     if k == "evaluate":

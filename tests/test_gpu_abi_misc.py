@@ -29,11 +29,11 @@ def test_launch_log_records_what_ran():
     assert log[0]["kind"] == "pass" and (log[0]["kf"], log[0]["ks"], log[0]["log_in"]) == (0, 3, 20)
     size, rounds = 20, 0
     for r in log:
-        assert r["kind"] in ("pass", "tail_pass") and r["log_in"] == size and r["ms"] > 0
+        assert r["kind"] in ("pass", "tail_pass", "grid_pass") and r["log_in"] == size and r["ms"] > 0
         assert r["bytes_read"] == 16 << size and r["bytes_written"] == ((16 << (size - r["kf"])) if r["kf"] else 0)
         size -= r["kf"]
         rounds += r["ks"]
-    assert rounds == n
+    assert rounds == n and log[-1]["kind"] == "grid_pass"      # the smallest tables: up to five rounds per launch
     n_launch, ms = ctx.kernel_time(reset=True)
     assert n_launch == len(log) and abs(ms - sum(r["ms"] for r in log)) < 1e-6   # the totals of the same records
     assert ctx.kernel_time(reset=True) == (0, 0.0)

@@ -690,6 +690,208 @@ small_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u6
 }
 
 // ------------------------------------------------------------------------------------
+// Up to FIVE rounds per pass for the tables at the end of a proof (folded size <= 2^14 entries or so).
+//
+// The tail of a proof is a chain of passes whose cost is latency - launch, one dependent chain of work,
+// hand-off to the host - and not bytes; at 8 GPUs (2^25-entry shards) it is more than half of the proof.
+// Two things shorten it: fewer passes (a pass that serves KS rounds accumulates the 3^KS-cell grid in the
+// {0,1,inf} basis; for KS = 4, 5 that is 81 / 243 cells over groups of 16 / 32 folded entries, a few
+// thousand products - nothing at these sizes) and a shorter dependent chain inside a pass (small_pass3_kernel
+// lets one thread in eight walk all 27 cells of its octet, ~600 instructions on a wave that issues alone at
+// half rate; here the cells are spread over the threads).  kf (0..5) and ks (1..5) are run-time values: these
+// launches are not throughput-bound and one kernel per field keeps the build small.
+//
+// Per block iteration ("chunk") of kGridChunk = 256 folded entries per table:
+//  1. fold: thread t produces folded entry t of both tables, sum_c w[c] * in[2^kf t + c] (one lazy sum,
+//     one reduction), stores it to the folded tables and to its place in the block's extension arrays
+//  2. extend: ea/eb[group][cell], cell = sum_j d_j 3^(ks-1-j), d_j in {0,1,inf} the evaluation point of the
+//     group's variable j (variable 0 = index bit 0, the round served first: the slowest axis, as in
+//     pass_kernel); level j fills the cells with d_j = inf from d_j = 1 minus d_j = 0, one subtraction each,
+//     3^j 2^(ks-1-j) per group and level, all threads, one barrier per level
+//  3. multiply: thread (cell c, split s) adds ea[g][c] * eb[g][c] over the groups g = s (mod S) to ITS lazy
+//     accumulator, which lives across chunks
+// End: accumulators -> residues, the S splits of a cell are added through LDS, thread c < 3^ks holds cell c.
+// Several blocks: partials [block][256], ticket, the last block's thread c adds its column (Guideline 16 R1,
+// as finish_pass).  The cells leave as whole residues (no limb split: these passes are never sharded) in the
+// wide part of the host mailbox, then the sequence word.
+constexpr int kGridChunk = 256;
+constexpr int kGridMaxVars = 5;
+constexpr int kGridMaxCells = 243;
+constexpr int kMailboxWide = 64;        // first word of the wide area (kGridMaxCells words)
+constexpr int kMailboxWords = kMailboxWide + 256;
+struct GridW {
+  u64 w[1 << kGridMaxVars];   // w[c] = eq((r_0 .. r_{kf-1}), c); w[0] = 1 for kf = 0
+};
+struct GridOut {
+  u64* partials;        // [blocks][kGridChunk]
+  unsigned* ticket;
+  unsigned ticket_base;
+  u64* mailbox;
+  u64 seq;
+};
+__device__ __forceinline__ int grid_pow3(int k) {
+  return k == 0 ? 1 : k == 1 ? 3 : k == 2 ? 9 : k == 3 ? 27 : k == 4 ? 81 : 243;
+}
+// folded entry i of both tables: sum_c w[c] * in[2^KF i + c], stored to the folded tables
+template <class F, int KF>
+__device__ __forceinline__ void grid_fold(const F& f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
+                                          u64* __restrict__ B2, const GridW& gw, size_t i, u64& va, u64& vb) {
+  constexpr int FAN = 1 << KF, NPIECE = FAN / 2;
+  const ull2* __restrict__ pa = reinterpret_cast<const ull2*>(A + i * FAN);
+  const ull2* __restrict__ pb = reinterpret_cast<const ull2*>(B + i * FAN);
+  ull2 xa[NPIECE], xb[NPIECE];
+#pragma unroll
+  for (int m = 0; m < NPIECE; ++m) {
+    xa[m] = pa[m];
+    xb[m] = pb[m];
+  }
+  typename F::Acc3 sa, sb;
+  f.acc3_zero(sa);
+  f.acc3_zero(sb);
+#pragma unroll
+  for (int m = 0; m < NPIECE; ++m) {
+    f.acc3_mac(sa, xa[m].x, gw.w[2 * m]); f.acc3_mac(sa, xa[m].y, gw.w[2 * m + 1]);
+    f.acc3_mac(sb, xb[m].x, gw.w[2 * m]); f.acc3_mac(sb, xb[m].y, gw.w[2 * m + 1]);
+  }
+  va = f.acc3_get(sa);
+  vb = f.acc3_get(sb);
+  A2[i] = va;
+  B2[i] = vb;
+}
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+grid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
+                 GridW gw, int kf, int ks, size_t n_out, GridOut out) {
+  constexpr int kMaxExt = (kGridChunk >> kGridMaxVars) * kGridMaxCells;   // 8 groups x 243 cells: the largest of the five
+  __shared__ u64 ea[kMaxExt], eb[kMaxExt];
+  __shared__ u64 red[kBlock];
+  __shared__ int cell_of[1 << kGridMaxVars], suffix_of[1 << kGridMaxVars];
+  __shared__ int lds_flag;
+  const int tid = threadIdx.x;
+#ifdef SC_GRID_STAMPS
+  __shared__ unsigned long long stamps[12];
+#define SC_GSTAMP(k) do { if (tid == 0) stamps[k] = wall_clock64(); } while (0)
+#else
+#define SC_GSTAMP(k) do { } while (0)
+#endif
+  SC_GSTAMP(0);
+  const int cells = grid_pow3(ks), G = 1 << ks, groups = kGridChunk >> ks;
+  if (tid < (1 << kGridMaxVars)) {
+    // cell of a group's entry e (its bits are the points of the group's variables, variable 0 = bit 0) and the
+    // cell offset of a suffix s whose bit m is the point of variable ks-1-m
+    int c = 0, u = 0, p3 = 1;
+    for (int m = 0; m < ks; ++m) {
+      c += ((tid >> (ks - 1 - m)) & 1) * p3;
+      u += ((tid >> m) & 1) * p3;
+      p3 *= 3;
+    }
+    cell_of[tid] = c;
+    suffix_of[tid] = u;
+  }
+  // products: thread = (cell, split); S splits share the groups of a chunk
+  const int S = min(groups, kBlock / cells);
+  const bool multiplies = tid < cells * S;
+  const int my_cell = tid % cells, my_split = tid / cells;
+  typename F::Acc acc;
+  f.acc_zero(acc);
+  __syncthreads();
+  SC_GSTAMP(1);
+
+  const size_t n_chunks = (n_out + kGridChunk - 1) / kGridChunk;
+  for (size_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
+    // 1. fold
+    const size_t i = chunk * kGridChunk + tid;
+    u64 va = 0, vb = 0;
+    if (i < n_out) {
+      switch (kf) {   // compile-time fan-in: all loads of an entry are in flight together
+        case 0: va = A[i]; vb = B[i]; break;
+        case 1: grid_fold<F, 1>(f, A, B, A2, B2, gw, i, va, vb); break;
+        case 2: grid_fold<F, 2>(f, A, B, A2, B2, gw, i, va, vb); break;
+        case 3: grid_fold<F, 3>(f, A, B, A2, B2, gw, i, va, vb); break;
+        case 4: grid_fold<F, 4>(f, A, B, A2, B2, gw, i, va, vb); break;
+        default: grid_fold<F, 5>(f, A, B, A2, B2, gw, i, va, vb); break;
+      }
+    }
+    {
+      const int slot = (tid >> ks) * cells + cell_of[tid & (G - 1)];
+      ea[slot] = va;
+      eb[slot] = vb;
+    }
+    __syncthreads();
+    SC_GSTAMP(2);
+    // 2. extend, one variable per level
+    for (int j = 0; j < ks; ++j) {
+      const int low = ks - 1 - j, pj = grid_pow3(j), stride = grid_pow3(low), items = (groups * pj) << low;
+      const unsigned inv = (1u << 20) / (unsigned)pj + 1u;   // t / pj for t < 4096, pj in {1,3,9,27,81}: exact
+      for (int idx = tid; idx < items; idx += kBlock) {
+        const int sfx = idx & ((1 << low) - 1), t = idx >> low;
+        const int g = (int)(((unsigned)t * inv) >> 20), p = t - g * pj;
+        const int base = g * cells + p * 3 * stride + suffix_of[sfx];
+        ea[base + 2 * stride] = f.sub(ea[base + stride], ea[base]);
+        eb[base + 2 * stride] = f.sub(eb[base + stride], eb[base]);
+      }
+      __syncthreads();
+    }
+    SC_GSTAMP(3);
+    // 3. multiply
+    if (multiplies) {
+      for (int g = my_split; g < groups; g += S) f.acc_mac(acc, ea[g * cells + my_cell], eb[g * cells + my_cell]);
+    }
+    __syncthreads();
+  }
+
+  SC_GSTAMP(4);
+  red[tid] = multiplies ? f.acc_get(acc) : 0;
+  __syncthreads();
+  SC_GSTAMP(5);
+  u64 total = 0;
+  if (tid < cells) {
+    for (int sp = 0; sp < S; ++sp) total = f.add(total, red[sp * cells + tid]);
+  }
+  if (gridDim.x > 1) {
+    if (tid < cells)
+      __hip_atomic_store(out.partials + (size_t)blockIdx.x * kGridChunk + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(out.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t - out.ticket_base == gridDim.x - 1) ? 1 : 0;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      lds_flag = last;
+    }
+    __syncthreads();
+    if (!lds_flag) return;
+    total = 0;
+    if (tid < cells) {
+      const int n_blocks = gridDim.x;
+      int b = 0;
+      for (; b + 8 <= n_blocks; b += 8) {
+        u64 x[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          x[q] = __hip_atomic_load(out.partials + (size_t)(b + q) * kGridChunk + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) total = f.add(total, x[q]);
+      }
+      for (; b < n_blocks; ++b)
+        total = f.add(total, __hip_atomic_load(out.partials + (size_t)b * kGridChunk + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    }
+  }
+  SC_GSTAMP(6);
+  if (tid < cells) __hip_atomic_store(out.mailbox + kMailboxWide + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+  SC_GSTAMP(7);
+#ifdef SC_GRID_STAMPS
+  if (tid < 8) __hip_atomic_store(out.mailbox + kMailboxWide + 244 + tid, (u64)stamps[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  __syncthreads();
+#endif
+  if (tid == 0) __hip_atomic_store(out.mailbox + kMailboxSeq, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// ------------------------------------------------------------------------------------
 // The resident prover kernel: every pass after the first two of a proof in ONE launch.
 //
 // From the third pass on a proof is a chain of short passes (at n = 28: 2^25, 2^23, 2^21 entries

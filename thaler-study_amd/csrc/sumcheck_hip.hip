@@ -80,6 +80,7 @@ bool load_rccl(std::string* why) {
 }
 
 enum class Transport { kNone, kRccl, kHost, kPeer };
+constexpr int kGridMaxBlocks = 64;   // blocks of a grid_pass_kernel launch at most (rows of its partials)
 
 }  // namespace
 
@@ -104,6 +105,14 @@ struct sc_ctx {
   // two everywhere
   int tail_pass_vars = 3;
   int tail_pass_log = 19;  // largest input (log2 entries per table) that takes the three-round tail pass
+  // the passes on the smallest tables (kernels.hpp, grid_pass_kernel): up to five rounds each
+  int grid_pass = 1;
+  int grid_log = 14;        // largest FOLDED table (log2 entries) they take: <= kGridMaxBlocks chunks of 256
+  int grid_max_vars = 5;    // most rounds one of them serves (1..5)
+  int grid_vars4_log = 14;  // largest folded table that gets four rounds ...
+  int grid_vars5_log = 11;  // ... and five
+  int grid_blocks = 64;     // most blocks of such a launch (each takes chunks of 256 folded entries)
+  u64* d_gpartials = nullptr;   // [kGridMaxBlocks][kGridChunk]
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
                       // cheaper than the ~25 us of collective latency of each further sharded pass
   // grid cap of the streaming kernels: three 256-thread blocks per CU (set in sc_ctx_create).
@@ -370,6 +379,23 @@ sc::FoldW make_fold_weights(const sc_ctx* ctx, const u64* r, int kf) {
   return fw;
 }
 
+// the same for the passes on the smallest tables (kernels.hpp: GridW), kf <= 5
+sc::GridW make_grid_weights(const sc_ctx* ctx, const u64* r, int kf) {
+  HostField hf(ctx->fp);
+  sc::GridW gw;
+  for (int c = 0; c < (1 << sc::kGridMaxVars); ++c) gw.w[c] = 0;
+  gw.w[0] = hf.one();
+  for (int j = 0; j < kf; ++j) {
+    const int half = 1 << j;
+    for (int c = half - 1; c >= 0; --c) {
+      const u64 base = gw.w[c];
+      gw.w[c + half] = hf.mul(base, r[j]);
+      gw.w[c] = hf.mul(base, hf.sub(hf.one(), r[j]));
+    }
+  }
+  return gw;
+}
+
 // (H(0), H(1), H(inf)) -> H(2) = 2 H(1) - H(0) + 2 H(inf)   (H quadratic, inf = leading coefficient)
 u64 eval2_from_inf(const HostField& hf, u64 e0, u64 e1, u64 einf) {
   u64 t = hf.add(e1, einf);
@@ -570,6 +596,52 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   if (grid > 1) ctx->ticket_base += (unsigned)grid;
   SC_TRY(timer_end(ctx));
   *from_mailbox = mailbox;
+  return SC_OK;
+}
+
+int wait_mailbox(sc_ctx* ctx, u64 seq);
+
+// One pass of the tail by grid_pass_kernel: folds kf <= 5 pending challenges of tables of 2^log_in entries and
+// leaves the 3^ks cells of the next ks <= 5 rounds as whole residues in the wide mailbox (unsharded only).
+int launch_grid_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, const u64* r, int log_in) {
+  if (kf < 0 || kf > sc::kGridMaxVars || ks < 1 || ks > sc::kGridMaxVars || log_in < kf + ks)
+    return fail(ctx, SC_ERR_ARG, "launch_grid_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
+  if (!ctx->use_mailbox) return fail(ctx, SC_ERR_STATE, "launch_grid_pass needs the host mailbox");
+  const sc::GridW gw = make_grid_weights(ctx, r, kf);
+  const size_t n_out = (size_t)1 << (log_in - kf);
+  const size_t n_chunks = (n_out + sc::kGridChunk - 1) / sc::kGridChunk;
+  const int grid = (int)std::min<size_t>(n_chunks, (size_t)std::min(ctx->grid_blocks, kGridMaxBlocks));
+  sc::GridOut out;
+  out.partials = ctx->d_gpartials;
+  out.ticket = ctx->d_ticket;
+  out.ticket_base = ctx->ticket_base;
+  out.mailbox = ctx->d_mailbox;
+  out.seq = ctx->mailbox_seq + 1;
+  SC_TRY(timer_begin(ctx, SC_KIND_GRID_PASS, kf, ks, log_in, (u64)16 << log_in, kf > 0 ? (u64)16 << (log_in - kf) : 0));
+  SC_DISPATCH_FIELD(ctx, F, f,
+                    hipLaunchKernelGGL((sc::grid_pass_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, A, B, A2, B2, gw,
+                                       kf, ks, n_out, out));
+  SC_HIP(ctx, hipGetLastError());
+  ctx->mailbox_seq += 1;
+  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  SC_TRY(timer_end(ctx));
+  return SC_OK;
+}
+// its cells: wait for the sequence word, copy the residues
+int collect_grid(sc_ctx* ctx, int ks, u64* out) {
+  SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
+  int cells = 1;
+  for (int i = 0; i < ks; ++i) cells *= 3;
+  for (int c = 0; c < cells; ++c) out[c] = ctx->h_mailbox[sc::kMailboxWide + c];
+#ifdef SC_GRID_STAMPS
+  {
+    const u64* st = ctx->h_mailbox + sc::kMailboxWide + 244;
+    fprintf(stderr, "grid stamps (10 ns): init %llu fold %llu extend %llu mult %llu get %llu reduce+xblock %llu publish %llu\n",
+            (unsigned long long)(st[1] - st[0]), (unsigned long long)(st[2] - st[1]), (unsigned long long)(st[3] - st[2]),
+            (unsigned long long)(st[4] - st[3]), (unsigned long long)(st[5] - st[4]), (unsigned long long)(st[6] - st[5]),
+            (unsigned long long)(st[7] - st[6]));
+  }
+#endif
   return SC_OK;
 }
 
@@ -1089,8 +1161,9 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
   SC_CREATE_HIP(hipHostMalloc(&ctx->h_sums, 64 * sizeof(u64), hipHostMallocDefault));
   SC_CREATE_HIP(hipMalloc(&ctx->d_ticket, 64));
   SC_CREATE_HIP(hipMemset(ctx->d_ticket, 0, 64));
-  SC_CREATE_HIP(hipHostMalloc(&ctx->h_mailbox, 64 * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
-  memset(ctx->h_mailbox, 0, 64 * sizeof(u64));
+  SC_CREATE_HIP(hipHostMalloc(&ctx->h_mailbox, sc::kMailboxWords * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
+  memset(ctx->h_mailbox, 0, sc::kMailboxWords * sizeof(u64));
+  SC_CREATE_HIP(hipMalloc(&ctx->d_gpartials, (size_t)kGridMaxBlocks * sc::kGridChunk * sizeof(u64)));
   SC_CREATE_HIP(hipHostGetDevicePointer((void**)&ctx->d_mailbox, ctx->h_mailbox, 0));
   SC_CREATE_HIP(hipHostMalloc(&ctx->h_cmd, 64 * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->h_cmd, 0, 64 * sizeof(u64));
@@ -1119,6 +1192,7 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
   for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
   for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
+  if (ctx->d_gpartials) (void)hipFree(ctx->d_gpartials);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
   if (ctx->h_sums) (void)hipHostFree(ctx->h_sums);
   if (ctx->h_mailbox) (void)hipHostFree(ctx->h_mailbox);
@@ -1152,6 +1226,23 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "tail_pass_log") {
     if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "tail_pass_log out of range");
     ctx->tail_pass_log = (int)value;
+  } else if (k == "grid_pass") {
+    ctx->grid_pass = value ? 1 : 0;
+  } else if (k == "grid_log") {
+    if (value < 0 || value > 14) return fail(ctx, SC_ERR_ARG, "grid_log out of range (0..14)");
+    ctx->grid_log = (int)value;
+  } else if (k == "grid_max_vars") {
+    if (value < 1 || value > sc::kGridMaxVars) return fail(ctx, SC_ERR_ARG, "grid_max_vars must be 1..5");
+    ctx->grid_max_vars = (int)value;
+  } else if (k == "grid_vars4_log") {
+    if (value < 0 || value > 14) return fail(ctx, SC_ERR_ARG, "grid_vars4_log out of range (0..14)");
+    ctx->grid_vars4_log = (int)value;
+  } else if (k == "grid_vars5_log") {
+    if (value < 0 || value > 14) return fail(ctx, SC_ERR_ARG, "grid_vars5_log out of range (0..14)");
+    ctx->grid_vars5_log = (int)value;
+  } else if (k == "grid_blocks") {
+    if (value < 1 || value > kGridMaxBlocks) return fail(ctx, SC_ERR_ARG, "grid_blocks must be 1..%d", kGridMaxBlocks);
+    ctx->grid_blocks = (int)value;
   } else if (k == "tail_log") {
     if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "tail_log out of range");
     ctx->tail_log = (int)value;
@@ -1196,6 +1287,12 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   else if (k == "first_pass_vars") *value = ctx->first_pass_vars;
   else if (k == "tail_pass_vars") *value = ctx->tail_pass_vars;
   else if (k == "tail_pass_log") *value = ctx->tail_pass_log;
+  else if (k == "grid_pass") *value = ctx->grid_pass;
+  else if (k == "grid_log") *value = ctx->grid_log;
+  else if (k == "grid_max_vars") *value = ctx->grid_max_vars;
+  else if (k == "grid_vars4_log") *value = ctx->grid_vars4_log;
+  else if (k == "grid_vars5_log") *value = ctx->grid_vars5_log;
+  else if (k == "grid_blocks") *value = ctx->grid_blocks;
   else if (k == "tail_log") *value = ctx->tail_log;
   else if (k == "max_blocks") *value = ctx->max_blocks;
   else if (k == "time_kernels") *value = ctx->time_kernels;
@@ -1824,7 +1921,7 @@ struct sc_prover {
   // cache of the last pass
   int cache_ks = 0;
   size_t cache_round = 0;
-  u64 S[27];
+  u64 S[sc::kGridMaxCells];
   u64 c1 = 0;
   // resident kernel serving this prover's remaining passes (kernels.hpp, resident_kernel)
   struct {
@@ -1857,6 +1954,37 @@ int pass_rounds(const sc_ctx* ctx, size_t num_vars, size_t j, int kf, int cur_lo
   if (kf > 0 && ctx->vars_per_pass == 2 && ctx->tail_pass_vars == 3 && remaining >= 3 && cur_log <= ctx->tail_pass_log)
     ks = 3;
   return ks;
+}
+
+// Rounds a grid pass (kernels.hpp, grid_pass_kernel) serves when `vars` variables are left, i.e. the folded table
+// has 2^vars entries: as few passes as the size limits allow (five rounds on tables of <= 2^grid_vars5_log entries,
+// four up to 2^grid_vars4_log, else three), the rounds shared evenly among them where the limits permit.
+int grid_max_rounds(const sc_ctx* ctx, int vars) {
+  int m = vars <= ctx->grid_vars5_log ? 5 : vars <= ctx->grid_vars4_log ? 4 : 3;
+  m = std::min(m, ctx->grid_max_vars);
+  return std::max(1, std::min(m, vars));
+}
+int grid_passes_needed(const sc_ctx* ctx, int vars) {
+  int n = 0;
+  while (vars > 0) {
+    vars -= grid_max_rounds(ctx, vars);
+    ++n;
+  }
+  return n;
+}
+int grid_rounds(const sc_ctx* ctx, int vars) {
+  const int need = grid_passes_needed(ctx, vars), most = grid_max_rounds(ctx, vars);
+  for (int ks = std::min(most, (vars + need - 1) / need); ks < most; ++ks)   // an even share, if the rest still fits
+    if (1 + grid_passes_needed(ctx, vars - ks) == need) return ks;
+  return most;
+}
+// does the pass at round j go to grid_pass_kernel?  (unsharded, folded table small enough)
+// (the one-round-per-pass mode, a two-round tail, an explicit first_pass_vars and the resident kernel are requests
+// for those schedules)
+bool takes_grid_pass(const sc_ctx* ctx, bool sharded, int cur_log, int kf, size_t j) {
+  if (!ctx->grid_pass || ctx->resident || !ctx->use_mailbox || ctx->vars_per_pass != 2 || ctx->tail_pass_vars != 3 || sharded) return false;
+  if (j == 0 && kf == 0 && ctx->first_pass_vars != 0) return false;
+  return cur_log - kf >= 1 && cur_log - kf <= ctx->grid_log;
 }
 
 int resident_capacity(sc_ctx* ctx) {
@@ -2160,8 +2288,8 @@ int prover_pass(sc_prover* pr, size_t j) {
     }
   }
   const int kf = (int)pr->pending.size();
-  const int ks = pass_rounds(ctx, pr->num_vars, j, kf, pr->cur_log);
-  if (kf > 3) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges", kf);
+  int ks = pass_rounds(ctx, pr->num_vars, j, kf, pr->cur_log);
+  if (kf > sc::kGridMaxVars) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges", kf);
 
   // Sharded: pairs (2b, 2b+1) stay shard-local while the local table still has the kf+ks
   // variables this pass touches; below tail_log the latency of a collective per pass costs
@@ -2198,6 +2326,10 @@ int prover_pass(sc_prover* pr, size_t j) {
     pr->cur_log += ctx->log_world;
     pr->sharded = false;
   }
+  // the smallest tables: up to five rounds per pass (after a gather the table is whole: decide here)
+  const bool by_grid = takes_grid_pass(ctx, pr->sharded, pr->cur_log, kf, j);
+  if (by_grid) ks = grid_rounds(ctx, pr->cur_log - kf);
+  if (kf > 3 && !by_grid) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges and no grid pass to fold them", kf);
   if (pr->cur_log < kf + ks)
     return fail(ctx, SC_ERR_STATE, "prover: table has %d variables, pass needs %d", pr->cur_log, kf + ks);
 
@@ -2212,8 +2344,14 @@ int prover_pass(sc_prover* pr, size_t j) {
     }
   }
   bool mb = false;
-  int rc = launch_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, pr->pending.data(), pr->cur_log, pr->sharded, &mb);
-  if (rc == SC_OK) rc = collect_sums(ctx, ks == 1 ? 3 : ks == 2 ? 9 : 27, pr->sharded, mb, pr->S);
+  int rc;
+  if (by_grid) {
+    rc = launch_grid_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, pr->pending.data(), pr->cur_log);
+    if (rc == SC_OK) rc = collect_grid(ctx, ks, pr->S);
+  } else {
+    rc = launch_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, pr->pending.data(), pr->cur_log, pr->sharded, &mb);
+    if (rc == SC_OK) rc = collect_sums(ctx, ks == 1 ? 3 : ks == 2 ? 9 : 27, pr->sharded, mb, pr->S);
+  }
   if (rc != SC_OK) {
     pool_release(ctx, na);
     pool_release(ctx, nb);
@@ -2242,7 +2380,7 @@ int prover_pass(sc_prover* pr, size_t j) {
 // after it are summed over {0,1}.
 void prover_answer(const sc_prover* pr, size_t j, u64 e[3]) {
   HostField hf(pr->ctx->fp);
-  u64 g[27];
+  u64 g[sc::kGridMaxCells];
   int cells = 1;
   for (int i = 0; i < pr->cache_ks; ++i) cells *= 3;
   for (int i = 0; i < cells; ++i) g[i] = pr->S[i];
