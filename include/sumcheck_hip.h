@@ -87,6 +87,8 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      "grid_max_vars" (default 5) rounds each and fold up to five pending challenges at once
  *                      (grid_pass_kernel, unsharded passes only): five rounds on tables of <= 2^"grid_vars5_log" (11)
  *                      entries, four up to 2^"grid_vars4_log" (14), else three; "grid_blocks" (64) caps the launch.
+ *                      "mid_pass" (1): three-round tail passes on larger tables and sharded ones run the same body
+ *                      (grid_pass3_kernel) instead of small_pass3_kernel.
  *                      1 (default) | 0.  Not used with "vars_per_pass" 1, "tail_pass_vars" 2, an explicit
  *                      "first_pass_vars" for the first pass, or "resident" - those name their own schedules.
  *   "tail_log"         shard log-size at which a sharded prover gathers (default 16)

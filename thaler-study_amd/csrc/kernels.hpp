@@ -758,23 +758,15 @@ __device__ __forceinline__ void grid_fold(const F& f, const u64* __restrict__ A,
   A2[i] = va;
   B2[i] = vb;
 }
+// the block's sums: thread c < 3^ks returns cell c
 template <class F>
-__global__ void __launch_bounds__(kBlock)
-grid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
-                 GridW gw, int kf, int ks, size_t n_out, GridOut out) {
+__device__ __forceinline__ u64 grid_pass_body(const F& f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
+                                              u64* __restrict__ B2, const GridW& gw, int kf, int ks, size_t n_out) {
   constexpr int kMaxExt = (kGridChunk >> kGridMaxVars) * kGridMaxCells;   // 8 groups x 243 cells: the largest of the five
   __shared__ u64 ea[kMaxExt], eb[kMaxExt];
   __shared__ u64 red[kBlock];
   __shared__ int cell_of[1 << kGridMaxVars], suffix_of[1 << kGridMaxVars];
-  __shared__ int lds_flag;
   const int tid = threadIdx.x;
-#ifdef SC_GRID_STAMPS
-  __shared__ unsigned long long stamps[12];
-#define SC_GSTAMP(k) do { if (tid == 0) stamps[k] = wall_clock64(); } while (0)
-#else
-#define SC_GSTAMP(k) do { } while (0)
-#endif
-  SC_GSTAMP(0);
   const int cells = grid_pow3(ks), G = 1 << ks, groups = kGridChunk >> ks;
   if (tid < (1 << kGridMaxVars)) {
     // cell of a group's entry e (its bits are the points of the group's variables, variable 0 = bit 0) and the
@@ -795,7 +787,6 @@ grid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64*
   typename F::Acc acc;
   f.acc_zero(acc);
   __syncthreads();
-  SC_GSTAMP(1);
 
   const size_t n_chunks = (n_out + kGridChunk - 1) / kGridChunk;
   for (size_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
@@ -818,7 +809,6 @@ grid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64*
       eb[slot] = vb;
     }
     __syncthreads();
-    SC_GSTAMP(2);
     // 2. extend, one variable per level
     for (int j = 0; j < ks; ++j) {
       const int low = ks - 1 - j, pj = grid_pow3(j), stride = grid_pow3(low), items = (groups * pj) << low;
@@ -832,7 +822,6 @@ grid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64*
       }
       __syncthreads();
     }
-    SC_GSTAMP(3);
     // 3. multiply
     if (multiplies) {
       for (int g = my_split; g < groups; g += S) f.acc_mac(acc, ea[g * cells + my_cell], eb[g * cells + my_cell]);
@@ -840,14 +829,22 @@ grid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64*
     __syncthreads();
   }
 
-  SC_GSTAMP(4);
   red[tid] = multiplies ? f.acc_get(acc) : 0;
   __syncthreads();
-  SC_GSTAMP(5);
   u64 total = 0;
   if (tid < cells) {
     for (int sp = 0; sp < S; ++sp) total = f.add(total, red[sp * cells + tid]);
   }
+  return total;
+}
+
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+grid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
+                 GridW gw, int kf, int ks, size_t n_out, GridOut out) {
+  __shared__ int lds_flag;
+  const int tid = threadIdx.x, cells = grid_pow3(ks);
+  u64 total = grid_pass_body<F>(f, A, B, A2, B2, gw, kf, ks, n_out);
   if (gridDim.x > 1) {
     if (tid < cells)
       __hip_atomic_store(out.partials + (size_t)blockIdx.x * kGridChunk + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -880,15 +877,21 @@ grid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64*
         total = f.add(total, __hip_atomic_load(out.partials + (size_t)b * kGridChunk + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
   }
-  SC_GSTAMP(6);
   if (tid < cells) __hip_atomic_store(out.mailbox + kMailboxWide + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
-  SC_GSTAMP(7);
-#ifdef SC_GRID_STAMPS
-  if (tid < 8) __hip_atomic_store(out.mailbox + kMailboxWide + 244 + tid, (u64)stamps[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  __syncthreads();
-#endif
   if (tid == 0) __hip_atomic_store(out.mailbox + kMailboxSeq, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// The same body for the three-round passes on tables too large for one row of partials per block (folded tables
+// of 2^15 .. 2^20 entries, any number of blocks) and for sharded passes: the 27 cells leave through finish_pass
+// (split limbs, ticket over sum-major rows, in-kernel exchange) like those of pass_kernel.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+grid_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
+                  GridW gw, int kf, size_t n_out, PassOut out) {
+  __shared__ int lds_flag;
+  const u64 mine = grid_pass_body<F>(f, A, B, A2, B2, gw, kf, 3, n_out);
+  finish_pass<F, 27>(f, out, mine, &lds_flag);
 }
 
 // ------------------------------------------------------------------------------------

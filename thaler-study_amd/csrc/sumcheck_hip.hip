@@ -111,6 +111,7 @@ struct sc_ctx {
   int grid_max_vars = 5;    // most rounds one of them serves (1..5)
   int grid_vars4_log = 14;  // largest folded table that gets four rounds ...
   int grid_vars5_log = 11;  // ... and five
+  int mid_pass = 1;         // three-round tail passes above that size by the same body (grid_pass3_kernel) instead of small_pass3_kernel
   int grid_blocks = 64;     // most blocks of such a launch (each takes chunks of 256 folded entries)
   u64* d_gpartials = nullptr;   // [kGridMaxBlocks][kGridChunk]
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
@@ -454,7 +455,9 @@ template <class F>
 int pass_resident_blocks_t(sc_ctx* ctx, int kf, int ks) {
   const void* fn = nullptr;
 #define SC_FN(KF, KS) fn = reinterpret_cast<const void*>(&sc::pass_kernel<F, KF, KS, 1>)
-  if (ks == 3 && kf > 0) {
+  if (ks == 3 && kf > 0 && ctx->mid_pass) {
+    fn = reinterpret_cast<const void*>(&sc::grid_pass3_kernel<F>);
+  } else if (ks == 3 && kf > 0) {
     if (kf == 1) fn = reinterpret_cast<const void*>(&sc::small_pass3_kernel<F, 1>);
     else if (kf == 2) fn = reinterpret_cast<const void*>(&sc::small_pass3_kernel<F, 2>);
     else fn = reinterpret_cast<const void*>(&sc::small_pass3_kernel<F, 3>);
@@ -509,6 +512,12 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
     else                                                                                                           \
       hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS, 0>), g, b, 0, s, f, A, B, A2, B2, fw, n_units, out);          \
   } while (0)
+  if (ks == 3 && kf > 0 && ctx->mid_pass) {  // tail pass by the grid-pass body (kernels.hpp, grid_pass3_kernel)
+    sc::GridW gw;
+    for (int c = 0; c < (1 << sc::kGridMaxVars); ++c) gw.w[c] = c < 8 ? fw.w[c] : 0;
+    hipLaunchKernelGGL((sc::grid_pass3_kernel<F>), g, b, 0, s, f, A, B, A2, B2, gw, kf, n_units * 8, out);
+    return;
+  }
   if (ks == 3 && kf > 0) {  // tail pass: one thread per output (kernels.hpp, small_pass3_kernel)
     const size_t n_out = n_units * 8;
     switch (kf) {
@@ -633,15 +642,6 @@ int collect_grid(sc_ctx* ctx, int ks, u64* out) {
   int cells = 1;
   for (int i = 0; i < ks; ++i) cells *= 3;
   for (int c = 0; c < cells; ++c) out[c] = ctx->h_mailbox[sc::kMailboxWide + c];
-#ifdef SC_GRID_STAMPS
-  {
-    const u64* st = ctx->h_mailbox + sc::kMailboxWide + 244;
-    fprintf(stderr, "grid stamps (10 ns): init %llu fold %llu extend %llu mult %llu get %llu reduce+xblock %llu publish %llu\n",
-            (unsigned long long)(st[1] - st[0]), (unsigned long long)(st[2] - st[1]), (unsigned long long)(st[3] - st[2]),
-            (unsigned long long)(st[4] - st[3]), (unsigned long long)(st[5] - st[4]), (unsigned long long)(st[6] - st[5]),
-            (unsigned long long)(st[7] - st[6]));
-  }
-#endif
   return SC_OK;
 }
 
@@ -1240,6 +1240,9 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "grid_vars5_log") {
     if (value < 0 || value > 14) return fail(ctx, SC_ERR_ARG, "grid_vars5_log out of range (0..14)");
     ctx->grid_vars5_log = (int)value;
+  } else if (k == "mid_pass") {
+    ctx->mid_pass = value ? 1 : 0;
+    memset(ctx->resident_blocks, 0, sizeof(ctx->resident_blocks));   // the cached grids of the tail passes belong to the other kernel
   } else if (k == "grid_blocks") {
     if (value < 1 || value > kGridMaxBlocks) return fail(ctx, SC_ERR_ARG, "grid_blocks must be 1..%d", kGridMaxBlocks);
     ctx->grid_blocks = (int)value;
@@ -1293,6 +1296,7 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   else if (k == "grid_vars4_log") *value = ctx->grid_vars4_log;
   else if (k == "grid_vars5_log") *value = ctx->grid_vars5_log;
   else if (k == "grid_blocks") *value = ctx->grid_blocks;
+  else if (k == "mid_pass") *value = ctx->mid_pass;
   else if (k == "tail_log") *value = ctx->tail_log;
   else if (k == "max_blocks") *value = ctx->max_blocks;
   else if (k == "time_kernels") *value = ctx->time_kernels;

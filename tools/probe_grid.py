@@ -1,4 +1,5 @@
-"""A/B of the grid passes (option grid_pass) at several n: transcript equality, proof time, launches per proof"""
+"""A/B of one 0/1 library option (SC_PROBE_AB, default grid_pass) at several n: transcript equality, proof time and
+the launches of a proof; SC_PROBE_OPTIONS="k=v,..." sets other options first"""
 import os, sys, time
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -17,7 +18,7 @@ for n in ns:
     out = {}
     for rep in range(2):
         for opt in (0, 1):
-            ctx.set_option("grid_pass", opt)
+            ctx.set_option(os.environ.get("SC_PROBE_AB", "grid_pass"), opt)
             r = mm.prove(ctx, g, syn.SEED_R)
             for _ in range(10):
                 mm.prove(ctx, g, syn.SEED_R)
@@ -34,8 +35,8 @@ for n in ns:
             ctx.set_option("time_kernels", 0)
             out[opt] = (r, ts[len(ts) // 2], " ".join("%s%d,%d:%.1f" % ("g" if x["kind"] == "grid_pass" else "", x["kf"], x["ks"], x["ms"] * 1e3) for x in log))
         same = out[0][0][0] == out[1][0][0] and np.array_equal(out[0][0][1], out[1][0][1])
-        print("n=%2d same=%s  launches: proof %.4f ms   grid: proof %.4f ms" % (n, same, out[0][1], out[1][1]), flush=True)
+        print("n=%2d same=%s  off: proof %.4f ms   on: proof %.4f ms" % (n, same, out[0][1], out[1][1]), flush=True)
         if rep == 1:
-            print("      old :", out[0][2])
-            print("      grid:", out[1][2], flush=True)
+            print("      off :", out[0][2])
+            print("      on  :", out[1][2], flush=True)
     del a, b, g
