@@ -65,7 +65,7 @@ def kernel_name(rec):
     if k == "pass":
         return "sc::pass_kernel<GoldilocksMont,%d,%d> on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
     if k == "tail_pass":
-        return "sc::small_pass3_kernel<GoldilocksMont,%d> on 2^%d-entry tables" % (rec["kf"], rec["log_in"])
+        return "sc::grid_pass3_kernel<GoldilocksMont> (kf=%d, ks=3; small_pass3_kernel with mid_pass=0) on 2^%d-entry tables" % (rec["kf"], rec["log_in"])
     if k == "grid_pass":
         return "sc::grid_pass_kernel<GoldilocksMont> (kf=%d, ks=%d) on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
     if k == "tail_resident":
@@ -305,6 +305,8 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
     alg_bytes = 64 * 2**n - 96
     value = muladds * args.steps / elapsed
     kernels = aggregate_launches(log, steps_with_events)
+    per_step = len(log) // max(steps_with_events, 1)
+    schedule = [[r["kind"], r["kf"], r["ks"], r["log_in"]] for r in log[:per_step]]    # the launches of one proof, in order
     kernel_ms_per_step = kernel_ms / max(steps_with_events, 1)
     moved = sum(k["bytes_per_launch"] * k["launches_per_step"] for k in kernels)    # this rank's launches
     ms_per_step = elapsed / args.steps * 1e3
@@ -358,7 +360,7 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                 "tail_pass_vars": ctx.get_option("tail_pass_vars"),
                 "parallelism": "hypercube-shard x%d" % world,
                 "parity_gate": "verifier identities at n=%d ok" % n,
-                "transport": transport, "options": dict(context_options()),
+                "transport": transport, "options": dict(context_options()), "schedule": schedule,
                 "ms_per_step_median_unsampled": statistics.median(unsampled) if unsampled else None,
             },
             "roofline": {

@@ -861,20 +861,32 @@ grid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64*
     }
     __syncthreads();
     if (!lds_flag) return;
+    // column sums of the [block][256] partials: thread = (cell, slice), every load of a thread in flight at once
+    // (a round of dependent loads costs ~0.6 us from L2: eight rounds of eight were most of this hand-off)
+    __shared__ u64 colsum[kBlock];
+    const int n_blocks = gridDim.x, slices = max(1, kBlock / cells);
+    const int cell = tid % cells, slice = tid / cells;
+    u64 part = 0;
+    if (slice < slices) {
+      constexpr int U = 32;
+      for (int b0 = slice; b0 < n_blocks; b0 += slices * U) {
+        u64 x[U];
+#pragma unroll
+        for (int q = 0; q < U; ++q) {
+          const int b = b0 + q * slices;
+          x[q] = (b < n_blocks)
+                     ? __hip_atomic_load(out.partials + (size_t)b * kGridChunk + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                     : 0;
+        }
+#pragma unroll
+        for (int q = 0; q < U; ++q) part = f.add(part, x[q]);
+      }
+    }
+    colsum[tid] = part;
+    __syncthreads();
     total = 0;
     if (tid < cells) {
-      const int n_blocks = gridDim.x;
-      int b = 0;
-      for (; b + 8 <= n_blocks; b += 8) {
-        u64 x[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          x[q] = __hip_atomic_load(out.partials + (size_t)(b + q) * kGridChunk + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) total = f.add(total, x[q]);
-      }
-      for (; b < n_blocks; ++b)
-        total = f.add(total, __hip_atomic_load(out.partials + (size_t)b * kGridChunk + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      for (int sl = 0; sl < slices; ++sl) total = f.add(total, colsum[sl * cells + tid]);
     }
   }
   if (tid < cells) __hip_atomic_store(out.mailbox + kMailboxWide + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
