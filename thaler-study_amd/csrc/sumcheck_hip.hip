@@ -1925,6 +1925,10 @@ struct sc_prover {
   // cache of the last pass
   int cache_ks = 0;
   size_t cache_round = 0;
+  // the grid S with its leading `g_known` axes collapsed at the challenges received since the pass (prover_answer's
+  // working copy: each round collapses one more axis instead of starting from S again); g_known < 0: not built
+  mutable u64 G[sc::kGridMaxCells];
+  mutable int g_known = -1;
   u64 S[sc::kGridMaxCells];
   u64 c1 = 0;
   // resident kernel serving this prover's remaining passes (kernels.hpp, resident_kernel)
@@ -2118,6 +2122,7 @@ void resident_advance(sc_prover* pr, int p, size_t j) {
   pr->cur_log -= pr->res.plan.kf[p];
   pr->pending.clear();
   pr->cache_ks = pr->res.plan.ks[p];
+  pr->g_known = -1;
   pr->cache_round = j;
   pr->res.next_phase = p + 1;
 }
@@ -2373,6 +2378,7 @@ int prover_pass(sc_prover* pr, size_t j) {
   }
   pr->cache_ks = ks;
   pr->cache_round = j;
+  pr->g_known = -1;
   return SC_OK;
 }
 
@@ -2384,12 +2390,17 @@ int prover_pass(sc_prover* pr, size_t j) {
 // after it are summed over {0,1}.
 void prover_answer(const sc_prover* pr, size_t j, u64 e[3]) {
   HostField hf(pr->ctx->fp);
-  u64 g[sc::kGridMaxCells];
-  int cells = 1;
-  for (int i = 0; i < pr->cache_ks; ++i) cells *= 3;
-  for (int i = 0; i < cells; ++i) g[i] = pr->S[i];
+  int total = 1;
+  for (int i = 0; i < pr->cache_ks; ++i) total *= 3;
   const int known = (int)(j - pr->cache_round);  // == pr->pending.size()
-  for (int i = 0; i < known; ++i) {
+  u64* g = pr->G;
+  if (pr->g_known < 0 || pr->g_known > known) {
+    for (int i = 0; i < total; ++i) g[i] = pr->S[i];
+    pr->g_known = 0;
+  }
+  int cells = total;
+  for (int i = 0; i < pr->g_known; ++i) cells /= 3;
+  for (int i = pr->g_known; i < known; ++i) {
     const u64 r = pr->pending[i];
     const u64 r2 = hf.mul(r, r);
     cells /= 3;
@@ -2399,6 +2410,7 @@ void prover_answer(const sc_prover* pr, size_t j, u64 e[3]) {
       g[c] = hf.add(hf.add(s0, hf.mul(r, lin)), hf.mul(r2, si));
     }
   }
+  pr->g_known = known;
   const int rest = cells / 3;  // cells per value of the round's variable
   u64 h[3];
   for (int x = 0; x < 3; ++x) {
