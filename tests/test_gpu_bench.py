@@ -71,6 +71,31 @@ def test_bench_two_ranks_on_one_device():
 
 
 @pytest.mark.gpu
+def test_bench_eight_ranks_n28_on_one_device():
+    """BASELINE config 4 at its stated shape - n = 28 over 8 ranks of 2^25-entry shards - through the driver's launch
+    line and the default data plane (in-kernel exchange through HIP-IPC-mapped inboxes), the eight processes sharing
+    GPU 0 (what a one-GPU box can run: everything but xGMI).  The run gates on the verifier identities of the n = 28
+    transcript; its sharded schedule ends in the unsharded grid passes after the gather."""
+    env = dict(os.environ, SC_BENCH_SINGLE_DEVICE="1")
+    env.pop("SC_BENCH_TRANSPORT", None)
+    port = 29750 + (os.getpid() % 90)
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8",
+                          "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                          "--gpus", "8", "--steps", "6", "--warmup", "2", "--cpu-num-vars", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-1500:], out.stderr[-1500:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["scaling"] == "strong" and d["value"] > 0
+    c = d["config"]
+    assert c["num_vars"] == 28 and c["transport"] == "peer" and "verifier identities at n=28 ok" in c["parity_gate"]
+    sched = c["schedule"]
+    assert sched[0] == ["pass", 0, 3, 25] and sched[-1][0] == "grid_pass"       # 2^25-entry shards; the tail is unsharded
+    assert sum(s[2] for s in sched) == 28
+
+
+@pytest.mark.gpu
 def test_bench_mle_workload():
     """--workload mle (BASELINE configs[1]): evaluate + fix_variables, own roofline object, parity gate"""
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "mle", "--num-vars", "20", "--steps", "5",
