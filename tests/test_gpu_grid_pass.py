@@ -54,7 +54,7 @@ def test_default_schedule_uses_grid_passes(pkg, p):
     {"grid_log": 3}, {"grid_log": 8, "grid_vars5_log": 8, "grid_vars4_log": 8},
     {"grid_vars5_log": 14}, {"grid_vars5_log": 0, "grid_vars4_log": 0},
     {"grid_blocks": 1}, {"grid_blocks": 3}, {"grid_blocks": 7, "grid_vars5_log": 13},
-    {"grid_pass": 0},
+    {"grid_pass": 0}, {"mid_pass": 0}, {"grid_pass": 0, "mid_pass": 0},
 ], ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()))
 def test_every_grid_schedule_matches_the_oracle(pkg, opts):
     for p in (GOLD, 1572869):
@@ -63,7 +63,7 @@ def test_every_grid_schedule_matches_the_oracle(pkg, opts):
             ctx.set_option(k, v)
             assert ctx.get_option(k) == v
         o = oracle(p)
-        for n in (1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 13, 14, 15, 17):
+        for n in (1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 13, 14, 15, 17, 19):
             log = prove_and_check(pkg, ctx, o, n, seed_shift=n)
             if opts.get("grid_pass", 1) == 0:
                 assert all(r["kind"] != "grid_pass" for r in log)
