@@ -121,6 +121,29 @@ def test_extreme_words_through_grid_passes(pkg):
     ctx.close()
 
 
+def test_random_schedules(pkg):
+    """seeded fuzz over the schedule options (all of them legal): whatever mix of pass widths, grid limits and block
+    counts the planner is given, the transcript is the oracle's"""
+    import random
+    rng = random.Random(20260)
+    for it in range(48):
+        p = rng.choice([GOLD, GOLD, 389, 2**64 - 59])
+        ctx = pkg.Context(pkg.Field(p))
+        opts = {"grid_pass": rng.choice([1, 1, 1, 0]), "mid_pass": rng.choice([1, 1, 0]), "grid_log": rng.randrange(0, 15),
+                "grid_max_vars": rng.randrange(1, 6), "grid_vars4_log": rng.randrange(0, 15), "grid_vars5_log": rng.randrange(0, 15),
+                "grid_blocks": rng.randrange(1, 65), "first_pass_vars": rng.choice([0, 0, 1, 2, 3]),
+                "tail_pass_log": rng.choice([10, 19, 21]), "max_blocks": rng.choice([7, 64, 768])}
+        for k, v in opts.items():
+            ctx.set_option(k, v)
+        o = oracle(p)
+        for n in rng.sample(range(1, 21), 4):
+            try:
+                prove_and_check(pkg, ctx, o, n, seed_shift=it)
+            except AssertionError as e:
+                raise AssertionError("options %r, p=%d, n=%d: %s" % (opts, p, n, e))
+        ctx.close()
+
+
 def test_option_ranges(pkg):
     ctx = pkg.Context(pkg.Field(GOLD))
     for k, bad in [("grid_log", 15), ("grid_max_vars", 0), ("grid_max_vars", 6), ("grid_vars4_log", 15), ("grid_vars5_log", -1),
