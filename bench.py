@@ -170,7 +170,9 @@ def setup_transport(args, pkg, ctx_factory, rank, world, dist):
         if want in ("", "peer"):
             ok, handle = True, None
             try:
-                ctx.set_option("peer_spin_ms", 5000)
+                # the bound of an in-kernel wait for a peer: only a failure detector, so generous - on a freshly
+                # started box a rank can stall for many seconds paging code in (measured: > 20 s with eight ranks)
+                ctx.set_option("peer_spin_ms", 60000)
                 handle = ctx.comm_peer_export(rank, world)
             except Exception as e:  # pragma: no cover - depends on the node
                 ok, err = False, str(e)

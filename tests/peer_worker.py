@@ -26,7 +26,7 @@ def main():
     for p in (pyref.GOLDILOCKS, 389):
         o = Oracle(p)
         ctx = pkg.Context(pkg.Field(p), device=0)
-        ctx.set_option("peer_spin_ms", 20000)
+        ctx.set_option("peer_spin_ms", 60000)   # a failure detector: generous (a cold box stalls ranks for many seconds)
         D.attach_peer(ctx, rank, world)
         assert ctx.rank_world() == (rank, world)
         for n, tail_log in [(1, 0), (2, 0), (5, 0), (12, 0), (12, 5), (16, 12), (20, 16), (22, 16)]:

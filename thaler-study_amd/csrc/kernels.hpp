@@ -347,7 +347,11 @@ __device__ __forceinline__ void exchange_and_publish(const PassOut& o, u64* xl) 
             else total += g & 0xFFFFFFFFull;
             break;
           }
-          if ((++spins & 31) == 0 && wall_clock64() - t0 > px.spin_ticks) { err = kXchgTimeout; break; }
+          if ((++spins & 31) == 0 && wall_clock64() - t0 > px.spin_ticks) {
+            // diagnosis for the host's message: which source, and the tag its slot still held
+            err = kXchgTimeout | (r << 8) | ((int)((g >> 32) & 0xFFFF) << 16);
+            break;
+          }
           __builtin_amdgcn_s_sleep(1);
         }
       }

@@ -714,7 +714,9 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
         return fail(ctx, SC_ERR_STATE, "the ranks of this sharded prover were given different challenges");
       if (err != 0) {
         poison(ctx);
-        return fail(ctx, SC_ERR_RCCL, "peer exchange: a rank's sums did not arrive within %d ms", ctx->peer_spin_ms);
+        return fail(ctx, SC_ERR_RCCL, "peer exchange: a rank's sums did not arrive within %d ms (rank %d waited for rank %d at tag %u; "
+                    "that rank's slot held tag ..%04x)", ctx->peer_spin_ms, ctx->rank, (int)((err >> 8) & 0xFF), ctx->xchg_tag,
+                    (unsigned)((err >> 16) & 0xFFFF));
       }
     }
   } else if (across_ranks && ctx->transport == Transport::kPeer) {
