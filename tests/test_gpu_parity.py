@@ -22,6 +22,18 @@ def pkg():
 _ctxs = {}
 
 
+@pytest.fixture(scope="module", autouse=True)
+def _close_cached_contexts():
+    """every cached context holds a stream (a hardware queue) and pinned buffers: give them back when the module is done"""
+    yield
+    for c in _ctxs.values():
+        try:
+            c.close()
+        except Exception:
+            pass
+    _ctxs.clear()
+
+
 def schedule_options(vpp):
     """test shorthand for the prover schedule: 1 = one round per pass; 2 = two rounds per pass;
     3 = two rounds per pass, three from the first pass and from every small tail pass (what the

@@ -14,19 +14,6 @@ pytestmark = pytest.mark.gpu
 
 
 
-def _quiet(text, n=3000):
-    """stderr of a torchrun launch without the rendezvous chatter"""
-    keep = [l for l in text.splitlines() if "[Gloo]" not in l and "socket.cpp" not in l and "amdgpu.ids" not in l]
-    try:   # the whole text for a post-mortem (gpurun_out/ travels back from the GPU box)
-        import os
-        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
-        os.makedirs(d, exist_ok=True)
-        with open(os.path.join(d, "failed_launch_%d.log" % os.getpid()), "a") as fh:
-            fh.write("\n".join(keep) + "\n=====\n")
-    except OSError:
-        pass
-    return "\n".join(keep)[-n:]
-
 class Loopback:
     """sum / concatenate across `world` threads"""
 
@@ -221,7 +208,7 @@ def test_virtual_ranks_peer_transport(p, world):
     Two ranks only when the ranks are threads of ONE process: a workgroup that waits for a peer needs the
     peer's kernel to run beside it, and one process's streams share a handful of hardware queues (with four
     contexts a waiting kernel can sit in front of the kernel it waits for: measured, bounded by peer_spin_ms).
-    One process per rank - the deployment - has no such coupling; the test below runs 2 and 4 processes."""
+    One process per rank - the deployment - has no such coupling; tests/test_gpu_00_multiprocess.py runs 2 and 8 processes."""
     pkg = load_package()
     o = oracle(p)
     g = world.bit_length() - 1
@@ -238,25 +225,3 @@ def test_virtual_ranks_peer_transport(p, world):
             if e0 is not None:
                 assert e0 == [int(x) for x in ref["evals"][0]]
 
-
-@pytest.mark.parametrize("nproc", [2, 8])
-def test_peer_transport_processes_one_device(nproc):
-    """2 / 8 PROCESSES on GPU 0 exchanging HIP IPC handles (the mapping a multi-GPU node uses, minus xGMI): sharded
-    proofs, sharded evaluate and the degenerate paths, bit-exact against the oracle on every rank"""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    port = 29950 + (os.getpid() % 40)
-    # (on a freshly started box one of eight ranks sharing the GPU can stall for tens of seconds; the others then wait
-    # until peer_spin_ms and report which rank they waited for - up to three attempts)
-    for attempt in range(3):
-        out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
-                              "--master-addr", "127.0.0.1", "--master-port", str(port + nproc + 11 * attempt),
-                              os.path.join(root, "tests", "peer_worker.py")],
-                             capture_output=True, text=True, timeout=600, cwd=root)
-        if out.returncode == 0 or "did not arrive within" not in (out.stderr + out.stdout):
-            break
-        _quiet(out.stderr)      # keep the failed attempt's text for a post-mortem
-    assert out.returncode == 0, (_quiet(out.stdout, 1500), _quiet(out.stderr))
-    assert out.stdout.count("PEER-OK") == nproc, out.stdout[-3000:]
