@@ -67,7 +67,7 @@ def kernel_name(rec):
     if k == "tail_pass":
         return "sc::grid_pass3_kernel<GoldilocksMont> (kf=%d, ks=3; small_pass3_kernel with mid_pass=0) on 2^%d-entry tables" % (rec["kf"], rec["log_in"])
     if k == "grid_pass":
-        return "sc::grid_pass_kernel<GoldilocksMont> (kf=%d, ks=%d) on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
+        return "sc::wgrid_pass_kernel<GoldilocksMont,ks> (kf=%d, ks=%d) on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
     if k == "tail_resident":
         return "sc::tail_resident_kernel<GoldilocksMont> from 2^%d-entry tables (%d rounds)" % (rec["log_in"], rec["ks"])
     if k == "evaluate":

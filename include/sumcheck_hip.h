@@ -83,14 +83,14 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      (never more than vars_per_pass allows)
  *   "tail_pass_vars"   rounds served by a folding pass whose input has <= 2^"tail_pass_log"
  *                      (default 19) entries, where every pass is latency-bound: 3 (default) | 2
- *   "grid_pass"        the passes whose FOLDED tables have <= 2^"grid_log" (default 14, at most 14) entries serve up to
+ *   "grid_pass"        the passes whose FOLDED tables have <= 2^"grid_log" (default 20) entries serve up to
  *                      "grid_max_vars" (default 5) rounds each and fold up to five pending challenges at once
- *                      (grid_pass_kernel, unsharded passes only): five rounds on tables of <= 2^"grid_vars5_log" (11)
- *                      entries, four up to 2^"grid_vars4_log" (14), else three; "grid_blocks" (64) caps the launch.
- *                      "mid_pass" (1): three-round tail passes on larger tables and sharded ones run the same body
- *                      (grid_pass3_kernel) instead of small_pass3_kernel.
- *                      1 (default) | 0.  Not used with "vars_per_pass" 1, "tail_pass_vars" 2, an explicit
- *                      "first_pass_vars" for the first pass, or "resident" - those name their own schedules.
+ *                      (wgrid_pass_kernel, unsharded passes only).  "grid_vars5_log" / "grid_vars4_log" bound the
+ *                      folded size that gets five / four rounds (default: no bound below grid_log); "grid_blocks"
+ *                      caps the launch (0 = what is resident).  1 (default) | 0.  Not used with "vars_per_pass" 1,
+ *                      "tail_pass_vars" 2, an explicit "first_pass_vars" for the first pass, or "resident" - those
+ *                      name their own schedules.  "mid_pass" (1): the three-round tail passes outside this planner
+ *                      (sharded ones) run grid_pass3_kernel instead of small_pass3_kernel.
  *   "tail_log"         shard log-size at which a sharded prover gathers (default 16)
  *   "max_blocks"       grid cap of the streaming kernels (default 3 per CU = 768); a pass never
  *                      launches more blocks than are resident at once
@@ -129,7 +129,7 @@ int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset);
 #define SC_KIND_GKR 7        /* GKR W pass: fold add/mul/w + round sums */
 #define SC_KIND_MATSQ 8      /* triangle counting: square of the adjacency matrix */
 #define SC_KIND_TAIL_RESIDENT 9 /* resident tail kernel: all remaining rounds of a small instance in one launch */
-#define SC_KIND_GRID_PASS 10 /* grid_pass_kernel: fold kf <= 5 variables of small tables + the 3^ks cells of ks <= 5 rounds */
+#define SC_KIND_GRID_PASS 10 /* wgrid_pass_kernel: fold kf <= 5 variables of tables of <= 2^20 folded entries + the 3^ks cells of ks <= 5 rounds */
 typedef struct sc_launch_record {
   int32_t kind;           /* SC_KIND_* */
   int32_t kf, ks;         /* variables folded / rounds served (meaning per kind above) */

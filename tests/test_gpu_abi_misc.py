@@ -25,8 +25,8 @@ def test_launch_log_records_what_ran():
     pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
     log = ctx.launch_log(reset=False)
     assert log == ctx.launch_log(reset=True) and ctx.launch_log() == []
-    # the schedule of DESIGN.md section 4 at n = 20: first pass three rounds, then folds; sizes shrink by kf
-    assert log[0]["kind"] == "pass" and (log[0]["kf"], log[0]["ks"], log[0]["log_in"]) == (0, 3, 20)
+    # the schedule of DESIGN.md section 4 at n = 20: four passes of five rounds; sizes shrink by kf
+    assert log[0]["kind"] == "grid_pass" and (log[0]["kf"], log[0]["ks"], log[0]["log_in"]) == (0, 5, 20)
     size, rounds = 20, 0
     for r in log:
         assert r["kind"] in ("pass", "tail_pass", "grid_pass") and r["log_in"] == size and r["ms"] > 0

@@ -1,5 +1,5 @@
-"""The passes on the smallest tables (grid_pass_kernel: up to five pending challenges folded, up to five
-rounds served per launch): every schedule the planner can produce gives the reference's transcript
+"""The passes on the smaller tables (wgrid_pass_kernel: up to five pending challenges folded, up to five
+rounds served per launch, folded tables of <= 2^20 entries): every schedule the planner can produce gives the reference's transcript
 (sum-check-protocol/src/lib.rs:105-112 one round at a time), bit for bit against the C oracle."""
 import numpy as np
 import pytest
@@ -36,24 +36,24 @@ def prove_and_check(pkg, ctx, o, n, seed_shift=0):
 def test_default_schedule_uses_grid_passes(pkg, p):
     ctx = pkg.Context(pkg.Field(p))
     o = oracle(p)
-    for n in range(1, 19):
+    for n in list(range(1, 19)) + [20, 21, 22]:
         log = prove_and_check(pkg, ctx, o, n)
         kinds = [r["kind"] for r in log]
-        # tables of <= 2^14 entries are proved by grid passes alone; larger ones end with them
+        # tables of <= 2^20 entries are proved by grid passes alone; larger ones end with them
         assert kinds[-1] == "grid_pass", (n, kinds)
-        if n <= 14:
+        if n <= 20:
             assert set(kinds) == {"grid_pass"}, (n, kinds)
+            assert len(log) == (n + 4) // 5, (n, log)                        # five rounds per launch
         assert sum(r["ks"] for r in log) == n, (n, log)                      # every round served exactly once
         assert all(r["kf"] <= 5 and 1 <= r["ks"] <= 5 for r in log)
-        assert len(log) <= (4 if n <= 14 else 6), (n, len(log))
     ctx.close()
 
 
 @pytest.mark.parametrize("opts", [
     {"grid_max_vars": 1}, {"grid_max_vars": 2}, {"grid_max_vars": 3}, {"grid_max_vars": 4},
-    {"grid_log": 3}, {"grid_log": 8, "grid_vars5_log": 8, "grid_vars4_log": 8},
-    {"grid_vars5_log": 14}, {"grid_vars5_log": 0, "grid_vars4_log": 0},
-    {"grid_blocks": 1}, {"grid_blocks": 3}, {"grid_blocks": 7, "grid_vars5_log": 13},
+    {"grid_log": 3}, {"grid_log": 8, "grid_vars5_log": 8, "grid_vars4_log": 8}, {"grid_log": 14, "grid_vars5_log": 11, "grid_vars4_log": 14},
+    {"grid_vars5_log": 14}, {"grid_vars5_log": 0, "grid_vars4_log": 0}, {"grid_log": 26},
+    {"grid_blocks": 1}, {"grid_blocks": 3}, {"grid_blocks": 33}, {"grid_blocks": 70, "grid_vars5_log": 13},
     {"grid_pass": 0}, {"mid_pass": 0}, {"grid_pass": 0, "mid_pass": 0},
 ], ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()))
 def test_every_grid_schedule_matches_the_oracle(pkg, opts):
@@ -63,7 +63,7 @@ def test_every_grid_schedule_matches_the_oracle(pkg, opts):
             ctx.set_option(k, v)
             assert ctx.get_option(k) == v
         o = oracle(p)
-        for n in (1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 13, 14, 15, 17, 19):
+        for n in (1, 2, 3, 4, 5, 6, 7, 9, 10, 11, 13, 14, 15, 17, 19, 21):
             log = prove_and_check(pkg, ctx, o, n, seed_shift=n)
             if opts.get("grid_pass", 1) == 0:
                 assert all(r["kind"] != "grid_pass" for r in log)
@@ -106,7 +106,7 @@ def test_extreme_words_through_grid_passes(pkg):
     ctx = pkg.Context(pkg.Field(p))
     o = oracle(p)
     for n, pattern in [(5, [p - 1]), (10, [p - 1, p - 2]), (13, [p - 1, 0, 1, p - 1, p - 2, 0, 0xFFFFFFFF, 1 << 32]),
-                       (14, [p - 1, p - 1, p - 1, 0]), (16, [p - 1])]:
+                       (14, [p - 1, p - 1, p - 1, 0]), (16, [p - 1]), (20, [p - 1, p - 2, 0])]:
         words = np.array([pattern[i % len(pattern)] for i in range(1 << n)], dtype=np.uint64)
         other = words[::-1].copy()
         a = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, words)
@@ -129,14 +129,14 @@ def test_random_schedules(pkg):
     for it in range(48):
         p = rng.choice([GOLD, GOLD, 389, 2**64 - 59])
         ctx = pkg.Context(pkg.Field(p))
-        opts = {"grid_pass": rng.choice([1, 1, 1, 0]), "mid_pass": rng.choice([1, 1, 0]), "grid_log": rng.randrange(0, 15),
-                "grid_max_vars": rng.randrange(1, 6), "grid_vars4_log": rng.randrange(0, 15), "grid_vars5_log": rng.randrange(0, 15),
-                "grid_blocks": rng.randrange(1, 65), "first_pass_vars": rng.choice([0, 0, 1, 2, 3]),
+        opts = {"grid_pass": rng.choice([1, 1, 1, 0]), "mid_pass": rng.choice([1, 1, 0]), "grid_log": rng.randrange(0, 23),
+                "grid_max_vars": rng.randrange(1, 6), "grid_vars4_log": rng.randrange(0, 23), "grid_vars5_log": rng.randrange(0, 23),
+                "grid_blocks": rng.choice([0, 0, 1, 2, 5, 31, 32, 33, 64, 100, 1024]), "first_pass_vars": rng.choice([0, 0, 1, 2, 3]),
                 "tail_pass_log": rng.choice([10, 19, 21]), "max_blocks": rng.choice([7, 64, 768])}
         for k, v in opts.items():
             ctx.set_option(k, v)
         o = oracle(p)
-        for n in rng.sample(range(1, 21), 4):
+        for n in rng.sample(range(1, 23), 4):
             try:
                 prove_and_check(pkg, ctx, o, n, seed_shift=it)
             except AssertionError as e:
@@ -146,8 +146,8 @@ def test_random_schedules(pkg):
 
 def test_option_ranges(pkg):
     ctx = pkg.Context(pkg.Field(GOLD))
-    for k, bad in [("grid_log", 15), ("grid_max_vars", 0), ("grid_max_vars", 6), ("grid_vars4_log", 15), ("grid_vars5_log", -1),
-                   ("grid_blocks", 0), ("grid_blocks", 65)]:
+    for k, bad in [("grid_log", 27), ("grid_max_vars", 0), ("grid_max_vars", 6), ("grid_vars4_log", 27), ("grid_vars5_log", -1),
+                   ("grid_blocks", -1), ("grid_blocks", 1025)]:
         with pytest.raises(Exception):
             ctx.set_option(k, bad)
     ctx.close()

@@ -52,7 +52,7 @@ def test_first_pass_occupancy_and_no_scratch(isa):
     assert u["ScratchSize [bytes/lane]"] == 0 and u["VGPRs Spill"] == 0 and u["SGPRs Spill"] == 0, u
     assert u["VGPRs"] <= 256
     for frag in ("pass_kernel%sLi3ELi2ELi3E" % GOLD, "pass_kernel%sLi2ELi2ELi1E" % GOLD, "small_pass3_kernel%sLi3E" % GOLD,
-                 "evaluate_kernel%sLb1E" % GOLD, "fix_low_kernel%sLb1E" % GOLD, "grid_pass_kernel%s" % GOLD,
+                 "evaluate_kernel%sLb1E" % GOLD, "fix_low_kernel%sLb1E" % GOLD, "wgrid_pass_kernel%sLi5E" % GOLD,
                  "grid_pass3_kernel%s" % GOLD):
         u = kernel_usage(usage, frag)
         assert u["ScratchSize [bytes/lane]"] == 0 and u["VGPRs Spill"] == 0, (frag, u)

@@ -694,169 +694,207 @@ small_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u6
 }
 
 // ------------------------------------------------------------------------------------
-// Up to FIVE rounds per pass for the tables at the end of a proof (folded size <= 2^14 entries or so).
+// Up to FIVE rounds per pass on the smaller tables of a proof (folded size <= 2^20 entries).
 //
-// The tail of a proof is a chain of passes whose cost is latency - launch, one dependent chain of work,
-// hand-off to the host - and not bytes; at 8 GPUs (2^25-entry shards) it is more than half of the proof.
-// Two things shorten it: fewer passes (a pass that serves KS rounds accumulates the 3^KS-cell grid in the
-// {0,1,inf} basis; for KS = 4, 5 that is 81 / 243 cells over groups of 16 / 32 folded entries, a few
-// thousand products - nothing at these sizes) and a shorter dependent chain inside a pass (small_pass3_kernel
-// lets one thread in eight walk all 27 cells of its octet, ~600 instructions on a wave that issues alone at
-// half rate; here the cells are spread over the threads).  kf (0..5) and ks (1..5) are run-time values: these
-// launches are not throughput-bound and one kernel per field keeps the build small.
+// Below ~2^21 entries a pass is latency - launch, one dependent chain of work, hand-off to the host - and not
+// bytes; at 8 GPUs (2^25-entry shards) that is more than a third of the proof.  Two things shorten it: fewer
+// passes (a pass that serves KS rounds accumulates the 3^KS-cell grid in the {0,1,inf} basis; for KS = 4, 5 that is
+// 81 / 243 cells over groups of 16 / 32 folded entries - 5 to 7.6 products per entry, nothing at these sizes) and a
+// shorter dependent chain inside a pass (small_pass3_kernel lets one thread in eight walk all 27 cells of its
+// octet, ~600 instructions on a wave that issues alone at half rate, tools/valu_rate.hip).
 //
-// Per block iteration ("chunk") of kGridChunk = 256 folded entries per table:
-//  1. fold: thread t produces folded entry t of both tables, sum_c w[c] * in[2^kf t + c] (one lazy sum,
-//     one reduction), stores it to the folded tables and to its place in the block's extension arrays
-//  2. extend: ea/eb[group][cell], cell = sum_j d_j 3^(ks-1-j), d_j in {0,1,inf} the evaluation point of the
-//     group's variable j (variable 0 = index bit 0, the round served first: the slowest axis, as in
-//     pass_kernel); level j fills the cells with d_j = inf from d_j = 1 minus d_j = 0, one subtraction each,
-//     3^j 2^(ks-1-j) per group and level, all threads, one barrier per level
-//  3. multiply: thread (cell c, split s) adds ea[g][c] * eb[g][c] over the groups g = s (mod S) to ITS lazy
-//     accumulator, which lives across chunks
-// End: accumulators -> residues, the S splits of a cell are added through LDS, thread c < 3^ks holds cell c.
-// Several blocks: partials [block][256], ticket, the last block's thread c adds its column (Guideline 16 R1,
-// as finish_pass).  The cells leave as whole residues (no limb split: these passes are never sharded) in the
-// wide part of the host mailbox, then the sequence word.
-constexpr int kGridChunk = 256;
+// Every WAVE works alone.  One wave iteration takes 32 consecutive folded entries of both tables:
+//  1. fold: lane = table x entry - all 64 lanes fold one entry, sum_c w[c] * in[2^kf i + c] (kf = 0..5 pending
+//     challenges, run-time; all loads of an entry in flight, one lazy sum, one reduction), and store it to the
+//     folded table and to its place in the wave's extension arrays
+//  2. extend: ext[table][group][cell], cell = sum_j d_j 3^(KS-1-j), d_j in {0,1,inf} the evaluation point of the
+//     group's variable j (variable 0 = index bit 0, the round served first: the slowest axis, as in pass_kernel);
+//     the 32 entries are 2^(5-KS) groups of 2^KS.  Level j fills the cells with d_j = inf from d_j = 1 minus
+//     d_j = 0: 2 * groups * 3^j * 2^(KS-1-j) subtractions, at most three per lane, whose LDS addresses are the same
+//     in every iteration and are decoded once; levels are separated by wave-level LDS ordering only (the arrays
+//     are private to the wave: no barrier)
+//  3. multiply: the (group, cell) pairs - at most 243 - by lane p, p + 64, p + 128, p + 192 into four lazy
+//     accumulators per lane that live across the wave's iterations
+// ~120 VGPRs and 4 KiB of LDS per wave: four waves per SIMD cover each other's latencies.  KS is a template
+// parameter (constant strides), kf a run-time switch.  End: accumulators -> residues, waves and groups added through
+// LDS, thread c < 3^KS holds cell c of the block.
+//  * wgrid_pass_kernel (unsharded passes): rows of 256 words per block, two ticket levels (groups of 32 blocks,
+//    then the groups; Guideline 16 R1 as in finish_pass), each one round of up to 32 loads per thread; the block
+//    that finishes last resets the counters and publishes the cells as whole residues (no limb split) in the
+//    wide part of the host mailbox, then the sequence word.
+//  * grid_pass3_kernel (KS = 3; sharded tail passes, and unsharded ones when the five-round planner is off):
+//    the 27 cells leave through finish_pass like those of pass_kernel.
+constexpr int kGridChunk = 256;          // words per row of partials (>= 243 cells)
 constexpr int kGridMaxVars = 5;
 constexpr int kGridMaxCells = 243;
-constexpr int kMailboxWide = 64;        // first word of the wide area (kGridMaxCells words)
+constexpr int kMailboxWide = 64;         // first word of the wide area (kGridMaxCells words)
 constexpr int kMailboxWords = kMailboxWide + 256;
+constexpr int kWgEntries = 32;           // folded entries per table and wave iteration
+constexpr int kWgGroupBlocks = 32;       // blocks per first-level ticket
 struct GridW {
   u64 w[1 << kGridMaxVars];   // w[c] = eq((r_0 .. r_{kf-1}), c); w[0] = 1 for kf = 0
 };
-struct GridOut {
-  u64* partials;        // [blocks][kGridChunk]
-  unsigned* ticket;
-  unsigned ticket_base;
+struct WgOut {
+  u64* partials;     // [blocks][kGridChunk]
+  u64* group_rows;   // [groups of 32 blocks][kGridChunk]
+  unsigned* tickets; // [0]: groups done; [1 + g]: blocks of group g done; all zero between launches
   u64* mailbox;
   u64 seq;
 };
-__device__ __forceinline__ int grid_pow3(int k) {
-  return k == 0 ? 1 : k == 1 ? 3 : k == 2 ? 9 : k == 3 ? 27 : k == 4 ? 81 : 243;
+// LDS hand-off between the lanes of ONE wave: a wave's LDS operations execute in order, so all that is needed is
+// that the earlier ones have been issued and returned and that the compiler keeps the order.  (wave_lds_fence()
+// is a workgroup-scope fence: it would also wait for the wave's global stores - here the folded entries on
+// their way out, which nobody in this kernel waits for.)
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
 }
-// folded entry i of both tables: sum_c w[c] * in[2^KF i + c], stored to the folded tables
+// folded entry i of one table: sum_c w[c] * in[2^KF i + c], stored to the folded table
 template <class F, int KF>
-__device__ __forceinline__ void grid_fold(const F& f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
-                                          u64* __restrict__ B2, const GridW& gw, size_t i, u64& va, u64& vb) {
+__device__ __forceinline__ u64 grid_fold1(const F& f, const u64* __restrict__ T, u64* __restrict__ T2, const GridW& gw, size_t i) {
   constexpr int FAN = 1 << KF, NPIECE = FAN / 2;
-  const ull2* __restrict__ pa = reinterpret_cast<const ull2*>(A + i * FAN);
-  const ull2* __restrict__ pb = reinterpret_cast<const ull2*>(B + i * FAN);
-  ull2 xa[NPIECE], xb[NPIECE];
+  const ull2* __restrict__ pt = reinterpret_cast<const ull2*>(T + i * FAN);
+  ull2 x[NPIECE];
+#pragma unroll
+  for (int m = 0; m < NPIECE; ++m) x[m] = pt[m];
+  typename F::Acc3 s;
+  f.acc3_zero(s);
 #pragma unroll
   for (int m = 0; m < NPIECE; ++m) {
-    xa[m] = pa[m];
-    xb[m] = pb[m];
+    f.acc3_mac(s, x[m].x, gw.w[2 * m]);
+    f.acc3_mac(s, x[m].y, gw.w[2 * m + 1]);
   }
-  typename F::Acc3 sa, sb;
-  f.acc3_zero(sa);
-  f.acc3_zero(sb);
-#pragma unroll
-  for (int m = 0; m < NPIECE; ++m) {
-    f.acc3_mac(sa, xa[m].x, gw.w[2 * m]); f.acc3_mac(sa, xa[m].y, gw.w[2 * m + 1]);
-    f.acc3_mac(sb, xb[m].x, gw.w[2 * m]); f.acc3_mac(sb, xb[m].y, gw.w[2 * m + 1]);
-  }
-  va = f.acc3_get(sa);
-  vb = f.acc3_get(sb);
-  A2[i] = va;
-  B2[i] = vb;
+  const u64 v = f.acc3_get(s);
+  T2[i] = v;
+  return v;
 }
-// the block's sums: thread c < 3^ks returns cell c
-template <class F>
-__device__ __forceinline__ u64 grid_pass_body(const F& f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
-                                              u64* __restrict__ B2, const GridW& gw, int kf, int ks, size_t n_out) {
-  constexpr int kMaxExt = (kGridChunk >> kGridMaxVars) * kGridMaxCells;   // 8 groups x 243 cells: the largest of the five
-  __shared__ u64 ea[kMaxExt], eb[kMaxExt];
-  __shared__ u64 red[kBlock];
-  __shared__ int cell_of[1 << kGridMaxVars], suffix_of[1 << kGridMaxVars];
-  const int tid = threadIdx.x;
-  const int cells = grid_pow3(ks), G = 1 << ks, groups = kGridChunk >> ks;
-  if (tid < (1 << kGridMaxVars)) {
+// the block's sums: thread c < 3^KS returns cell c
+template <class F, int KS>
+__device__ __forceinline__ u64 wgrid_body(const F& f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
+                                          u64* __restrict__ B2, const GridW& gw, int kf, size_t n_out) {
+  constexpr int kWaves = kBlock / kWave;
+  constexpr int kPow3[6] = {1, 3, 9, 27, 81, 243};
+  constexpr int cells = kPow3[KS], G = 1 << KS, gpi = kWgEntries >> KS, pairs = gpi * cells;
+  __shared__ u64 ext[kWaves][2][kGridChunk];   // wave-private: [table][group][cell]
+  __shared__ u64 red[kWaves][kGridChunk];
+  __shared__ int cell_of[kWgEntries], suffix_of[kWgEntries];
+  typedef __attribute__((address_space(3))) u64 lds_u64;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  if (tid < kWgEntries) {
     // cell of a group's entry e (its bits are the points of the group's variables, variable 0 = bit 0) and the
-    // cell offset of a suffix s whose bit m is the point of variable ks-1-m
+    // cell offset of a suffix s whose bit m is the point of variable KS-1-m
     int c = 0, u = 0, p3 = 1;
-    for (int m = 0; m < ks; ++m) {
-      c += ((tid >> (ks - 1 - m)) & 1) * p3;
+    for (int m = 0; m < KS; ++m) {
+      c += ((tid >> (KS - 1 - m)) & 1) * p3;
       u += ((tid >> m) & 1) * p3;
       p3 *= 3;
     }
     cell_of[tid] = c;
     suffix_of[tid] = u;
   }
-  // products: thread = (cell, split); S splits share the groups of a chunk
-  const int S = min(groups, kBlock / cells);
-  const bool multiplies = tid < cells * S;
-  const int my_cell = tid % cells, my_split = tid / cells;
-  typename F::Acc acc;
-  f.acc_zero(acc);
   __syncthreads();
+  u64* const ef = &ext[wave][0][0];   // [table][256], flat
+  // fold role of the lane: table and entry of the iteration; its place in the extension array
+  const int tbl = lane >> 5, ent = lane & (kWgEntries - 1);
+  const int slot = tbl * kGridChunk + (ent >> KS) * cells + cell_of[ent & (G - 1)];
+  const u64* __restrict__ src = tbl ? B : A;
+  u64* __restrict__ dst = tbl ? B2 : A2;
+  // step[j][q] = bit 31 | LDS byte address of the d_j = 0 cell of the lane's q-th subtraction of level j, or 0
+  unsigned step[KS][3];
+#pragma unroll
+  for (int j = 0; j < KS; ++j) {
+    const int low = KS - 1 - j, pj = kPow3[j], stride = kPow3[low], items = (gpi * pj) << low;   // per table
+    const unsigned inv = (1u << 20) / (unsigned)pj + 1u;   // t / pj for t < 4096, pj in {1,3,9,27,81}: exact
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int idx = lane + kWave * q;
+      unsigned d = 0;
+      if (idx < 2 * items) {
+        const int tb = idx >= items ? 1 : 0, id = idx - tb * items;
+        const int sfx = id & ((1 << low) - 1), t = id >> low;
+        const int g = (int)(((unsigned)t * inv) >> 20), p = t - g * pj;
+        d = 0x80000000u | (unsigned)(size_t)(lds_u64*)(ef + tb * kGridChunk + g * cells + p * 3 * stride + suffix_of[sfx]);
+      }
+      step[j][q] = d;
+    }
+  }
+  typename F::Acc acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) f.acc_zero(acc[k]);
 
-  const size_t n_chunks = (n_out + kGridChunk - 1) / kGridChunk;
-  for (size_t chunk = blockIdx.x; chunk < n_chunks; chunk += gridDim.x) {
-    // 1. fold
-    const size_t i = chunk * kGridChunk + tid;
-    u64 va = 0, vb = 0;
+  const size_t n_iter = (n_out + kWgEntries - 1) / kWgEntries;
+  for (size_t it = (size_t)blockIdx.x * kWaves + wave; it < n_iter; it += (size_t)gridDim.x * kWaves) {
+    const size_t i = it * kWgEntries + ent;
+    u64 v = 0;   // entries past the end of a short table are zeros: they add nothing to any cell
     if (i < n_out) {
       switch (kf) {   // compile-time fan-in: all loads of an entry are in flight together
-        case 0: va = A[i]; vb = B[i]; break;
-        case 1: grid_fold<F, 1>(f, A, B, A2, B2, gw, i, va, vb); break;
-        case 2: grid_fold<F, 2>(f, A, B, A2, B2, gw, i, va, vb); break;
-        case 3: grid_fold<F, 3>(f, A, B, A2, B2, gw, i, va, vb); break;
-        case 4: grid_fold<F, 4>(f, A, B, A2, B2, gw, i, va, vb); break;
-        default: grid_fold<F, 5>(f, A, B, A2, B2, gw, i, va, vb); break;
+        case 0: v = src[i]; break;
+        case 1: v = grid_fold1<F, 1>(f, src, dst, gw, i); break;
+        case 2: v = grid_fold1<F, 2>(f, src, dst, gw, i); break;
+        case 3: v = grid_fold1<F, 3>(f, src, dst, gw, i); break;
+        case 4: v = grid_fold1<F, 4>(f, src, dst, gw, i); break;
+        default: v = grid_fold1<F, 5>(f, src, dst, gw, i); break;
       }
     }
-    {
-      const int slot = (tid >> ks) * cells + cell_of[tid & (G - 1)];
-      ea[slot] = va;
-      eb[slot] = vb;
-    }
-    __syncthreads();
-    // 2. extend, one variable per level
-    for (int j = 0; j < ks; ++j) {
-      const int low = ks - 1 - j, pj = grid_pow3(j), stride = grid_pow3(low), items = (groups * pj) << low;
-      const unsigned inv = (1u << 20) / (unsigned)pj + 1u;   // t / pj for t < 4096, pj in {1,3,9,27,81}: exact
-      for (int idx = tid; idx < items; idx += kBlock) {
-        const int sfx = idx & ((1 << low) - 1), t = idx >> low;
-        const int g = (int)(((unsigned)t * inv) >> 20), p = t - g * pj;
-        const int base = g * cells + p * 3 * stride + suffix_of[sfx];
-        ea[base + 2 * stride] = f.sub(ea[base + stride], ea[base]);
-        eb[base + 2 * stride] = f.sub(eb[base + stride], eb[base]);
+    ef[slot] = v;
+    wave_lds_sync();
+#pragma unroll
+    for (int j = 0; j < KS; ++j) {
+      const int st = kPow3[KS - 1 - j];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        if (2 * ((gpi * kPow3[j]) << (KS - 1 - j)) > kWave * q) {   // does any lane have a q-th step at this level?
+          const unsigned d = step[j][q];
+          if (d != 0) {
+            lds_u64* const x = (lds_u64*)(size_t)(d & 0x7FFFFFFFu);
+            x[2 * st] = f.sub(x[st], x[0]);
+          }
+        }
       }
-      __syncthreads();
+      wave_lds_sync();
     }
-    // 3. multiply
-    if (multiplies) {
-      for (int g = my_split; g < groups; g += S) f.acc_mac(acc, ea[g * cells + my_cell], eb[g * cells + my_cell]);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = lane + kWave * k;
+      if (p < pairs) f.acc_mac(acc[k], ef[p], ef[kGridChunk + p]);
     }
-    __syncthreads();
+    wave_lds_sync();    // the next iteration overwrites the arrays
   }
 
-  red[tid] = multiplies ? f.acc_get(acc) : 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = lane + kWave * k;
+    red[wave][p] = (p < pairs) ? f.acc_get(acc[k]) : 0;
+  }
   __syncthreads();
   u64 total = 0;
   if (tid < cells) {
-    for (int sp = 0; sp < S; ++sp) total = f.add(total, red[sp * cells + tid]);
+    for (int w = 0; w < kWaves; ++w)
+      for (int g = 0; g < gpi; ++g) total = f.add(total, red[w][g * cells + tid]);
   }
   return total;
 }
 
-template <class F>
+template <class F, int KS>
 __global__ void __launch_bounds__(kBlock)
-grid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
-                 GridW gw, int kf, int ks, size_t n_out, GridOut out) {
+wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
+                  GridW gw, int kf, size_t n_out, WgOut out) {
+  constexpr int kPow3[6] = {1, 3, 9, 27, 81, 243};
+  constexpr int cells = kPow3[KS];
   __shared__ int lds_flag;
-  const int tid = threadIdx.x, cells = grid_pow3(ks);
-  u64 total = grid_pass_body<F>(f, A, B, A2, B2, gw, kf, ks, n_out);
+  const int tid = threadIdx.x;
+  u64 total = wgrid_body<F, KS>(f, A, B, A2, B2, gw, kf, n_out);
   if (gridDim.x > 1) {
+    // level 1: the blocks of a group of 32
+    const int n_blocks = gridDim.x, group = blockIdx.x / kWgGroupBlocks, n_groups = (n_blocks + kWgGroupBlocks - 1) / kWgGroupBlocks;
+    const int group_size = min(kWgGroupBlocks, n_blocks - group * kWgGroupBlocks);
     if (tid < cells)
       __hip_atomic_store(out.partials + (size_t)blockIdx.x * kGridChunk + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains its write-through stores
     __syncthreads();
     if (tid == 0) {
-      const unsigned t = __hip_atomic_fetch_add(out.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = (t - out.ticket_base == gridDim.x - 1) ? 1 : 0;
+      const unsigned t = __hip_atomic_fetch_add(out.tickets + 1 + group, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == (unsigned)group_size - 1) ? 1 : 0;
       if (last) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -865,48 +903,59 @@ grid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64*
     }
     __syncthreads();
     if (!lds_flag) return;
-    // column sums of the [block][256] partials: thread = (cell, slice), every load of a thread in flight at once
-    // (a round of dependent loads costs ~0.6 us from L2: eight rounds of eight were most of this hand-off)
-    __shared__ u64 colsum[kBlock];
-    const int n_blocks = gridDim.x, slices = max(1, kBlock / cells);
-    const int cell = tid % cells, slice = tid / cells;
-    u64 part = 0;
-    if (slice < slices) {
-      constexpr int U = 32;
-      for (int b0 = slice; b0 < n_blocks; b0 += slices * U) {
-        u64 x[U];
+    total = 0;
+    if (tid < cells) {   // every load of the column in flight at once: a round of dependent loads costs ~0.6 us from L2
+      u64 x[kWgGroupBlocks];
 #pragma unroll
-        for (int q = 0; q < U; ++q) {
-          const int b = b0 + q * slices;
-          x[q] = (b < n_blocks)
-                     ? __hip_atomic_load(out.partials + (size_t)b * kGridChunk + cell, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                     : 0;
+      for (int q = 0; q < kWgGroupBlocks; ++q)
+        x[q] = (q < group_size) ? __hip_atomic_load(out.partials + (size_t)(group * kWgGroupBlocks + q) * kGridChunk + tid, __ATOMIC_RELAXED,
+                                                    __HIP_MEMORY_SCOPE_AGENT)
+                                : 0;
+#pragma unroll
+      for (int q = 0; q < kWgGroupBlocks; ++q) total = f.add(total, x[q]);
+    }
+    if (n_groups > 1) {
+      // level 2: the groups
+      __syncthreads();   // lds_flag is reused
+      if (tid < cells)
+        __hip_atomic_store(out.group_rows + (size_t)group * kGridChunk + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const unsigned t = __hip_atomic_fetch_add(out.tickets, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = (t == (unsigned)n_groups - 1) ? 1 : 0;
+        if (last) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
+        lds_flag = last;
+      }
+      __syncthreads();
+      if (!lds_flag) return;
+      total = 0;
+      if (tid < cells) {
+        u64 x[kWgGroupBlocks];
 #pragma unroll
-        for (int q = 0; q < U; ++q) part = f.add(part, x[q]);
+        for (int q = 0; q < kWgGroupBlocks; ++q)
+          x[q] = (q < n_groups) ? __hip_atomic_load(out.group_rows + (size_t)q * kGridChunk + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+#pragma unroll
+        for (int q = 0; q < kWgGroupBlocks; ++q) total = f.add(total, x[q]);
       }
     }
-    colsum[tid] = part;
-    __syncthreads();
-    total = 0;
-    if (tid < cells) {
-      for (int sl = 0; sl < slices; ++sl) total = f.add(total, colsum[sl * cells + tid]);
-    }
+    // everything of this launch has been counted: leave the counters at zero for the next one
+    if (tid <= n_groups) __hip_atomic_store(out.tickets + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   if (tid < cells) __hip_atomic_store(out.mailbox + kMailboxWide + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
   if (tid == 0) __hip_atomic_store(out.mailbox + kMailboxSeq, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// The same body for the three-round passes on tables too large for one row of partials per block (folded tables
-// of 2^15 .. 2^20 entries, any number of blocks) and for sharded passes: the 27 cells leave through finish_pass
-// (split limbs, ticket over sum-major rows, in-kernel exchange) like those of pass_kernel.
 template <class F>
 __global__ void __launch_bounds__(kBlock)
 grid_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
                   GridW gw, int kf, size_t n_out, PassOut out) {
   __shared__ int lds_flag;
-  const u64 mine = grid_pass_body<F>(f, A, B, A2, B2, gw, kf, 3, n_out);
+  const u64 mine = wgrid_body<F, 3>(f, A, B, A2, B2, gw, kf, n_out);
   finish_pass<F, 27>(f, out, mine, &lds_flag);
 }
 

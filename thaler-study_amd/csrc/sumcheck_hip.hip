@@ -80,7 +80,7 @@ bool load_rccl(std::string* why) {
 }
 
 enum class Transport { kNone, kRccl, kHost, kPeer };
-constexpr int kGridMaxBlocks = 64;   // blocks of a grid_pass_kernel launch at most (rows of its partials)
+constexpr int kWgMaxBlocks = 1024;   // blocks of a wgrid_pass_kernel launch at most: 32 groups of 32
 
 }  // namespace
 
@@ -105,15 +105,18 @@ struct sc_ctx {
   // two everywhere
   int tail_pass_vars = 3;
   int tail_pass_log = 19;  // largest input (log2 entries per table) that takes the three-round tail pass
-  // the passes on the smallest tables (kernels.hpp, grid_pass_kernel): up to five rounds each
+  // the passes on the smaller tables (kernels.hpp, wgrid_pass_kernel): up to five rounds each
   int grid_pass = 1;
-  int grid_log = 14;        // largest FOLDED table (log2 entries) they take: <= kGridMaxBlocks chunks of 256
+  int grid_log = 20;        // largest FOLDED table (log2 entries) they take (measured: 21 costs n = 28 10 us, 19 costs n = 25 18 us)
   int grid_max_vars = 5;    // most rounds one of them serves (1..5)
-  int grid_vars4_log = 14;  // largest folded table that gets four rounds ...
-  int grid_vars5_log = 11;  // ... and five
-  int mid_pass = 1;         // three-round tail passes above that size by the same body (grid_pass3_kernel) instead of small_pass3_kernel
-  int grid_blocks = 64;     // most blocks of such a launch (each takes chunks of 256 folded entries)
-  u64* d_gpartials = nullptr;   // [kGridMaxBlocks][kGridChunk]
+  int grid_vars4_log = 26;  // largest folded table that gets four rounds ...
+  int grid_vars5_log = 26;  // ... and five (no limit below grid_log by default: the kernel's cost hardly grows with the rounds)
+  int mid_pass = 1;         // three-round tail passes outside that planner (sharded ones) by grid_pass3_kernel instead of small_pass3_kernel
+  int wgrid_blocks = 0;     // resident grid of wgrid_pass_kernel (0 = not asked yet)
+  int grid_blocks = 0;      // cap on the blocks of such a launch (0 = as many as are resident; tests use it to reach both ticket levels)
+  u64* d_wg_partials = nullptr;   // [kWgMaxBlocks][kGridChunk]
+  u64* d_wg_groups = nullptr;     // [kWgMaxBlocks / 32][kGridChunk]
+  unsigned* d_wg_tickets = nullptr;
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
                       // cheaper than the ~25 us of collective latency of each further sharded pass
   // grid cap of the streaming kernels: three 256-thread blocks per CU (set in sc_ctx_create).
@@ -610,29 +613,48 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
 
 int wait_mailbox(sc_ctx* ctx, u64 seq);
 
-// One pass of the tail by grid_pass_kernel: folds kf <= 5 pending challenges of tables of 2^log_in entries and
-// leaves the 3^ks cells of the next ks <= 5 rounds as whole residues in the wide mailbox (unsharded only).
+// One pass by wgrid_pass_kernel: folds kf <= 5 pending challenges of tables of 2^log_in entries and leaves the 3^ks
+// cells of the next ks <= 5 rounds as whole residues in the wide mailbox (unsharded only).  Its counters rest at zero.
 int launch_grid_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, const u64* r, int log_in) {
   if (kf < 0 || kf > sc::kGridMaxVars || ks < 1 || ks > sc::kGridMaxVars || log_in < kf + ks)
     return fail(ctx, SC_ERR_ARG, "launch_grid_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
   if (!ctx->use_mailbox) return fail(ctx, SC_ERR_STATE, "launch_grid_pass needs the host mailbox");
   const sc::GridW gw = make_grid_weights(ctx, r, kf);
   const size_t n_out = (size_t)1 << (log_in - kf);
-  const size_t n_chunks = (n_out + sc::kGridChunk - 1) / sc::kGridChunk;
-  const int grid = (int)std::min<size_t>(n_chunks, (size_t)std::min(ctx->grid_blocks, kGridMaxBlocks));
-  sc::GridOut out;
-  out.partials = ctx->d_gpartials;
-  out.ticket = ctx->d_ticket;
-  out.ticket_base = ctx->ticket_base;
-  out.mailbox = ctx->d_mailbox;
-  out.seq = ctx->mailbox_seq + 1;
+  if (ctx->wgrid_blocks == 0) {
+    int per_cu = 0;
+    const void* fn = ctx->gold ? reinterpret_cast<const void*>(&sc::wgrid_pass_kernel<sc::GoldilocksMont, 5>)
+                               : reinterpret_cast<const void*>(&sc::wgrid_pass_kernel<sc::MontGeneric, 5>);
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, sc::kBlock, 0) != hipSuccess || per_cu < 1) {
+      (void)hipGetLastError();
+      per_cu = 2;
+    }
+    ctx->wgrid_blocks = std::min(per_cu * ctx->num_cus, kWgMaxBlocks);
+  }
+  constexpr size_t kWaves = sc::kBlock / sc::kWave;
+  const size_t n_iter = (n_out + sc::kWgEntries - 1) / sc::kWgEntries;   // one per wave
+  const size_t cap = ctx->grid_blocks > 0 ? (size_t)std::min(ctx->grid_blocks, ctx->wgrid_blocks) : (size_t)ctx->wgrid_blocks;
+  const int grid = (int)std::max<size_t>(1, std::min<size_t>((n_iter + kWaves - 1) / kWaves, cap));
+  sc::WgOut wo;
+  wo.partials = ctx->d_wg_partials;
+  wo.group_rows = ctx->d_wg_groups;
+  wo.tickets = ctx->d_wg_tickets;
+  wo.mailbox = ctx->d_mailbox;
+  wo.seq = ctx->mailbox_seq + 1;
   SC_TRY(timer_begin(ctx, SC_KIND_GRID_PASS, kf, ks, log_in, (u64)16 << log_in, kf > 0 ? (u64)16 << (log_in - kf) : 0));
-  SC_DISPATCH_FIELD(ctx, F, f,
-                    hipLaunchKernelGGL((sc::grid_pass_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, A, B, A2, B2, gw,
-                                       kf, ks, n_out, out));
+#define SC_WG(KS) hipLaunchKernelGGL((sc::wgrid_pass_kernel<F, KS>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, A, B, A2, B2, gw, kf, n_out, wo)
+  SC_DISPATCH_FIELD(ctx, F, f, {
+    switch (ks) {
+      case 1: SC_WG(1); break;
+      case 2: SC_WG(2); break;
+      case 3: SC_WG(3); break;
+      case 4: SC_WG(4); break;
+      default: SC_WG(5); break;
+    }
+  });
+#undef SC_WG
   SC_HIP(ctx, hipGetLastError());
   ctx->mailbox_seq += 1;
-  if (grid > 1) ctx->ticket_base += (unsigned)grid;
   SC_TRY(timer_end(ctx));
   return SC_OK;
 }
@@ -1165,7 +1187,10 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
   SC_CREATE_HIP(hipMemset(ctx->d_ticket, 0, 64));
   SC_CREATE_HIP(hipHostMalloc(&ctx->h_mailbox, sc::kMailboxWords * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->h_mailbox, 0, sc::kMailboxWords * sizeof(u64));
-  SC_CREATE_HIP(hipMalloc(&ctx->d_gpartials, (size_t)kGridMaxBlocks * sc::kGridChunk * sizeof(u64)));
+  SC_CREATE_HIP(hipMalloc(&ctx->d_wg_partials, (size_t)kWgMaxBlocks * sc::kGridChunk * sizeof(u64)));
+  SC_CREATE_HIP(hipMalloc(&ctx->d_wg_groups, (size_t)(kWgMaxBlocks / sc::kWgGroupBlocks) * sc::kGridChunk * sizeof(u64)));
+  SC_CREATE_HIP(hipMalloc(&ctx->d_wg_tickets, 64 * sizeof(unsigned)));
+  SC_CREATE_HIP(hipMemset(ctx->d_wg_tickets, 0, 64 * sizeof(unsigned)));
   SC_CREATE_HIP(hipHostGetDevicePointer((void**)&ctx->d_mailbox, ctx->h_mailbox, 0));
   SC_CREATE_HIP(hipHostMalloc(&ctx->h_cmd, 64 * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
   memset(ctx->h_cmd, 0, 64 * sizeof(u64));
@@ -1194,7 +1219,9 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
   for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
   for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
   if (ctx->d_partials) (void)hipFree(ctx->d_partials);
-  if (ctx->d_gpartials) (void)hipFree(ctx->d_gpartials);
+  if (ctx->d_wg_partials) (void)hipFree(ctx->d_wg_partials);
+  if (ctx->d_wg_groups) (void)hipFree(ctx->d_wg_groups);
+  if (ctx->d_wg_tickets) (void)hipFree(ctx->d_wg_tickets);
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
   if (ctx->h_sums) (void)hipHostFree(ctx->h_sums);
   if (ctx->h_mailbox) (void)hipHostFree(ctx->h_mailbox);
@@ -1231,22 +1258,22 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "grid_pass") {
     ctx->grid_pass = value ? 1 : 0;
   } else if (k == "grid_log") {
-    if (value < 0 || value > 14) return fail(ctx, SC_ERR_ARG, "grid_log out of range (0..14)");
+    if (value < 0 || value > 26) return fail(ctx, SC_ERR_ARG, "grid_log out of range (0..26)");
     ctx->grid_log = (int)value;
   } else if (k == "grid_max_vars") {
     if (value < 1 || value > sc::kGridMaxVars) return fail(ctx, SC_ERR_ARG, "grid_max_vars must be 1..5");
     ctx->grid_max_vars = (int)value;
   } else if (k == "grid_vars4_log") {
-    if (value < 0 || value > 14) return fail(ctx, SC_ERR_ARG, "grid_vars4_log out of range (0..14)");
+    if (value < 0 || value > 26) return fail(ctx, SC_ERR_ARG, "grid_vars4_log out of range (0..26)");
     ctx->grid_vars4_log = (int)value;
   } else if (k == "grid_vars5_log") {
-    if (value < 0 || value > 14) return fail(ctx, SC_ERR_ARG, "grid_vars5_log out of range (0..14)");
+    if (value < 0 || value > 26) return fail(ctx, SC_ERR_ARG, "grid_vars5_log out of range (0..26)");
     ctx->grid_vars5_log = (int)value;
   } else if (k == "mid_pass") {
     ctx->mid_pass = value ? 1 : 0;
     memset(ctx->resident_blocks, 0, sizeof(ctx->resident_blocks));   // the cached grids of the tail passes belong to the other kernel
   } else if (k == "grid_blocks") {
-    if (value < 1 || value > kGridMaxBlocks) return fail(ctx, SC_ERR_ARG, "grid_blocks must be 1..%d", kGridMaxBlocks);
+    if (value < 0 || value > kWgMaxBlocks) return fail(ctx, SC_ERR_ARG, "grid_blocks must be 0..%d", kWgMaxBlocks);
     ctx->grid_blocks = (int)value;
   } else if (k == "tail_log") {
     if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "tail_log out of range");
@@ -1297,8 +1324,8 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   else if (k == "grid_max_vars") *value = ctx->grid_max_vars;
   else if (k == "grid_vars4_log") *value = ctx->grid_vars4_log;
   else if (k == "grid_vars5_log") *value = ctx->grid_vars5_log;
-  else if (k == "grid_blocks") *value = ctx->grid_blocks;
   else if (k == "mid_pass") *value = ctx->mid_pass;
+  else if (k == "grid_blocks") *value = ctx->grid_blocks;
   else if (k == "tail_log") *value = ctx->tail_log;
   else if (k == "max_blocks") *value = ctx->max_blocks;
   else if (k == "time_kernels") *value = ctx->time_kernels;

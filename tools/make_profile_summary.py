@@ -41,7 +41,7 @@ with open(os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, workload)), "w") as f
         w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 
 # ---- per-launch trace: the hot-path kernels in dispatch order
-HOT = ("pass_kernel<", "small_pass3_kernel<", "grid_pass_kernel<", "grid_pass3_kernel<", "resident_kernel<", "evaluate_kernel<",
+HOT = ("pass_kernel<", "small_pass3_kernel<", "wgrid_pass_kernel<", "grid_pass3_kernel<", "resident_kernel<", "evaluate_kernel<",
        "fold_kernel<", "fix_low_kernel<", "fold_be_kernel<", "coldot_kernel<")
 
 
@@ -56,7 +56,7 @@ def describe(name):
         return "tail_pass", int(m.group(1)), 3
     if "grid_pass3_kernel<" in name:
         return "tail_pass", -1, 3        # kf is a run-time argument: taken from bench.py's schedule
-    if "grid_pass_kernel<" in name:
+    if "wgrid_pass_kernel<" in name:
         return "grid_pass", -1, -1       # kf, ks from bench.py's schedule
     m = re.search(r"pass_kernel<sc::\w+, (\d), (\d)(?:, \d)?>", name)
     if m:
@@ -71,7 +71,7 @@ def describe(name):
 
 
 if workload == "prover":   # a proof is passes only (the evaluate launches behind it are bench.py's parity gate)
-    HOT = ("pass_kernel<", "small_pass3_kernel<", "grid_pass_kernel<", "grid_pass3_kernel<", "resident_kernel<")
+    HOT = ("pass_kernel<", "small_pass3_kernel<", "wgrid_pass_kernel<", "grid_pass3_kernel<", "resident_kernel<")
 trace = [r for r in csv.DictReader(open(one(d_stats, "*_kernel_trace.csv"))) if is_hot(r["Kernel_Name"])]
 
 
@@ -113,7 +113,7 @@ def bench_name(kind, kf, ks, log_in):
     if kind == "tail_pass":
         return "sc::grid_pass3_kernel<GoldilocksMont> (kf=%d, ks=3; small_pass3_kernel with mid_pass=0) on 2^%d-entry tables" % (kf, log_in)
     if kind == "grid_pass":
-        return "sc::grid_pass_kernel<GoldilocksMont> (kf=%d, ks=%d) on 2^%d-entry tables" % (kf, ks, log_in)
+        return "sc::wgrid_pass_kernel<GoldilocksMont,ks> (kf=%d, ks=%d) on 2^%d-entry tables" % (kf, ks, log_in)
     if kind == "evaluate":
         return "sc::evaluate_kernel<GoldilocksMont> on a 2^%d-entry table" % log_in
     if kind == "fold":
