@@ -89,7 +89,9 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      folded size that gets five / four rounds (default: no bound below grid_log); "grid_blocks"
  *                      caps the launch (0 = what is resident).  1 (default) | 0.  Not used with "vars_per_pass" 1,
  *                      "tail_pass_vars" 2, an explicit "first_pass_vars" for the first pass, or "resident" - those
- *                      name their own schedules.  "mid_pass" (1): the three-round tail passes outside this planner
+ *                      name their own schedules.  "grid_sharded" (1): on the peer transport the shards of a sharded
+ *                      prover go on with these passes too (cells exchanged inside the kernel) until they are down to their
+ *                      pending challenges, and are gathered only then.  "mid_pass" (1): the three-round tail passes outside this planner
  *                      (sharded ones) run grid_pass3_kernel instead of small_pass3_kernel.
  *   "tail_log"         shard log-size at which a sharded prover gathers (default 16)
  *   "max_blocks"       grid cap of the streaming kernels (default 3 per CU = 768); a pass never

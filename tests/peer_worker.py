@@ -29,17 +29,27 @@ def main():
         ctx.set_option("peer_spin_ms", 60000)   # a failure detector: generous (a cold box stalls ranks for many seconds)
         D.attach_peer(ctx, rank, world)
         assert ctx.rank_world() == (rank, world)
-        for n, tail_log in [(1, 0), (2, 0), (5, 0), (12, 0), (12, 5), (16, 12), (20, 16), (22, 16)]:
+        # grid_sharded 1: the shards go on with five-round passes (cells exchanged inside the kernel) down to one entry;
+        # 0: two-round passes with the exchange, gather at tail_log, unsharded tail
+        for n, tail_log, gs in [(1, 0, 1), (2, 0, 1), (5, 0, 1), (12, 0, 1), (12, 5, 0), (12, 0, 0), (16, 12, 1), (16, 12, 0), (20, 16, 1),
+                                (20, 16, 0), (22, 16, 1)]:
             if n < world.bit_length() - 1:
                 continue            # fewer entries than ranks
             ctx.set_option("tail_log", tail_log)
+            ctx.set_option("grid_sharded", gs)
             start, length = D.shard_range(n, rank, world)
             nl = length.bit_length() - 1
             a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, nl, start=start)
             b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, nl, start=start)
             g = pkg.matrix_multiplication.G(a, b)
             assert g.num_vars() == n
+            ctx.set_option("time_kernels", 1)
+            ctx.launch_log(reset=True)
             c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+            log = ctx.launch_log(reset=True)
+            ctx.set_option("time_kernels", 0)
+            if gs and nl >= 6:      # the shard's own variables are served five at a time, then one pass on the gathered table
+                assert [r["kind"] for r in log].count("grid_pass") >= 2 and log[-1]["log_in"] <= 5 + world.bit_length() - 1, log
             oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
             ref = o.prove(oa, ob, ch)
             assert ref["status"] == 0
@@ -58,6 +68,7 @@ def main():
         b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, nl, start=start)
         g = pkg.matrix_multiplication.G(a, b)
         ctx.set_option("tail_log", 0)
+        ctx.set_option("grid_sharded", 1)
         try:
             pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R + (7 if rank == 1 else 0))
             raise AssertionError("different challenges were accepted")

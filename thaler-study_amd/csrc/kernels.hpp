@@ -279,7 +279,8 @@ constexpr int kMailboxErr = 62;   // 0, or why the pass's cross-rank exchange fa
 // challenges the pass folds; ranks that were fed different challenges fail loudly instead of proving
 // different statements.
 constexpr int kMaxPeers = 8;
-constexpr int kInboxWords = 64;
+constexpr int kInboxWords = 64 + 512; // 64 for the passes with up to 27 cells (+ digest, gather flag), then the wide part
+constexpr int kInboxWide = 64;       // first granule of the wide part: 2 x 243 limbs of a five-round pass
 constexpr int kInboxDigest = 56;     // granule index of the challenge digest
 constexpr int kInboxGather = 57;     // granule index of the table-gather flag
 constexpr int kXchgTimeout = 1, kXchgDigest = 2;
@@ -728,7 +729,7 @@ constexpr int kGridChunk = 256;          // words per row of partials (>= 243 ce
 constexpr int kGridMaxVars = 5;
 constexpr int kGridMaxCells = 243;
 constexpr int kMailboxWide = 64;         // first word of the wide area (kGridMaxCells words)
-constexpr int kMailboxWords = kMailboxWide + 256;
+constexpr int kMailboxWords = kMailboxWide + 512;   // 243 residues, or 486 limb totals of a sharded pass
 constexpr int kWgEntries = 32;           // folded entries per table and wave iteration
 constexpr int kWgGroupBlocks = 32;       // blocks per first-level ticket
 struct GridW {
@@ -740,6 +741,7 @@ struct WgOut {
   unsigned* tickets; // [0]: groups done; [1 + g]: blocks of group g done; all zero between launches
   u64* mailbox;
   u64 seq;
+  PeerX px;          // world > 0: a sharded pass - the cells are exchanged with the peers before they are published
 };
 // LDS hand-off between the lanes of ONE wave: a wave's LDS operations execute in order, so all that is needed is
 // that the earlier ones have been issued and returned and that the compiler keeps the order.  (wave_lds_fence()
@@ -875,6 +877,69 @@ __device__ __forceinline__ u64 wgrid_body(const F& f, const u64* __restrict__ A,
   return total;
 }
 
+// The in-kernel exchange of finish_pass (PeerX) for up to 243 cells, by the whole last block: thread c owns cell c,
+// i.e. the granules kInboxWide + 2c (low limb) and + 2c + 1 (high limb) of every inbox.  Leaves the limb TOTALS in
+// the wide mailbox (the host recombines them mod p), the error word and then the sequence word.
+template <int CELLS>
+__device__ __forceinline__ void exchange_wide(const WgOut& o, u64 total) {
+  const PeerX& px = o.px;
+  const int tid = threadIdx.x;
+  const size_t par = (size_t)(px.tag & 1u) * kMaxPeers * kInboxWords;
+  int err = 0;
+  u64 lo = 0, hi = 0;
+  if (tid < CELLS) {
+    const size_t mine = par + (size_t)px.rank * kInboxWords + kInboxWide + 2 * (size_t)tid;
+    const u64 g0 = ((u64)px.tag << 32) | (total & 0xFFFFFFFFull), g1 = ((u64)px.tag << 32) | (total >> 32);
+    for (int q = 0; q < px.world; ++q) {
+      __hip_atomic_store(px.inbox[q] + mine, g0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(px.inbox[q] + mine + 1, g1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  if (tid == CELLS) {   // one more thread carries the digest of the challenges
+    const u64 g = ((u64)px.tag << 32) | (u64)px.digest;
+    for (int q = 0; q < px.world; ++q)
+      __hip_atomic_store(px.inbox[q] + par + (size_t)px.rank * kInboxWords + kInboxDigest, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (tid <= CELLS) {
+    const unsigned long long t0 = wall_clock64();
+    const u64* base = px.inbox[px.rank] + par + (tid < CELLS ? kInboxWide + 2 * (size_t)tid : (size_t)kInboxDigest);
+    const int n_gran = tid < CELLS ? 2 : 1;
+    for (int r = 0; r < px.world && !err; ++r) {
+      for (int k = 0; k < n_gran && !err; ++k) {
+        unsigned spins = 0;
+        while (true) {
+          const u64 g = __hip_atomic_load(base + (size_t)r * kInboxWords + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if ((unsigned)(g >> 32) == px.tag) {
+            if (tid == CELLS) err = ((unsigned)g != px.digest) ? kXchgDigest : 0;
+            else if (k == 0) lo += g & 0xFFFFFFFFull;
+            else hi += g & 0xFFFFFFFFull;
+            break;
+          }
+          if ((++spins & 31) == 0 && wall_clock64() - t0 > px.spin_ticks) {
+            err = kXchgTimeout | (r << 8);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+    }
+  }
+  if (tid < CELLS) {
+    __hip_atomic_store(o.mailbox + kMailboxWide + 2 * tid, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(o.mailbox + kMailboxWide + 2 * tid + 1, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // any thread's failure reaches the host before the sequence word does (a timeout outranks a digest mismatch)
+  __shared__ int worst;
+  if (tid == 0) worst = 0;
+  __syncthreads();
+  if (err) atomicMax(&worst, err);
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store(o.mailbox + kMailboxErr, (u64)worst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(o.mailbox + kMailboxSeq, o.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 template <class F, int KS>
 __global__ void __launch_bounds__(kBlock)
 wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
@@ -944,6 +1009,10 @@ wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
     }
     // everything of this launch has been counted: leave the counters at zero for the next one
     if (tid <= n_groups) __hip_atomic_store(out.tickets + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (out.px.world > 0) {
+    exchange_wide<cells>(out, total);
+    return;
   }
   if (tid < cells) __hip_atomic_store(out.mailbox + kMailboxWide + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();

@@ -111,6 +111,7 @@ struct sc_ctx {
   int grid_max_vars = 5;    // most rounds one of them serves (1..5)
   int grid_vars4_log = 26;  // largest folded table that gets four rounds ...
   int grid_vars5_log = 26;  // ... and five (no limit below grid_log by default: the kernel's cost hardly grows with the rounds)
+  int grid_sharded = 1;     // sharded passes too (peer transport: the cells are exchanged inside the kernel), down to one-entry shards
   int mid_pass = 1;         // three-round tail passes outside that planner (sharded ones) by grid_pass3_kernel instead of small_pass3_kernel
   int wgrid_blocks = 0;     // resident grid of wgrid_pass_kernel (0 = not asked yet)
   int grid_blocks = 0;      // cap on the blocks of such a launch (0 = as many as are resident; tests use it to reach both ticket levels)
@@ -564,8 +565,7 @@ unsigned challenge_digest(const u64* r, int kf, int ks, int log_in) {
 
 // Exchange fields of a sharded launch on the peer transport.  The tag advances with every such launch,
 // in the same order on every rank.
-void fill_peer(sc_ctx* ctx, sc::PassOut* out, unsigned digest) {
-  sc::PeerX& px = out->px;
+void fill_peer(sc_ctx* ctx, sc::PeerX& px, unsigned digest) {
   for (int q = 0; q < ctx->world; ++q) px.inbox[q] = ctx->peer_base[q];
   px.world = ctx->world;
   px.rank = ctx->rank;
@@ -597,7 +597,7 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   out.sums_dev = ctx->d_sums;
   out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
   out.seq = mailbox ? ctx->mailbox_seq + 1 : 0;
-  if (peer) fill_peer(ctx, &out, challenge_digest(r, kf, ks, log_in));
+  if (peer) fill_peer(ctx, out.px, challenge_digest(r, kf, ks, log_in));
   SC_TRY(timer_begin(ctx, (ks == 3 && kf > 0) ? SC_KIND_TAIL_PASS : SC_KIND_PASS, kf, ks, log_in, (u64)16 << log_in,
                      kf > 0 ? (u64)16 << (log_in - kf) : 0));
   SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, fw, n_units, grid, log_in, out));
@@ -615,7 +615,7 @@ int wait_mailbox(sc_ctx* ctx, u64 seq);
 
 // One pass by wgrid_pass_kernel: folds kf <= 5 pending challenges of tables of 2^log_in entries and leaves the 3^ks
 // cells of the next ks <= 5 rounds as whole residues in the wide mailbox (unsharded only).  Its counters rest at zero.
-int launch_grid_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, const u64* r, int log_in) {
+int launch_grid_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, const u64* r, int log_in, bool across_ranks) {
   if (kf < 0 || kf > sc::kGridMaxVars || ks < 1 || ks > sc::kGridMaxVars || log_in < kf + ks)
     return fail(ctx, SC_ERR_ARG, "launch_grid_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
   if (!ctx->use_mailbox) return fail(ctx, SC_ERR_STATE, "launch_grid_pass needs the host mailbox");
@@ -641,6 +641,10 @@ int launch_grid_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u6
   wo.tickets = ctx->d_wg_tickets;
   wo.mailbox = ctx->d_mailbox;
   wo.seq = ctx->mailbox_seq + 1;
+  if (across_ranks) {
+    if (ctx->transport != Transport::kPeer) return fail(ctx, SC_ERR_STATE, "a sharded five-round pass needs the peer transport");
+    fill_peer(ctx, wo.px, challenge_digest(r, kf, ks, log_in));
+  }
   SC_TRY(timer_begin(ctx, SC_KIND_GRID_PASS, kf, ks, log_in, (u64)16 << log_in, kf > 0 ? (u64)16 << (log_in - kf) : 0));
 #define SC_WG(KS) hipLaunchKernelGGL((sc::wgrid_pass_kernel<F, KS>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, A, B, A2, B2, gw, kf, n_out, wo)
   SC_DISPATCH_FIELD(ctx, F, f, {
@@ -658,12 +662,26 @@ int launch_grid_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u6
   SC_TRY(timer_end(ctx));
   return SC_OK;
 }
-// its cells: wait for the sequence word, copy the residues
-int collect_grid(sc_ctx* ctx, int ks, u64* out) {
+// its cells: wait for the sequence word; the residues, or (sharded) the limb totals of all ranks recombined mod p
+int collect_grid(sc_ctx* ctx, int ks, bool across_ranks, u64* out) {
   SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
   int cells = 1;
   for (int i = 0; i < ks; ++i) cells *= 3;
-  for (int c = 0; c < cells; ++c) out[c] = ctx->h_mailbox[sc::kMailboxWide + c];
+  if (!across_ranks) {
+    for (int c = 0; c < cells; ++c) out[c] = ctx->h_mailbox[sc::kMailboxWide + c];
+    return SC_OK;
+  }
+  const u64 err = __atomic_load_n(ctx->h_mailbox + sc::kMailboxErr, __ATOMIC_ACQUIRE);
+  if (err == (u64)sc::kXchgDigest)
+    return fail(ctx, SC_ERR_STATE, "the ranks of this sharded prover were given different challenges");
+  if (err != 0) {
+    poison(ctx);
+    return fail(ctx, SC_ERR_RCCL, "peer exchange: a rank's sums did not arrive within %d ms (rank %d waited for rank %d at tag %u)",
+                ctx->peer_spin_ms, ctx->rank, (int)((err >> 8) & 0xFF), ctx->xchg_tag);
+  }
+  HostField hf(ctx->fp);
+  for (int c = 0; c < cells; ++c)
+    out[c] = hf.recombine(ctx->h_mailbox[sc::kMailboxWide + 2 * c], ctx->h_mailbox[sc::kMailboxWide + 2 * c + 1]);
   return SC_OK;
 }
 
@@ -751,7 +769,7 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
     po.sums_dev = ctx->d_sums;
     po.mailbox = ctx->d_mailbox;
     po.seq = ctx->mailbox_seq + 1;
-    fill_peer(ctx, &po, 0x5c5c5c5cu + (unsigned)ns);
+    fill_peer(ctx, po.px, 0x5c5c5c5cu + (unsigned)ns);
     const u64* limbs = ctx->d_sums;
     switch (ns) {
       case 1: hipLaunchKernelGGL((sc::peer_exchange_kernel<1>), dim3(1), dim3(sc::kWave), 0, ctx->stream, limbs, po); break;
@@ -813,7 +831,7 @@ int peer_gather(sc_ctx* ctx, const u64* a, const u64* b, size_t len, const u64**
   out.sums_dev = ctx->d_sums;
   out.mailbox = ctx->d_mailbox;
   out.seq = ctx->mailbox_seq + 1;
-  fill_peer(ctx, &out, 0);
+  fill_peer(ctx, out.px, 0);
   const size_t arena_off = kInboxRegionWords + (size_t)(out.px.tag & 1u) * 2 * cap;
   sc::PeerG pg;
   for (int q = 0; q < ctx->world; ++q) pg.arena[q] = ctx->peer_base[q] + arena_off;
@@ -1269,6 +1287,8 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "grid_vars5_log") {
     if (value < 0 || value > 26) return fail(ctx, SC_ERR_ARG, "grid_vars5_log out of range (0..26)");
     ctx->grid_vars5_log = (int)value;
+  } else if (k == "grid_sharded") {
+    ctx->grid_sharded = value ? 1 : 0;
   } else if (k == "mid_pass") {
     ctx->mid_pass = value ? 1 : 0;
     memset(ctx->resident_blocks, 0, sizeof(ctx->resident_blocks));   // the cached grids of the tail passes belong to the other kernel
@@ -1325,6 +1345,7 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   else if (k == "grid_vars4_log") *value = ctx->grid_vars4_log;
   else if (k == "grid_vars5_log") *value = ctx->grid_vars5_log;
   else if (k == "mid_pass") *value = ctx->mid_pass;
+  else if (k == "grid_sharded") *value = ctx->grid_sharded;
   else if (k == "grid_blocks") *value = ctx->grid_blocks;
   else if (k == "tail_log") *value = ctx->tail_log;
   else if (k == "max_blocks") *value = ctx->max_blocks;
@@ -1658,7 +1679,7 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
   out.sums_dev = ctx->d_sums;
   out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
   out.seq = mailbox ? ctx->mailbox_seq + 1 : 0;
-  if (peer) fill_peer(ctx, &out, challenge_digest(pt_le, std::min(nv, 3), 0, nv));
+  if (peer) fill_peer(ctx, out.px, challenge_digest(pt_le, std::min(nv, 3), 0, nv));
   const int nt = nv >= ctx->nt_load_log ? 1 : 0;
   SC_TRY(timer_begin(ctx, SC_KIND_EVALUATE, nv, 0, nv, (u64)8 << nv, 0));
   if (nt)
@@ -2015,11 +2036,13 @@ int grid_rounds(const sc_ctx* ctx, int vars) {
     if (1 + grid_passes_needed(ctx, vars - ks) == need) return ks;
   return most;
 }
-// does the pass at round j go to grid_pass_kernel?  (unsharded, folded table small enough)
+// does the pass at round j go to wgrid_pass_kernel?  Unsharded: folded table small enough.  Sharded: the same on the
+// local shard, with the in-kernel exchange of the peer transport, while the shard keeps at least one variable.
 // (the one-round-per-pass mode, a two-round tail, an explicit first_pass_vars and the resident kernel are requests
 // for those schedules)
 bool takes_grid_pass(const sc_ctx* ctx, bool sharded, int cur_log, int kf, size_t j) {
-  if (!ctx->grid_pass || ctx->resident || !ctx->use_mailbox || ctx->vars_per_pass != 2 || ctx->tail_pass_vars != 3 || sharded) return false;
+  if (!ctx->grid_pass || ctx->resident || !ctx->use_mailbox || ctx->vars_per_pass != 2 || ctx->tail_pass_vars != 3) return false;
+  if (sharded && (ctx->transport != Transport::kPeer || !ctx->grid_sharded)) return false;
   if (j == 0 && kf == 0 && ctx->first_pass_vars != 0) return false;
   return cur_log - kf >= 1 && cur_log - kf <= ctx->grid_log;
 }
@@ -2333,7 +2356,10 @@ int prover_pass(sc_prover* pr, size_t j) {
   // variables this pass touches; below tail_log the latency of a collective per pass costs
   // more than finishing redundantly on every rank, so gather once and go on unsharded.
   const int gather_log = ctx->transport == Transport::kPeer ? std::min(ctx->tail_log, ctx->arena_log) : ctx->tail_log;
-  if (pr->sharded && ctx->transport == Transport::kPeer && (pr->cur_log < kf + ks || pr->cur_log <= gather_log)) {
+  // (a shard that can go on with five-round passes and their in-kernel exchange is gathered only when it is down to
+  // its pending challenges: 2^kf <= 32 entries)
+  const bool shard_grid = pr->sharded && takes_grid_pass(ctx, true, pr->cur_log, kf, j);
+  if (pr->sharded && !shard_grid && ctx->transport == Transport::kPeer && (pr->cur_log < kf + ks || pr->cur_log <= gather_log)) {
     // the peers write their shards straight into this rank's arena; the gathered tables live there
     const u64 *fa = nullptr, *fb = nullptr;
     SC_TRY(peer_gather(ctx, pr->cur_a, pr->cur_b, (size_t)1 << pr->cur_log, &fa, &fb));
@@ -2366,7 +2392,7 @@ int prover_pass(sc_prover* pr, size_t j) {
   }
   // the smallest tables: up to five rounds per pass (after a gather the table is whole: decide here)
   const bool by_grid = takes_grid_pass(ctx, pr->sharded, pr->cur_log, kf, j);
-  if (by_grid) ks = grid_rounds(ctx, pr->cur_log - kf);
+  if (by_grid) ks = grid_rounds(ctx, pr->cur_log - kf);   // sharded: planned on the shard's own variables
   if (kf > 3 && !by_grid) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges and no grid pass to fold them", kf);
   if (pr->cur_log < kf + ks)
     return fail(ctx, SC_ERR_STATE, "prover: table has %d variables, pass needs %d", pr->cur_log, kf + ks);
@@ -2384,8 +2410,8 @@ int prover_pass(sc_prover* pr, size_t j) {
   bool mb = false;
   int rc;
   if (by_grid) {
-    rc = launch_grid_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, pr->pending.data(), pr->cur_log);
-    if (rc == SC_OK) rc = collect_grid(ctx, ks, pr->S);
+    rc = launch_grid_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, pr->pending.data(), pr->cur_log, pr->sharded);
+    if (rc == SC_OK) rc = collect_grid(ctx, ks, pr->sharded, pr->S);
   } else {
     rc = launch_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, pr->pending.data(), pr->cur_log, pr->sharded, &mb);
     if (rc == SC_OK) rc = collect_sums(ctx, ks == 1 ? 3 : ks == 2 ? 9 : 27, pr->sharded, mb, pr->S);
