@@ -131,6 +131,7 @@ struct MontGeneric {
   SC_HD void acc_mac(Acc& a, u64 x, u64 y) const { a = add(a, mul(x, y)); }
   SC_HD void acc_mac(Acc& a, X64 x, X64 y) const { acc_mac(a, join64(x), join64(y)); }
   SC_HD u64 acc_get(const Acc& a) const { return a; }
+  SC_HD void acc_add(Acc& a, const Acc& b) const { a = add(a, b); }   // sum of two accumulators (block reductions)
   typedef u64 Acc3;  // short sums (folds): same thing for a generic modulus
   SC_HD void acc3_zero(Acc3& a) const { a = 0; }
   SC_HD void acc3_mac(Acc3& a, u64 x, u64 y) const { a = add(a, mul(x, y)); }
@@ -274,6 +275,16 @@ struct GoldilocksMont {
     u32 l0, l1, l2, l3;  // little-endian 32-bit limbs of the two's-complement sum
   };
   SC_HD void acc_zero(Acc& a) const { a.l0 = a.l1 = a.l2 = a.l3 = 0; }
+  // sum of two accumulators: a plain 128-bit two's-complement add (the term bound covers the sum of their terms)
+  SC_HD void acc_add(Acc& a, const Acc& b) const {
+    const u64 s0 = (u64)a.l0 + b.l0;
+    const u64 s1 = (u64)a.l1 + b.l1 + (s0 >> 32);
+    const u64 s2 = (u64)a.l2 + b.l2 + (s1 >> 32);
+    a.l0 = (u32)s0;
+    a.l1 = (u32)s1;
+    a.l2 = (u32)s2;
+    a.l3 = a.l3 + b.l3 + (u32)(s2 >> 32);
+  }
   SC_HD void acc_mac(Acc& a, u64 x, u64 y) const { acc_mac(a, split64(x), split64(y)); }
   SC_HD void acc_mac(Acc& a, X64 xs, X64 ys) const {
 #if defined(__HIP_DEVICE_COMPILE__)

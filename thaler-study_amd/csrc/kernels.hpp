@@ -479,6 +479,52 @@ __device__ __forceinline__ u64 reduce_cells(const F& f, const typename F::Acc (&
   return mine;
 }
 
+// The same through LDS, on the RAW accumulators: a thread that turns 27 lazy sums into residues and then takes
+// part in 27 x 6 shuffle rounds spends ~2800 instructions on it, on a wave that by then issues alone (~10 us of
+// every launch of the 27-cell pass, ~3.5 us of a 9-cell one: nothing at 2^28 entries, 10 % of a pass on a 2^25-entry
+// shard).  Here the accumulators of eight cells at a time go to LDS, thread (cell, part) adds eight of them as
+// integers, 32 lanes finish with five shuffle rounds and ONE lane per cell reduces to a residue: ~170 instructions
+// per chunk of eight cells.  scratch: 8 * kBlock accumulators; out: NS words.
+template <class A>
+__device__ __forceinline__ A shfl_down_acc(const A& a, int off) {
+  static_assert(sizeof(A) % 4 == 0, "accumulator words");
+  A r;
+  const unsigned* src = reinterpret_cast<const unsigned*>(&a);
+  unsigned* dst = reinterpret_cast<unsigned*>(&r);
+#pragma unroll
+  for (int w = 0; w < (int)(sizeof(A) / 4); ++w) dst[w] = (unsigned)__shfl_down((int)src[w], off, kWave);
+  return r;
+}
+template <class F, int NS>
+__device__ __forceinline__ u64 reduce_cells_lds(const F& f, const typename F::Acc (&acc)[NS], typename F::Acc* scratch, u64* out) {
+  typedef typename F::Acc Acc;
+  constexpr int CH = 8;
+  const int tid = threadIdx.x, cell = tid >> 5, part = tid & 31;
+#pragma unroll
+  for (int c0 = 0; c0 < NS; c0 += CH) {
+    constexpr int kRest = NS % CH;
+    const int n = (c0 + CH <= NS) ? CH : kRest;
+    if (c0 > 0) __syncthreads();   // the previous chunk's accumulators have been read
+#pragma unroll
+    for (int s = 0; s < CH; ++s)
+      if (s < n) scratch[s * kBlock + tid] = acc[(c0 + s < NS) ? c0 + s : 0];
+    __syncthreads();
+    if (cell < n) {
+      Acc t = scratch[cell * kBlock + part];
+#pragma unroll
+      for (int k = 1; k < kBlock / 32; ++k) f.acc_add(t, scratch[cell * kBlock + part + 32 * k]);
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) {
+        const Acc o = shfl_down_acc(t, off);
+        f.acc_add(t, o);
+      }
+      if (part == 0) out[c0 + cell] = f.acc_get(t);
+    }
+  }
+  __syncthreads();
+  return tid < NS ? out[tid] : 0;
+}
+
 // NT: bit 0 = nontemporal loads, bit 1 = nontemporal stores (see ld16 / st16)
 template <class F, int KF, int KS, int NT>
 __global__ void __launch_bounds__(kBlock)
@@ -488,7 +534,10 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   constexpr int IN = 1 << (KF + KS), OUT = 1 << KS, NS = (KS == 1) ? 3 : (KS == 2) ? 9 : 27;
   constexpr int NP = IN / 2, NPO = OUT / 2;  // 16-byte pieces per lane, in and out
   constexpr int kWaves = kBlock / kWave;
-  __shared__ ull2 lds_t[(NP > 1 || NPO > 1) ? kWaves * kWave * NP : 1];
+  // the tile transposes; after the loop the same bytes hold eight cells' accumulators of every thread (reduce_cells_lds)
+  constexpr int kTransposeSlots = (NP > 1 || NPO > 1) ? kWaves * kWave * NP : 1;
+  constexpr int kReduceSlots = (NS >= 9) ? (int)(8 * kBlock * sizeof(typename F::Acc) / sizeof(ull2)) : 1;
+  __shared__ ull2 lds_t[kTransposeSlots > kReduceSlots ? kTransposeSlots : kReduceSlots];
   __shared__ u64 lds[kWaves * NS];
   __shared__ int lds_flag;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
@@ -608,7 +657,13 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     }
   }
 
-  const u64 mine = reduce_cells<F, NS>(f, acc, lds);
+  u64 mine;
+  if constexpr (NS >= 9) {
+    __syncthreads();   // every wave is done with its transposes
+    mine = reduce_cells_lds<F, NS>(f, acc, reinterpret_cast<typename F::Acc*>(lds_t), lds);
+  } else {
+    mine = reduce_cells<F, NS>(f, acc, lds);
+  }
   finish_pass<F, NS>(f, out, mine, &lds_flag);
 }
 
