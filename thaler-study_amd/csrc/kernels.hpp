@@ -405,43 +405,74 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
   __syncthreads();
   if (!*lds_flag) return;
   const int n_blocks = gridDim.x;
-  // each wave takes the rows wave, wave+4, ... two at a time: the loads of one row are a chain of
-  // dependent rounds (~1 us each from L2), so two rows in flight halve the serial tail
-  constexpr int kWavesPerBlock = kBlock / kWave;
-  for (int s = wave; s < NS; s += 2 * kWavesPerBlock) {
-    const int s2 = s + kWavesPerBlock;
-    const bool two = s2 < NS;
-    const u64* row0 = o.partials + (size_t)s * o.n_rows;
-    const u64* row1 = o.partials + (size_t)(two ? s2 : s) * o.n_rows;
-    u64 a0 = 0, a1 = 0, c0 = 0, c1 = 0;
-    int b = lane;
-    for (; b + 3 * kWave < n_blocks; b += 4 * kWave) {  // eight loads in flight per lane
-      u64 x[4], y[4];
+  if constexpr (NS >= 9) {
+    // thread = (row, slice): every load of a thread in flight at once (a round of dependent loads costs ~0.6 us from
+    // L2; a wave per pair of rows walked 27 rows of 512 partials in four such iterations of two rounds, ~7 us)
+    constexpr int K = (kBlock / NS < 16) ? kBlock / NS : 16, U = 32;
+    __shared__ u64 fin[K * NS];
+    const int row = threadIdx.x % NS, slice = threadIdx.x / NS;
+    if (slice < K) {
+      const u64* src = o.partials + (size_t)row * o.n_rows;
+      u64 part = 0;
+      for (int b0 = slice; b0 < n_blocks; b0 += K * U) {
+        u64 x[U];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        x[q] = __hip_atomic_load(row0 + b + q * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        y[q] = __hip_atomic_load(row1 + b + q * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        for (int u = 0; u < U; ++u) {
+          const int b = b0 + u * K;
+          x[u] = (b < n_blocks) ? __hip_atomic_load(src + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) part = f.add(part, x[u]);
       }
-      a0 = f.add(a0, f.add(x[0], x[2])); a1 = f.add(a1, f.add(x[1], x[3]));
-      c0 = f.add(c0, f.add(y[0], y[2])); c1 = f.add(c1, f.add(y[1], y[3]));
+      fin[slice * NS + row] = part;
     }
-    for (; b < n_blocks; b += kWave) {
-      a0 = f.add(a0, __hip_atomic_load(row0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-      c0 = f.add(c0, __hip_atomic_load(row1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    }
-    u64 t = f.add(a0, a1), u = f.add(c0, c1);
+    __syncthreads();
+    if (threadIdx.x < NS) {
+      u64 t = 0;
 #pragma unroll
-    for (int off = kWave / 2; off >= 1; off >>= 1) {
-      t = f.add(t, shfl_down_u64(t, off));
-      u = f.add(u, shfl_down_u64(u, off));
+      for (int q = 0; q < K; ++q) t = f.add(t, fin[q * NS + threadIdx.x]);
+      if (xchg) write_split(xl, threadIdx.x, t);
+      else publish_value(o, threadIdx.x, t);
     }
-    if (lane == 0) {
-      if (xchg) {
-        write_split(xl, s, t);
-        if (two) write_split(xl, s2, u);
-      } else {
-        publish_value(o, s, t);
-        if (two) publish_value(o, s2, u);
+  } else {
+    // each wave takes the rows wave, wave+4, ... two at a time: the loads of one row are a chain of
+    // dependent rounds (~1 us each from L2), so two rows in flight halve the serial tail
+    constexpr int kWavesPerBlock = kBlock / kWave;
+    for (int s = wave; s < NS; s += 2 * kWavesPerBlock) {
+      const int s2 = s + kWavesPerBlock;
+      const bool two = s2 < NS;
+      const u64* row0 = o.partials + (size_t)s * o.n_rows;
+      const u64* row1 = o.partials + (size_t)(two ? s2 : s) * o.n_rows;
+      u64 a0 = 0, a1 = 0, c0 = 0, c1 = 0;
+      int b = lane;
+      for (; b + 3 * kWave < n_blocks; b += 4 * kWave) {  // eight loads in flight per lane
+        u64 x[4], y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          x[q] = __hip_atomic_load(row0 + b + q * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          y[q] = __hip_atomic_load(row1 + b + q * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a0 = f.add(a0, f.add(x[0], x[2])); a1 = f.add(a1, f.add(x[1], x[3]));
+        c0 = f.add(c0, f.add(y[0], y[2])); c1 = f.add(c1, f.add(y[1], y[3]));
+      }
+      for (; b < n_blocks; b += kWave) {
+        a0 = f.add(a0, __hip_atomic_load(row0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        c0 = f.add(c0, __hip_atomic_load(row1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+      u64 t = f.add(a0, a1), u = f.add(c0, c1);
+#pragma unroll
+      for (int off = kWave / 2; off >= 1; off >>= 1) {
+        t = f.add(t, shfl_down_u64(t, off));
+        u = f.add(u, shfl_down_u64(u, off));
+      }
+      if (lane == 0) {
+        if (xchg) {
+          write_split(xl, s, t);
+          if (two) write_split(xl, s2, u);
+        } else {
+          publish_value(o, s, t);
+          if (two) publish_value(o, s2, u);
+        }
       }
     }
   }
