@@ -2014,7 +2014,7 @@ int pass_rounds(const sc_ctx* ctx, size_t num_vars, size_t j, int kf, int cur_lo
   return ks;
 }
 
-// Rounds a grid pass (kernels.hpp, grid_pass_kernel) serves when `vars` variables are left, i.e. the folded table
+// Rounds a grid pass (kernels.hpp, wgrid_pass_kernel) serves when `vars` variables are left, i.e. the folded table
 // has 2^vars entries: as few passes as the size limits allow (five rounds on tables of <= 2^grid_vars5_log entries,
 // four up to 2^grid_vars4_log, else three), the rounds shared evenly among them where the limits permit.
 int grid_max_rounds(const sc_ctx* ctx, int vars) {
