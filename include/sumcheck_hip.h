@@ -91,7 +91,7 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      "tail_pass_vars" 2, an explicit "first_pass_vars" for the first pass, or "resident" - those
  *                      name their own schedules.  "grid_sharded" (1): on the peer transport the shards of a sharded
  *                      prover go on with these passes too (cells exchanged inside the kernel) until they are down to their
- *                      pending challenges, and are gathered only then.  "mid_pass" (1): the three-round tail passes outside this planner
+ *                      pending challenges; one small launch then serves the rounds of the rank bits (no gather).  "mid_pass" (1): the three-round tail passes outside this planner
  *                      (sharded ones) run grid_pass3_kernel instead of small_pass3_kernel.
  *   "tail_log"         shard log-size at which a sharded prover gathers (default 16)
  *   "max_blocks"       grid cap of the streaming kernels (default 3 per CU = 768); a pass never

@@ -1124,6 +1124,113 @@ wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
   if (tid == 0) __hip_atomic_store(out.mailbox + kMailboxSeq, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
+// The last pass of a sharded prover on the peer transport: the shard is down to its 2^kf pending entries (kf <= 5),
+// the rounds left are those of the rank bits.  One workgroup per rank folds the pending challenges (one entry per
+// table is left), hands that entry to every peer through the wide part of the inboxes - the gather and the exchange
+// in one - and computes the 3^g cells of the g = log2(world) <= 3 remaining rounds on the world-entry tables itself:
+// thread c forms its two extension values as signed sums of at most eight entries.  Every rank ends up with the same
+// tables (written to A2 / B2, world entries each) and the same cells (whole residues in the wide mailbox).
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+rank_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2, GridW gw, int kf,
+                 WgOut out) {
+  const PeerX& px = out.px;
+  __shared__ u64 ta[kMaxPeers], tb[kMaxPeers];
+  __shared__ int worst;
+  const int tid = threadIdx.x;
+  const size_t par = (size_t)(px.tag & 1u) * kMaxPeers * kInboxWords;
+  int err = 0;
+  if (tid == 0) worst = 0;
+  if (tid < 2) {   // thread 0: table a, thread 1: table b - fold the 2^kf entries, publish the result to every inbox
+    const u64* __restrict__ src = tid ? B : A;
+    const int fan = 1 << kf;
+    u64 v = 0;
+    for (int c = 0; c < fan; ++c) v = f.add(v, f.mul(src[c], gw.w[c]));
+    const ull2 pair = {((u64)px.tag << 32) | (v & 0xFFFFFFFFull), ((u64)px.tag << 32) | (v >> 32)};
+    const size_t mine = par + (size_t)px.rank * kInboxWords + kInboxWide + 2 * (size_t)tid;
+    for (int q = 0; q < px.world; ++q) st16_system(px.inbox[q] + mine, pair);
+  }
+  if (tid == 2) {   // the digest of the challenges
+    const u64 g = ((u64)px.tag << 32) | (u64)px.digest;
+    for (int q = 0; q < px.world; ++q)
+      __hip_atomic_store(px.inbox[q] + par + (size_t)px.rank * kInboxWords + kInboxDigest, g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  // sweep: thread (source r, what): what = 0 / 1 the entries of a / b, 2 the digest
+  const unsigned long long t0 = wall_clock64();
+  if (tid < 3 * px.world) {
+    const int r = tid / 3, what = tid % 3;
+    const u64* base = px.inbox[px.rank] + par + (size_t)r * kInboxWords;
+    unsigned spins = 0;
+    while (true) {
+      if (what < 2) {
+        const ull2 g = ld16_system(base + kInboxWide + 2 * what);
+        if ((unsigned)(g.x >> 32) == px.tag && (unsigned)(g.y >> 32) == px.tag) {
+          const u64 v = (g.x & 0xFFFFFFFFull) | (g.y << 32);
+          (what ? tb : ta)[r] = v;
+          break;
+        }
+      } else {
+        const u64 g = __hip_atomic_load(base + kInboxDigest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(g >> 32) == px.tag) {
+          err = ((unsigned)g != px.digest) ? kXchgDigest : 0;
+          break;
+        }
+      }
+      if ((++spins & 31) == 0 && wall_clock64() - t0 > px.spin_ticks) {
+        err = kXchgTimeout | (r << 8);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(1);
+    }
+  }
+  __syncthreads();
+  if (err) atomicMax(&worst, err);
+  __syncthreads();
+  if (worst == 0) {
+    if (tid < px.world) {
+      A2[tid] = ta[tid];
+      B2[tid] = tb[tid];
+    }
+    // cell c = sum_j d_j 3^(g-1-j), d_j the point of rank bit j (bit 0 = the next variable); its extension values are
+    // sum_e coef(c, e) t[e], coef = prod_j k(d_j, bit_j(e)), k(0, b) = [b = 0], k(1, b) = [b = 1], k(inf, b) = b ? +1 : -1
+    int g = 0;
+    while ((1 << g) < px.world) ++g;
+    int cells = 1;
+    for (int j = 0; j < g; ++j) cells *= 3;
+    if (tid < cells) {
+      int d[3] = {0, 0, 0};
+      int c = tid;
+      for (int j = g - 1; j >= 0; --j) {
+        d[j] = c % 3;
+        c /= 3;
+      }
+      u64 ea = 0, eb = 0;
+      for (int e = 0; e < px.world; ++e) {
+        int sign = 1;
+        for (int j = 0; j < g; ++j) {
+          const int b = (e >> j) & 1;
+          if (d[j] == 2) sign = b ? sign : -sign;
+          else if (d[j] != b) sign = 0;
+        }
+        if (sign > 0) {
+          ea = f.add(ea, ta[e]);
+          eb = f.add(eb, tb[e]);
+        } else if (sign < 0) {
+          ea = f.sub(ea, ta[e]);
+          eb = f.sub(eb, tb[e]);
+        }
+      }
+      __hip_atomic_store(out.mailbox + kMailboxWide + tid, f.mul(ea, eb), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    __hip_atomic_store(out.mailbox + kMailboxErr, (u64)worst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(out.mailbox + kMailboxSeq, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
 template <class F>
 __global__ void __launch_bounds__(kBlock)
 grid_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,

@@ -685,6 +685,41 @@ int collect_grid(sc_ctx* ctx, int ks, bool across_ranks, u64* out) {
   return SC_OK;
 }
 
+// The last pass of a sharded prover on the peer transport (kernels.hpp, rank_pass_kernel): folds the shard's 2^kf
+// pending entries, exchanges the one entry left per table with the peers and leaves the world-entry tables in A2 / B2
+// and the 3^log2(world) cells of the rank-bit rounds in out[].
+int rank_pass(sc_ctx* ctx, int kf, const u64* A, const u64* B, u64* A2, u64* B2, const u64* r, u64* out) {
+  if (ctx->transport != Transport::kPeer || !ctx->use_mailbox || kf < 0 || kf > sc::kGridMaxVars || ctx->log_world < 1 || ctx->log_world > 3)
+    return fail(ctx, SC_ERR_STATE, "rank_pass: needs the peer transport, the mailbox and 2..8 ranks");
+  const sc::GridW gw = make_grid_weights(ctx, r, kf);
+  sc::WgOut wo;
+  wo.partials = ctx->d_wg_partials;
+  wo.group_rows = ctx->d_wg_groups;
+  wo.tickets = ctx->d_wg_tickets;
+  wo.mailbox = ctx->d_mailbox;
+  wo.seq = ctx->mailbox_seq + 1;
+  fill_peer(ctx, wo.px, challenge_digest(r, kf, ctx->log_world, kf) ^ 0x72616e6bu);
+  SC_TRY(timer_begin(ctx, SC_KIND_GRID_PASS, kf, ctx->log_world, kf, (u64)16 << kf, (u64)16 << ctx->log_world));
+  SC_DISPATCH_FIELD(ctx, F, f,
+                    hipLaunchKernelGGL((sc::rank_pass_kernel<F>), dim3(1), dim3(sc::kBlock), 0, ctx->stream, f, A, B, A2, B2, gw, kf, wo));
+  SC_HIP(ctx, hipGetLastError());
+  ctx->mailbox_seq += 1;
+  SC_TRY(timer_end(ctx));
+  SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
+  const u64 err = __atomic_load_n(ctx->h_mailbox + sc::kMailboxErr, __ATOMIC_ACQUIRE);
+  if (err == (u64)sc::kXchgDigest)
+    return fail(ctx, SC_ERR_STATE, "the ranks of this sharded prover were given different challenges");
+  if (err != 0) {
+    poison(ctx);
+    return fail(ctx, SC_ERR_RCCL, "peer exchange: a rank's entries did not arrive within %d ms (rank %d waited for rank %d at tag %u)",
+                ctx->peer_spin_ms, ctx->rank, (int)((err >> 8) & 0xFF), ctx->xchg_tag);
+  }
+  int cells = 1;
+  for (int i = 0; i < ctx->log_world; ++i) cells *= 3;
+  for (int c = 0; c < cells; ++c) out[c] = ctx->h_mailbox[sc::kMailboxWide + c];
+  return SC_OK;
+}
+
 // PassOut of the next launch with `grid` blocks that publishes to the mailbox (unsharded paths).
 // Nothing is committed here: call commit_pass_out() once the launch is known to be in the stream.
 sc::PassOut next_pass_out(sc_ctx* ctx, int grid) {
@@ -2359,6 +2394,33 @@ int prover_pass(sc_prover* pr, size_t j) {
   // (a shard that can go on with five-round passes and their in-kernel exchange is gathered only when it is down to
   // its pending challenges: 2^kf <= 32 entries)
   const bool shard_grid = pr->sharded && takes_grid_pass(ctx, true, pr->cur_log, kf, j);
+  // ... and when nothing but those is left, the rounds of the rank bits are one small launch: fold, exchange the
+  // single entries (the gather), cells - instead of a gather launch and a pass on the gathered table
+  if (pr->sharded && !shard_grid && pr->cur_log == kf && ctx->log_world >= 1 && ctx->log_world <= 3 &&
+      pr->num_vars - j == (size_t)ctx->log_world && takes_grid_pass(ctx, true, pr->cur_log + 1, kf, j)) {
+    u64 *na = nullptr, *nb = nullptr;
+    SC_TRY(pool_alloc(ctx, (size_t)ctx->world, &na));
+    int rc = pool_alloc(ctx, (size_t)ctx->world, &nb);
+    if (rc == SC_OK) rc = rank_pass(ctx, kf, pr->cur_a, pr->cur_b, na, nb, pr->pending.data(), pr->S);
+    if (rc != SC_OK) {
+      pool_release(ctx, na);
+      pool_release(ctx, nb);
+      return rc;
+    }
+    pool_release(ctx, pr->own_a);
+    pool_release(ctx, pr->own_b);
+    pr->own_a = na;
+    pr->own_b = nb;
+    pr->cur_a = na;
+    pr->cur_b = nb;
+    pr->cur_log = ctx->log_world;
+    pr->pending.clear();
+    pr->sharded = false;
+    pr->cache_ks = ctx->log_world;
+    pr->cache_round = j;
+    pr->g_known = -1;
+    return SC_OK;
+  }
   if (pr->sharded && !shard_grid && ctx->transport == Transport::kPeer && (pr->cur_log < kf + ks || pr->cur_log <= gather_log)) {
     // the peers write their shards straight into this rank's arena; the gathered tables live there
     const u64 *fa = nullptr, *fb = nullptr;
