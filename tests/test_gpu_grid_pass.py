@@ -99,6 +99,34 @@ def test_round_by_round_api_over_grid_passes(pkg):
         ctx.close()
 
 
+def test_two_provers_interleaved_on_one_context(pkg):
+    """two provers of different sizes on one context, their rounds interleaved: each keeps its own copy of the cells
+    of its last pass (the wide mailbox and the ticket counters are shared and reused by every launch)"""
+    scp = pkg.sum_check_protocol
+    p = GOLD
+    ctx = pkg.Context(pkg.Field(p))
+    o = oracle(p)
+    F = ctx.field
+    pts = (0, F.one, F.add(F.one, F.one))
+    sizes = (13, 17)
+    gs, refs, chs, provers = [], [], [], []
+    for n in sizes:
+        a = pkg.DenseMultilinearExtension.generate(ctx, 31 + n, n)
+        b = pkg.DenseMultilinearExtension.generate(ctx, 32 + n, n)
+        gs.append(pkg.matrix_multiplication.G(a, b))
+        chs.append(challenges(o, n))
+        refs.append(o.prove(o.generate(31 + n, n), o.generate(32 + n, n), chs[-1]))
+        provers.append(scp.Prover.new(gs[-1].clone()))
+    for k, pr in enumerate(provers):
+        assert pr.c_1() == refs[k]["c_1"]
+    for j in range(max(sizes)):
+        for k, pr in enumerate(provers):
+            if j < sizes[k]:
+                poly = pr.round(int(chs[k][j - 1]) if j else F.one, j)
+                assert [poly.evaluate(x) for x in pts] == [int(x) for x in refs[k]["evals"][j]], (k, j)
+    ctx.close()
+
+
 def test_extreme_words_through_grid_passes(pkg):
     """largest and smallest Montgomery words, challenges p-1, p-2, p-3: the five-challenge fold weights and the
     243-cell lazy sums at their extremes"""
