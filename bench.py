@@ -459,6 +459,7 @@ def run_mle(args, pkg, torch, dist, rank, world, local_rank):
     def step():
         outs = [t.evaluate(pt, pkg.ORDER_LE), t.evaluate(pt, pkg.ORDER_BE)]
         outs += [t.fix_variables(pt[:k]) for k in ks]
+        ctx.synchronize()          # fix_variables returns once its launches are in the library's stream
         return outs
 
     ctx.set_option("time_kernels", 1)     # five launches per step, each hundreds of microseconds: probe cost is negligible

@@ -188,7 +188,8 @@ int sc_table_free(sc_ctx* ctx, sc_table* t);
 
 /* DenseMultilinearExtension::fix_variables(&r[..k]) (matrix-multiplication/src/lib.rs:83,86,
  * 104-105): new[b] = t[2b] + r*(t[2b+1]-t[2b]) per variable for SC_ORDER_LE; stride-half
- * pairing for SC_ORDER_BE.  *out has len >> k entries.  Input is not modified. */
+ * pairing for SC_ORDER_BE.  *out has len >> k entries.  Input is not modified.  Asynchronous: the new table is
+ * ready in the order of the context's stream (every sc_* call on the context is), sc_ctx_synchronize waits. */
 int sc_table_fix_variables(sc_ctx* ctx, const sc_table* in, const uint64_t* r, size_t k, int order,
                            sc_table** out);
 /* Polynomial::evaluate (matrix-multiplication/src/lib.rs:97-98) for SC_ORDER_LE;

@@ -1674,7 +1674,8 @@ extern "C" int sc_table_fix_variables(sc_ctx* ctx, const sc_table* in, const uin
     delete t;
     return rc;
   }
-  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+  // no synchronisation: every consumer of the new table (and every release of the old one) is work on the
+  // context's stream, behind these launches; a fault of theirs surfaces at the next call that waits
   *out = t;
   return SC_OK;
 }
