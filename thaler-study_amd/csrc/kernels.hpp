@@ -1727,15 +1727,23 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int tb = n - 7 - ta;
-  // every block builds the tile-in-segment weights itself: 2^ta products of ta factors
-  for (int i = threadIdx.x; i < (1 << ta); i += kBlock) {
+  // every block builds the tile-in-segment weights itself, as products of two half tables (<= 32 entries of <= 5
+  // factors each, then one product per weight): 2^ta weights of ta factors each were ~1000 instructions per thread
+  // on waves issuing alone - 4 us of a 35 us launch on a 2^24-entry table
+  __shared__ u64 eqH[2][32];
+  const int lo_bits = ta < 5 ? ta : 5, hi_bits = ta - lo_bits;
+  if (threadIdx.x < 64) {
+    const int half = threadIdx.x >> 5, i = threadIdx.x & 31;
+    const int nb = half ? hi_bits : lo_bits, off = half ? lo_bits : 0;
     u64 w = f.one();
-    for (int j = 0; j < ta; ++j) {
-      const u64 rj = rv.v[7 + j];
+    for (int j = 0; j < nb; ++j) {
+      const u64 rj = rv.v[7 + off + j];
       w = f.mul(w, ((i >> j) & 1) ? rj : f.sub(f.one(), rj));
     }
-    eqA[i] = w;
+    eqH[half][i] = w;   // entries with bits above nb repeat lower ones and are never read
   }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (1 << ta); i += kBlock) eqA[i] = f.mul(eqH[0][i & ((1 << lo_bits) - 1)], eqH[1][i >> lo_bits]);
   __syncthreads();
   const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
   const size_t n_tiles = (size_t)1 << (n - 7);
