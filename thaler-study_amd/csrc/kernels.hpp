@@ -1708,6 +1708,28 @@ eq_table_kernel(F f, RVec rv, int off, int nbits, u64* __restrict__ out) {
   }
 }
 
+// eqA[i] = prod_{j < ta} (bit_j(i) ? r[j] : 1 - r[j]), i < 2^ta <= 1024, by the whole block: products of two half
+// tables (<= 32 entries of <= 5 factors each, then one product per weight).  2^ta weights of ta factors each were ~1000
+// instructions per thread on waves issuing alone - 4 us of a 35 us launch on a 2^24-entry table.  Ends with a barrier.
+template <class F>
+__device__ __forceinline__ void build_eq_weights(const F& f, const u64* r, int ta, u64* eqA /* [1 << ta] */) {
+  __shared__ u64 eqH[2][32];
+  const int lo_bits = ta < 5 ? ta : 5, hi_bits = ta - lo_bits;
+  if (threadIdx.x < 64) {
+    const int half = threadIdx.x >> 5, i = threadIdx.x & 31;
+    const int nb = half ? hi_bits : lo_bits, off = half ? lo_bits : 0;
+    u64 w = f.one();
+    for (int j = 0; j < nb; ++j) {
+      const u64 rj = r[off + j];
+      w = f.mul(w, ((i >> j) & 1) ? rj : f.sub(f.one(), rj));
+    }
+    eqH[half][i] = w;   // entries with bits above nb repeat lower ones and are never read
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (1 << ta); i += kBlock) eqA[i] = f.mul(eqH[0][i & ((1 << lo_bits) - 1)], eqH[1][i >> lo_bits]);
+  __syncthreads();
+}
+
 // Polynomial::evaluate of a 2^n-entry table (n >= 8) in ONE streaming pass:
 //   sum_i t[i] * eq(r, i),  eq factored over the index bits as
 //   bit 0 (inside a 16-byte piece) | bits 1..6 (lane) | ta bits (tile within a segment,
@@ -1727,24 +1749,7 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int tb = n - 7 - ta;
-  // every block builds the tile-in-segment weights itself, as products of two half tables (<= 32 entries of <= 5
-  // factors each, then one product per weight): 2^ta weights of ta factors each were ~1000 instructions per thread
-  // on waves issuing alone - 4 us of a 35 us launch on a 2^24-entry table
-  __shared__ u64 eqH[2][32];
-  const int lo_bits = ta < 5 ? ta : 5, hi_bits = ta - lo_bits;
-  if (threadIdx.x < 64) {
-    const int half = threadIdx.x >> 5, i = threadIdx.x & 31;
-    const int nb = half ? hi_bits : lo_bits, off = half ? lo_bits : 0;
-    u64 w = f.one();
-    for (int j = 0; j < nb; ++j) {
-      const u64 rj = rv.v[7 + off + j];
-      w = f.mul(w, ((i >> j) & 1) ? rj : f.sub(f.one(), rj));
-    }
-    eqH[half][i] = w;   // entries with bits above nb repeat lower ones and are never read
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < (1 << ta); i += kBlock) eqA[i] = f.mul(eqH[0][i & ((1 << lo_bits) - 1)], eqH[1][i >> lo_bits]);
-  __syncthreads();
+  build_eq_weights(f, rv.v + 7, ta, eqA);   // the tile-in-segment weights
   const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
   const size_t n_tiles = (size_t)1 << (n - 7);
   const size_t n_chunks = n_tiles >> chunk_log;
@@ -1819,14 +1824,7 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int ta = k - 7;
-  for (int i = threadIdx.x; i < (1 << ta); i += kBlock) {
-    u64 w = f.one();
-    for (int j = 0; j < ta; ++j) {
-      const u64 rj = rv.v[7 + j];
-      w = f.mul(w, ((i >> j) & 1) ? rj : f.sub(f.one(), rj));
-    }
-    eqA[i] = w;
-  }
+  build_eq_weights(f, rv.v + 7, ta, eqA);
   u64 wl = f.one();
 #pragma unroll
   for (int j = 0; j < 6; ++j) {

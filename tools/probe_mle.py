@@ -13,7 +13,7 @@ def med(fn, reps=9):
     fn(); fn()
     ts = []
     for _ in range(reps):
-        ctx.synchronize(); t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        ctx.synchronize(); t0 = time.perf_counter(); fn(); ctx.synchronize(); ts.append(time.perf_counter() - t0)
     return sorted(ts)[len(ts)//2]
 for n in [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "24,28").split(",")]:
     t = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
