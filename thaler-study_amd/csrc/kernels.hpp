@@ -856,6 +856,17 @@ __device__ __forceinline__ u64 grid_fold1(const F& f, const u64* __restrict__ T,
   T2[i] = v;
   return v;
 }
+// fix_variables of four or five variables of one SMALL table in one launch (thread = output entry, its 2^kf inputs a
+// contiguous run: fine for tables that sit in the caches, where a chain of <= 3-variable folds is two launches)
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+fold_wide_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, GridW gw, int kf, size_t n_out) {
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n_out; i += (size_t)gridDim.x * kBlock) {
+    if (kf == 4) (void)grid_fold1<F, 4>(f, T, T2, gw, i);
+    else (void)grid_fold1<F, 5>(f, T, T2, gw, i);
+  }
+}
+
 // the block's sums: thread c < 3^KS returns cell c
 template <class F, int KS>
 __device__ __forceinline__ u64 wgrid_body(const F& f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,

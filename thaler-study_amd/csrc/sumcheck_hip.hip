@@ -1075,6 +1075,18 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
                                                         ctx->stream, f, cur, nxt, step, rv, nlen));
       SC_CHAIN(timer_end(ctx));
       cur_len = nlen;
+    } else if (order == SC_ORDER_LE && k - done >= 4 && cur_len <= ((size_t)1 << 20) && (cur_len >> std::min<size_t>(5, k - done)) >= 1) {
+      // a small table: four or five variables in one launch (kernels.hpp, fold_wide_kernel)
+      step = (int)std::min<size_t>(5, k - done);
+      const size_t nlen = cur_len >> step;
+      SC_CHAIN(pool_alloc(ctx, nlen, &nxt));
+      const sc::GridW gw = make_grid_weights(ctx, r + done, step);
+      SC_CHAIN(timer_begin(ctx, SC_KIND_FOLD, step, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * nlen));
+      const int grid = grid_for(ctx, nlen);
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_wide_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, cur, nxt,
+                                                      gw, step, nlen));
+      SC_CHAIN(timer_end(ctx));
+      cur_len = nlen;
     } else if (order == SC_ORDER_LE) {
       step = (int)std::min<size_t>(3, k - done);
       while (step > 1 && (cur_len >> step) < 2) --step;
