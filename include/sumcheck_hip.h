@@ -104,7 +104,7 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      "resident_stamps" = 1 records block 0's wall-clock stamps per phase (diagnostic: read
  *                      back with sc_ctx_get_option "resident_stamp_<i>", host think time "resident_host_ns")
  *   "arena_log"        peer transport: a gather arena holds world * 2^arena_log words per table (default 17;
- *                      set before sc_ctx_comm_peer_export); "peer_spin_ms": bound of in-kernel waits for peers
+ *                      set before sc_ctx_comm_peer_export); "peer_spin_ms": bound of in-kernel waits for peers (default 30000)
  *   "time_kernels"     HIP-event timing of pass kernels (see sc_ctx_kernel_time)
  *   "nt_load_log" / "nt_store_log"  table log-size from which loads / stores are nontemporal */
 int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value);

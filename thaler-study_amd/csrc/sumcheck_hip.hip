@@ -180,7 +180,7 @@ struct sc_ctx {
   bool peer_ipc_opened[sc::kMaxPeers] = {};
   int arena_log = 17;          // a gather arena holds world * 2^arena_log words per table
   unsigned xchg_tag = 0;       // exchange tag of the last sharded pass (the same on every rank)
-  int peer_spin_ms = 2000;     // bound of every in-kernel wait for a peer
+  int peer_spin_ms = 30000;    // bound of every in-kernel wait for a peer: a failure detector, so generous (a rank of a freshly started job can lag for seconds)
 
   // kernel timing
   // pass-kernel timing (option "time_kernels"): a ring of event pairs, read back only when the
