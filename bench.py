@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
 """bench.py - field mul-adds/s of the sumcheck prover (BASELINE.json metric).
 
-  python bench.py --gpus 1 --steps K --warmup W [--workload prover|mle]
+  python bench.py --gpus N --steps K --warmup W [--workload prover|mle]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
+(both forms work for N > 1: without WORLD_SIZE in the environment bench.py starts the N rank processes itself, as a
+child launcher, before it has touched the GPU)
 
 --workload prover (default).  One "step" = one complete interactive sumcheck proof of the synthetic
 n-variable instance of BASELINE.md section 3 (g = a*b, two 2^n-entry Goldilocks tables resident in HBM
@@ -12,7 +14,10 @@ round's sums were read back - the timed region of the reference's criterion benc
 (matrix-multiplication/benches/mm_benchmark.rs:88-96).  n = 28 (BASELINE.json configs[3], the
 configuration the metric is quoted on; 4 GiB of tables, fits one GPU).
 N > 1: strong scaling - the same 2^28 hypercube sharded by its top log2(N) index bits, one process per
-GPU, one exchange of the round sums per device pass.
+GPU, one exchange of the round sums per device pass.  Both in-library data planes are timed, each in its own
+barrier-bracketed region of exactly K proofs: the in-kernel exchange through peer-mapped inboxes and RCCL
+(one ncclAllReduce of the pass's split limbs, the collective BASELINE.json names); `value` is the faster one,
+`config.transports` carries both with the rank count each transport reports (ncclCommCount for RCCL).
 
 --workload mle.  BASELINE.json configs[1]: multilinear-extensions evaluate + fix_variable on ONE table
 of 2^n entries (n = 24 by default; --num-vars 28 for the large shape).  One step = evaluate (LE),
@@ -108,110 +113,99 @@ def load_traffic(key):
         return json.load(f).get(key)
 
 
-def setup_transport(args, pkg, ctx_factory, rank, world, dist):
-    """the context of this rank, joined to the data-plane transport"""
+def attach_plane(plane, pkg, ctx, rank, world, dist):
+    """Join this rank's context to one data plane ("peer" | "rccl" | "host") and prove a small sharded instance through
+    it.  Every rank executes the same control-plane collectives whatever happens locally (a one-sided failure must not
+    leave the others waiting in a rendezvous); returns (ok_on_every_rank, reason)."""
+    import torch
     D = pkg.distributed
-    ctx = ctx_factory()
-    transport = "none"
-    want = os.environ.get("SC_BENCH_TRANSPORT", "")
-    if world == 1 and (os.environ.get("SC_BENCH_FORCE_RCCL") == "1" or want in ("rccl", "peer")):
-        # diagnostic: the sharded code path (per-pass exchange, tail gather) with one rank on a single-GPU box
-        if want == "peer":
-            D.attach_peer(ctx, 0, 1)
-            return ctx, "peer(world=1, diagnostic)"
-        D.attach_rccl(ctx, 0, 1)
-        return ctx, "rccl(world=1, diagnostic)"
-    if world > 1:
-        import torch
-        if want == "host":
-            ar, ag = D.torch_collectives()
-            ctx.comm_init_host(rank, world, ar, ag)
-            return ctx, "host(gloo)"
-        # data plane inside the library.  Default: the peer transport (in-kernel exchange through IPC-mapped
-        # inboxes, no collective launch), validated by a small sharded proof before anything is timed; if
-        # that self-test fails on any rank every rank switches to RCCL and the line says so.  A rank that
-        # cannot create the transport it was asked for makes EVERY rank exit non-zero: a scaling run must
-        # never silently measure another transport (SC_BENCH_TRANSPORT=host requests the host transport).
-        def agree(ok):
-            flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            return int(flag.item()) == 1
 
-        def self_test(c, ok):
-            """a small sharded proof through the transport; every rank executes the same collectives whatever
-            happens locally, so a one-sided failure cannot leave the others waiting in a rendezvous"""
-            mine, why = None, ""
-            if ok:
-                try:
-                    mm, syn = pkg.matrix_multiplication, pkg.synthetic
-                    nt = 16
-                    start, length = D.shard_range(nt, rank, world)
-                    a, b = syn.tables(c, length.bit_length() - 1, start=start)
-                    g = mm.G(a, b)
-                    c1, evals, ch = mm.prove(c, g, syn.SEED_R)
-                    problem = check_identities(c.field, c1, evals, ch, g.evaluate([int(x) for x in ch]))
-                    if problem:
-                        raise RuntimeError("sharded self-test: " + problem)
-                    mine = (c1, evals.tobytes())
-                except Exception as e:  # pragma: no cover - depends on the node
-                    why = str(e)
-            seen = [None] * world
-            dist.all_gather_object(seen, mine)
-            if mine is None or any(x != seen[0] for x in seen):
-                return False, why or "ranks disagree on the self-test transcript"
-            return True, ""
+    def agree(ok):
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return int(flag.item()) == 1
 
-        err = ""
-        if os.environ.get("SC_BENCH_FAIL_TRANSPORT_RANK") in (str(rank), "all"):
-            ok, err = False, "injected transport failure (SC_BENCH_FAIL_TRANSPORT_RANK)"   # test hook
-            if not agree(ok):
-                raise SystemExit("bench.py: data-plane transport init failed on some rank: %s; set SC_BENCH_TRANSPORT=host "
-                                 "to run over the host (gloo) transport on purpose" % err)
-        if want in ("", "peer"):
-            ok, handle = True, None
+    def bail():
+        errs = [None] * world
+        dist.all_gather_object(errs, err)
+        return False, next((e for e in errs if e), "a rank failed to attach")
+
+    ok, err = True, ""
+    if os.environ.get("SC_BENCH_FAIL_TRANSPORT_RANK") in (str(rank), "all"):
+        ok, err = False, "injected transport failure (SC_BENCH_FAIL_TRANSPORT_RANK)"   # test hook
+    if plane == "peer":
+        handle = None
+        if ok:
             try:
-                # the bound of an in-kernel wait for a peer: only a failure detector, so generous - on a freshly
-                # started box a rank can stall for many seconds paging code in (measured: > 20 s with eight ranks)
-                ctx.set_option("peer_spin_ms", 60000)
                 handle = ctx.comm_peer_export(rank, world)
             except Exception as e:  # pragma: no cover - depends on the node
                 ok, err = False, str(e)
-            handles = [None] * world
-            dist.all_gather_object(handles, handle)
-            if ok and all(h is not None for h in handles):
-                try:
-                    ctx.comm_peer_connect(handles)
-                except Exception as e:  # pragma: no cover
-                    ok, err = False, str(e)
-            else:
-                ok = False
-            ok, why = self_test(ctx, ok)
-            err = err or why
-            if not ok:
-                sys.stderr.write("rank %d: peer transport failed (%s)\n" % (rank, err))
-            if agree(ok):
-                return ctx, "peer"
-            if want == "peer":
-                raise SystemExit("bench.py: the peer transport failed on some rank%s" % ((": " + err) if err else ""))
-            ctx.close()
-            ctx = ctx_factory()
-            transport = "rccl (peer transport self-test failed on some rank%s)" % ((": " + err[:120]) if err else "")
+        handles = [None] * world
+        dist.all_gather_object(handles, handle)
+        if ok and all(h is not None for h in handles):
+            try:
+                ctx.comm_peer_connect(handles)      # hello handshake + the library's own exchange / gather self-test
+            except Exception as e:  # pragma: no cover
+                ok, err = False, str(e)
         else:
-            transport = "rccl"
-        ok = True
+            ok = False
+    elif plane == "rccl":
+        uid = None
+        if rank == 0 and ok:
+            try:
+                uid = pkg.Context.rccl_unique_id()
+            except Exception as e:  # pragma: no cover
+                ok, err = False, str(e)
+        box = [uid]
+        dist.broadcast_object_list(box, src=0)
+        ok = ok and box[0] is not None
+        if not agree(ok):             # nobody enters ncclCommInitRank unless everybody does (it blocks until all ranks arrive)
+            return bail()
         try:
-            D.attach_rccl(ctx, rank, world)
-        except Exception as e:  # pragma: no cover - depends on the node
+            ctx.comm_init_rccl(box[0], rank, world)
+        except Exception as e:  # pragma: no cover - e.g. two ranks on one device: RCCL refuses duplicate GPUs
             ok, err = False, str(e)
-        if agree(ok):
-            ok, why = self_test(ctx, True)
-            err = err or why
-            ok = agree(ok)
-        if not ok:
-            sys.stderr.write("rank %d: RCCL transport failed (%s)\n" % (rank, err))
-            raise SystemExit("bench.py: data-plane transport init failed on some rank%s; set SC_BENCH_TRANSPORT=host "
-                             "to run over the host (gloo) transport on purpose" % ((": " + err) if err else ""))
-    return ctx, transport
+    else:
+        ar, ag = D.torch_collectives()
+        ctx.comm_init_host(rank, world, ar, ag)
+    if not agree(ok):
+        return bail()
+    # a small sharded proof; every rank must produce the same transcript
+    mine, why = None, ""
+    try:
+        mm, syn = pkg.matrix_multiplication, pkg.synthetic
+        start, length = D.shard_range(16, rank, world)
+        a, b = syn.tables(ctx, length.bit_length() - 1, start=start)
+        g = mm.G(a, b)
+        dist.barrier()
+        c1, evals, ch = mm.prove(ctx, g, syn.SEED_R)
+        problem = check_identities(ctx.field, c1, evals, ch, g.evaluate([int(x) for x in ch]))
+        if problem:
+            raise RuntimeError("sharded self-test: " + problem)
+        mine = (c1, evals.tobytes())
+    except Exception as e:  # pragma: no cover - depends on the node
+        why = str(e)
+    seen = [None] * world
+    dist.all_gather_object(seen, (mine, why))
+    if any(s[0] is None for s in seen) or any(s[0] != seen[0][0] for s in seen):
+        return False, next((s[1] for s in seen if s[1]), "ranks disagree on the self-test transcript")
+    return True, ""
+
+
+def planes_to_time(world):
+    """data planes a run times.  N > 1: BOTH in-library planes by default - the in-kernel peer exchange and RCCL (the
+    all-reduce per pass BASELINE.json names) - each in its own timed region of exactly K steps; the headline is the
+    faster one and config.transports carries both.  SC_BENCH_TRANSPORT=peer|rccl|host restricts the run to one."""
+    want = os.environ.get("SC_BENCH_TRANSPORT", "")
+    if world == 1:
+        if os.environ.get("SC_BENCH_FORCE_RCCL") == "1" or want in ("rccl", "peer"):
+            return [want or "rccl"]     # diagnostic: the sharded code path with one rank on a single-GPU box
+        return ["none"]
+    if want:
+        if want not in ("peer", "rccl", "host"):
+            raise SystemExit("SC_BENCH_TRANSPORT must be peer, rccl or host")
+        return [want]
+    return ["peer", "rccl"]
 
 
 def cpu_sample_size(requested):
@@ -239,31 +233,40 @@ def context_options():
     return out
 
 
-def run_prover(args, pkg, torch, dist, rank, world, local_rank):
-    import numpy as np
+def time_plane(args, pkg, torch, dist, rank, world, local_rank, plane, n):
+    """One data plane end to end: context, this rank's shards, exactly W untimed and K timed proofs (barrier +
+    synchronize on both sides, max over ranks), the verifier-identity gate on the last transcript.  Returns a dict;
+    {"ok": False, "error": ...} when the plane could not be set up on every rank."""
     mm, D, syn = pkg.matrix_multiplication, pkg.distributed, pkg.synthetic
-    n = args.num_vars if args.num_vars > 0 else 28
     F = pkg.Field(pkg.GOLDILOCKS)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    def make_ctx():
-        c = pkg.Context(F, device=local_rank)
-        c.set_option("vars_per_pass", args.vars_per_pass)
-        for k, v in context_options():
-            c.set_option(k, v)
-        return c
-
-    ctx, transport = setup_transport(args, pkg, make_ctx, rank, world, dist)
+    ctx = pkg.Context(F, device=local_rank)
+    ctx.set_option("vars_per_pass", args.vars_per_pass)
+    for k, v in context_options():
+        ctx.set_option(k, v)
+    label = plane
+    if plane != "none":
+        if world == 1:
+            (D.attach_peer if plane == "peer" else D.attach_rccl)(ctx, 0, 1)
+            label = "%s(world=1, diagnostic)" % plane
+        else:
+            ok, why = attach_plane(plane, pkg, ctx, rank, world, dist)
+            if not ok:
+                ctx.close()
+                return {"ok": False, "plane": plane, "error": why[:300]}
+    comm_nranks = ctx.get_option("comm_nranks")
     start, length = D.shard_range(n, rank, world)
     nl = length.bit_length() - 1
     a, b = syn.tables(ctx, nl, start=start)
     g = mm.G(a, b)
     assert g.num_vars() == n
 
-    for _ in range(args.warmup):          # exactly W untimed steps
+    barrier()                                 # the ranks enter every proof together (peer_spin_ms bounds their skew)
+    for _ in range(args.warmup):              # exactly W untimed steps
         mm.prove(ctx, g, syn.SEED_R)
 
     # HIP events around every kernel (on the library's stream) on every fourth timed step: the event
@@ -297,11 +300,52 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- correctness gates (outside the timed region) --------------------------------------
+    # ---- correctness gate (outside the timed region) ----------------------------------------
     final_eval = g.evaluate([int(x) for x in ch])
     problem = check_identities(F, c1, evals, ch, final_eval)
     if problem:
-        raise SystemExit("PARITY FAILURE at n=%d: %s" % (n, problem))
+        raise SystemExit("PARITY FAILURE at n=%d (%s): %s" % (n, label, problem))
+    return {"ok": True, "plane": plane, "label": label, "ctx": ctx, "tables": (a, b, g), "elapsed": elapsed, "step_ms": step_ms,
+            "n_launch": n_launch, "kernel_ms": kernel_ms, "log": log, "steps_with_events": steps_with_events,
+            "timed_every": timed_every, "comm_nranks": comm_nranks, "transcript": (c1, evals.tobytes())}
+
+
+def run_prover(args, pkg, torch, dist, rank, world, local_rank):
+    import numpy as np
+    mm, syn = pkg.matrix_multiplication, pkg.synthetic
+    n = args.num_vars if args.num_vars > 0 else 28
+    F = pkg.Field(pkg.GOLDILOCKS)
+
+    runs, failed = [], {}
+    for plane in planes_to_time(world):
+        r = time_plane(args, pkg, torch, dist, rank, world, local_rank, plane, n)
+        if not r["ok"]:
+            failed[plane] = r["error"]
+            if rank == 0:
+                sys.stderr.write("bench.py: data plane '%s' is not usable here: %s\n" % (plane, r["error"]))
+            continue
+        if runs:                      # one plane's tables at a time in HBM
+            if r["transcript"] != runs[0]["transcript"]:
+                raise SystemExit("PARITY FAILURE: the %s and %s data planes produced different transcripts" % (runs[0]["plane"], plane))
+            if r["elapsed"] < runs[0]["elapsed"]:
+                runs[0], r = r, runs[0]
+            r.pop("tables")
+            r.pop("ctx").close()
+        runs.append(r)
+    if not runs:
+        # a scaling run must never silently measure something else: no in-library data plane, no line
+        raise SystemExit("bench.py: no data-plane transport could be set up on every rank (%s); set SC_BENCH_TRANSPORT=host "
+                         "to run over the host (gloo) transport on purpose" % "; ".join("%s: %s" % kv for kv in failed.items()))
+    best = runs[0]
+    ctx = best["ctx"]
+    a, b, g = best.pop("tables")
+    elapsed, step_ms, log = best["elapsed"], best["step_ms"], best["log"]
+    n_launch, kernel_ms, steps_with_events, timed_every = best["n_launch"], best["kernel_ms"], best["steps_with_events"], best["timed_every"]
+    transport = best["label"]
+    transports = {r["plane"]: {"ms_per_step": r["elapsed"] / args.steps * 1e3, "ms_per_step_median": statistics.median(r["step_ms"]),
+                               "comm_nranks": r["comm_nranks"]} for r in runs}
+    for plane, why in failed.items():
+        transports[plane] = {"ms_per_step": None, "error": why}
 
     muladds = 5 * 2**n - 7
     alg_bytes = 64 * 2**n - 96
@@ -359,10 +403,13 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                 "algorithmic_bytes_per_step": alg_bytes,
                 "vars_per_pass": args.vars_per_pass,
                 "first_pass_vars": first_pass,
-                "tail_pass_vars": ctx.get_option("tail_pass_vars"),
                 "parallelism": "hypercube-shard x%d" % world,
-                "parity_gate": "verifier identities at n=%d ok" % n,
-                "transport": transport, "options": dict(context_options()), "schedule": schedule,
+                "parity_gate": "verifier identities at n=%d ok" % n + ("; every timed data plane gave the same transcript" if len(runs) > 1 else ""),
+                "transport": transport,
+                # every data plane this run timed (its own barrier-bracketed region of exactly `steps` proofs; the headline is
+                # the fastest); comm_nranks = the ranks the plane spans as the transport reports it (ncclCommCount for RCCL)
+                "transports": transports,
+                "options": dict(context_options()), "schedule": schedule,
                 "ms_per_step_median_unsampled": statistics.median(unsampled) if unsampled else None,
             },
             "roofline": {
@@ -375,6 +422,7 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                 "traffic": traffic,
                 "bytes_per_launch": dom["bytes_per_launch"] if dom else None,
                 "avg_launch_us": dom["avg_us"] if dom else None,
+                "per_gpu": True,
                 "step": {
                     "bytes_moved": moved,
                     "kernel_ms": kernel_ms_per_step,
@@ -389,8 +437,9 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                 "kernels": [{k: v for k, v in kk.items() if k != "_key"} for kk in kernels],
                 "steps_sampled": steps_with_events,
                 "note": "achieved/frac: the dominant kernel's HBM bytes per launch (inputs read once + outputs written "
-                        "once, from the launch log of this run) / its mean HIP-event duration. step.*: all launches of "
-                        "a proof. sec8d_credited_frac divides SURVEY 8d's one-round-per-pass byte model (64*2^n-96) by "
+                        "once, from the launch log of this run) / its mean HIP-event duration, on ONE GPU (rank 0's launches over "
+                        "its own shard: a per-GPU fraction of the per-GPU peak). step.*: all launches of "
+                        "a proof on that GPU. sec8d_credited_frac divides SURVEY 8d's one-round-per-pass byte model (64*2^n-96) by "
                         "kernel time; the multi-round schedule moves fewer bytes, so that figure can exceed 1 and is "
                         "not a roofline fraction.",
             },
@@ -577,6 +626,25 @@ def run_mle(args, pkg, torch, dist, rank, world, local_rank):
     return result
 
 
+def self_launch(n_ranks):
+    """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run ... bench.py <same flags>` as a
+    child process (one rank per GPU), relay its stdout and return its exit code"""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("OMP_NUM_THREADS", "1")      # what the launcher would set itself, without its warning on stderr
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    for line in proc.stdout:                    # stderr is inherited
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    return proc.wait()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -590,6 +658,12 @@ def main():
     ap.add_argument("--vars-per-pass", type=int, default=2)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # plain `python bench.py --gpus N`: start the N rank processes ourselves.  This process has not touched the GPU
+        # (torch is not even imported yet) and never will: the ranks run in a CHILD launcher, whose stdout (rank 0's one
+        # JSON line) and exit code are relayed.
+        return self_launch(args.gpus)
+
     import torch
     import __graft_entry__ as ge
 
@@ -597,7 +671,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch N>1 with torch.distributed.run" % (args.gpus, world))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if os.environ.get("SC_BENCH_SINGLE_DEVICE") == "1":
@@ -621,4 +695,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -81,33 +81,33 @@ const char* sc_last_error(const sc_ctx* ctx);
  *   "first_pass_vars"  rounds served by the prover's first pass, which has nothing to fold:
  *                      1 | 2 | 3, default 0 = three for tables of >= 2^18 entries, two below
  *                      (never more than vars_per_pass allows)
- *   "tail_pass_vars"   rounds served by a folding pass whose input has <= 2^"tail_pass_log"
- *                      (default 19) entries, where every pass is latency-bound: 3 (default) | 2
  *   "grid_pass"        the passes whose FOLDED tables have <= 2^"grid_log" (default 20) entries serve up to
  *                      "grid_max_vars" (default 5) rounds each and fold up to five pending challenges at once
- *                      (wgrid_pass_kernel, unsharded passes only).  "grid_vars5_log" / "grid_vars4_log" bound the
- *                      folded size that gets five / four rounds (default: no bound below grid_log); "grid_blocks"
- *                      caps the launch (0 = what is resident).  1 (default) | 0.  Not used with "vars_per_pass" 1,
- *                      "tail_pass_vars" 2, an explicit "first_pass_vars" for the first pass, or "resident" - those
- *                      name their own schedules.  "grid_sharded" (1): on the peer transport the shards of a sharded
- *                      prover go on with these passes too (cells exchanged inside the kernel) until they are down to their
- *                      pending challenges; one small launch then serves the rounds of the rank bits (no gather).  "mid_pass" (1): the three-round tail passes outside this planner
- *                      (sharded ones) run grid_pass3_kernel instead of small_pass3_kernel.
- *   "tail_log"         shard log-size at which a sharded prover gathers (default 16)
+ *                      (wgrid_pass_kernel); "grid_blocks" caps the launch (0 = what fits on the chip at once).
+ *                      1 (default) | 0 = two rounds per pass all the way down.  Not used with "vars_per_pass" 1
+ *                      or, for the first pass, an explicit "first_pass_vars" - those name their own schedules.
+ *                      "grid_sharded" (1): the shards of a sharded prover go on with these passes too (cells
+ *                      exchanged inside the kernel on the peer transport, summed by one collective per pass on
+ *                      the others) until they are down to their pending challenges; on the peer transport one
+ *                      small launch then serves the rounds of the rank bits (no gather).  0: two-round sharded
+ *                      passes, gather at "tail_log".
+ *   "tail_log"         shard log-size at which a sharded prover gathers with "grid_sharded" 0 (default 16)
  *   "max_blocks"       grid cap of the streaming kernels (default 3 per CU = 768); a pass never
- *                      launches more blocks than are resident at once
+ *                      launches more blocks than fit on the chip at once
  *   "use_mailbox"      kernels publish sums to pinned host memory the host spins on (default 1)
- *   "resident"         serve the latency-bound passes of a proof from ONE resident launch whose phases the
- *                      host steers through a pinned command line (default 0: measured equal to launches on
- *                      one GPU); "resident_log": largest table it starts from (default 19);
- *                      "park_ms": it leaves the GPU after this long without a command (default 20);
- *                      "resident_stamps" = 1 records block 0's wall-clock stamps per phase (diagnostic: read
- *                      back with sc_ctx_get_option "resident_stamp_<i>", host think time "resident_host_ns")
  *   "arena_log"        peer transport: a gather arena holds world * 2^arena_log words per table (default 17;
- *                      set before sc_ctx_comm_peer_export); "peer_spin_ms": bound of in-kernel waits for peers (default 30000)
+ *                      set before sc_ctx_comm_peer_export; longer gathers go in chunks)
+ *   "peer_spin_ms"     peer transport: bound of every in-kernel wait for a peer = the largest skew between the
+ *                      ranks' launches of the same pass that is tolerated (default 2000); past it the pass fails
+ *                      with SC_ERR_RCCL on every rank that waited.  "peer_connect_ms" (default 120000): how long
+ *                      sc_ctx_comm_peer_connect waits for every peer's hello (absorbs the start-up lag of a job)
+ *   "dbg_delay_ms" / "dbg_skip_tag"   fault injection for tests: delay every sharded launch of this rank on the
+ *                      host / make its next sharded launch skip an exchange tag (a rank out of step)
  *   "time_kernels"     HIP-event timing of pass kernels (see sc_ctx_kernel_time)
  *   "nt_load_log" / "nt_store_log"  table log-size from which loads / stores are nontemporal */
 int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value);
+/* reads any option back; also read-only: "transport" (0 none, 1 RCCL, 2 host callbacks, 3 peer) and "comm_nranks"
+ * = the number of ranks the data plane spans as the transport itself reports it (ncclCommCount for RCCL) */
 int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* value);
 int sc_ctx_synchronize(sc_ctx* ctx);
 /* the context's hipStream_t (for HIP-event timing by a benchmark harness) */
@@ -122,7 +122,7 @@ int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset);
  * really ran instead of from a model.  Copies min(cap, n) records, stores the number available in
  * *n_out, clears the log if reset.  The log keeps at most 65536 records. */
 #define SC_KIND_PASS 0       /* pass_kernel<kf,ks>: fold kf variables of both tables + grid sums of ks rounds */
-#define SC_KIND_TAIL_PASS 1  /* small_pass3_kernel<kf>: the same for cache-resident tables, ks = 3 */
+/* 1 was a three-round tail kernel that wgrid_pass_kernel replaced (round 3) */
 #define SC_KIND_EVALUATE 2   /* evaluate_kernel: one table, kf = number of variables */
 #define SC_KIND_FOLD 3       /* fold_kernel<kf>: LE fix of kf <= 3 variables of one table */
 #define SC_KIND_FIX_LOW 4    /* fix_low_kernel: LE fix of 8..17 variables in one pass */
@@ -130,7 +130,7 @@ int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset);
 #define SC_KIND_COLDOT 6     /* coldot_kernel (+ sum_rows_kernel): BE multi-variable fix / f_A of G::new */
 #define SC_KIND_GKR 7        /* GKR W pass: fold add/mul/w + round sums */
 #define SC_KIND_MATSQ 8      /* triangle counting: square of the adjacency matrix */
-#define SC_KIND_TAIL_RESIDENT 9 /* resident tail kernel: all remaining rounds of a small instance in one launch */
+/* 9 was the resident prover kernel (removed in round 3: measured equal to launches) */
 #define SC_KIND_GRID_PASS 10 /* wgrid_pass_kernel: fold kf <= 5 variables of tables of <= 2^20 folded entries + the 3^ks cells of ks <= 5 rounds */
 typedef struct sc_launch_record {
   int32_t kind;           /* SC_KIND_* */

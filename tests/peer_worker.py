@@ -1,7 +1,13 @@
-"""One rank of the two-process peer-transport test (launched by torch.distributed.run; both ranks on GPU 0).
-Not collected by pytest."""
+"""One rank of the multi-process peer-transport tests (launched by torch.distributed.run; every rank on GPU 0).
+SC_PEER_WORKER_MODE = parity | faults.  Not collected by pytest.
+
+The library's bound on an in-kernel wait for a peer (peer_spin_ms, default 2 s) is the skew it tolerates between the
+ranks' launches of the same pass; the ranks of a real run call in lockstep.  Here every rank does seconds of oracle
+work of its own between proofs, so each proof starts behind a control-plane barrier - the "all ranks are about to
+launch" handshake a caller owes the library."""
 import os
 import sys
+import time
 
 import numpy as np
 
@@ -10,6 +16,188 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+
+def shard_tables(pkg, ctx, pyref, n, rank, world, seeds=None):
+    D = pkg.distributed
+    sa, sb = seeds or (pyref.SEED_A, pyref.SEED_B)
+    start, length = D.shard_range(n, rank, world)
+    nl = length.bit_length() - 1
+    a = pkg.DenseMultilinearExtension.generate(ctx, sa, nl, start=start)
+    b = pkg.DenseMultilinearExtension.generate(ctx, sb, nl, start=start)
+    return a, b, nl
+
+
+def parity(pkg, dist, pyref, Oracle, rank, world):
+    D = pkg.distributed
+    for p in (pyref.GOLDILOCKS, 389):
+        o = Oracle(p)
+        ctx = pkg.Context(pkg.Field(p), device=0)
+        D.attach_peer(ctx, rank, world)          # default peer_spin_ms: the connect's handshake absorbed the start-up lag
+        assert ctx.rank_world() == (rank, world) and ctx.get_option("comm_nranks") == world and ctx.get_option("transport") == 3
+        # grid_sharded 1: the shards go on with five-round passes (cells exchanged inside the kernel) down to one entry;
+        # 0: two-round passes with the exchange, gather at tail_log, unsharded tail
+        for n, tail_log, gs in [(1, 0, 1), (2, 0, 1), (5, 0, 1), (12, 0, 1), (12, 5, 0), (12, 0, 0), (16, 12, 1), (16, 12, 0), (20, 16, 1),
+                                (20, 16, 0), (22, 16, 1)]:
+            if n < world.bit_length() - 1:
+                continue            # fewer entries than ranks
+            ctx.set_option("tail_log", tail_log)
+            ctx.set_option("grid_sharded", gs)
+            a, b, nl = shard_tables(pkg, ctx, pyref, n, rank, world)
+            g = pkg.matrix_multiplication.G(a, b)
+            assert g.num_vars() == n
+            ctx.set_option("time_kernels", 1)
+            ctx.launch_log(reset=True)
+            dist.barrier()
+            c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+            log = ctx.launch_log(reset=True)
+            ctx.set_option("time_kernels", 0)
+            if gs and nl >= 6:      # the shard's own variables are served five at a time, then one small launch for the rank bits
+                assert [r["kind"] for r in log].count("grid_pass") >= 2 and log[-1]["log_in"] <= 5 + world.bit_length() - 1, log
+            final = g.evaluate([int(x) for x in ch])
+            hs = g.hypercube_sum()
+            e0 = g.round_evals() if nl >= 1 else None
+            oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+            ref = o.prove(oa, ob, ch)
+            assert ref["status"] == 0
+            assert c1 == ref["c_1"], (p, n, tail_log, "c_1")
+            assert np.array_equal(evals, ref["evals"]), (p, n, tail_log, "round polynomials")
+            assert final == ref["final_eval"], (p, n, "evaluate")
+            assert hs == ref["c_1"]
+            if e0 is not None:
+                assert e0 == [int(x) for x in ref["evals"][0]]
+            del a, b, g
+        # ranks fed different challenges must fail loudly (digest in the exchange), on every rank
+        n = 10
+        a, b, nl = shard_tables(pkg, ctx, pyref, n, rank, world)
+        g = pkg.matrix_multiplication.G(a, b)
+        ctx.set_option("tail_log", 0)
+        ctx.set_option("grid_sharded", 1)
+        dist.barrier()
+        try:
+            pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R + (7 if rank == 1 else 0))
+            raise AssertionError("different challenges were accepted")
+        except pkg.SumcheckHipError as e:
+            assert e.code == 5 and "different challenges" in str(e), e
+        dist.barrier()
+        del a, b, g
+        ctx.close()
+    print("PEER-OK rank %d" % rank, flush=True)
+
+
+def faults(pkg, dist, pyref, Oracle, rank, world):
+    D = pkg.distributed
+    scp = pkg.sum_check_protocol
+    p = pyref.GOLDILOCKS
+    o = Oracle(p)
+    F = pkg.Field(p)
+
+    def reference(n, seeds=None):
+        sa, sb = seeds or (pyref.SEED_A, pyref.SEED_B)
+        ch = np.array([o.challenge(pyref.SEED_R, j + 1) for j in range(n)], dtype=np.uint64)
+        return o.prove(o.generate(sa, n), o.generate(sb, n), ch), ch
+
+    # ---- 1. a late rank: every sharded launch of one rank delayed by 1 .. 100 ms -------------------------------------
+    ctx = pkg.Context(F, device=0)
+    D.attach_peer(ctx, rank, world)
+    for n, gs, delay_rank, delay in [(14, 1, 0, 1), (14, 0, world - 1, 7), (18, 1, world - 1, 30), (12, 0, 0, 100), (20, 1, 1 % world, 3)]:
+        ctx.set_option("grid_sharded", gs)
+        ctx.set_option("tail_log", 4)
+        ctx.set_option("dbg_delay_ms", delay if rank == delay_rank else 0)
+        a, b, nl = shard_tables(pkg, ctx, pyref, n, rank, world)
+        g = pkg.matrix_multiplication.G(a, b)
+        ref, ch = reference(n)
+        dist.barrier()
+        t0 = time.perf_counter()
+        c1, evals, chn = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+        took = time.perf_counter() - t0
+        assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]) and np.array_equal(chn, ch), (n, gs, delay)
+        assert g.evaluate([int(x) for x in ch]) == ref["final_eval"]
+        assert took < 10.0, took
+        del a, b, g
+    ctx.set_option("dbg_delay_ms", 0)
+
+    # ---- 2. interleaved sharded provers on one context, gather in between (two-round schedule keeps gathered tables
+    #         alive for several rounds: they must be the prover's own copies, not the arena a later gather reuses) ------
+    ctx.set_option("grid_sharded", 0)
+    ctx.set_option("grid_pass", 0)
+    ctx.set_option("first_pass_vars", 2)
+    ctx.set_option("tail_log", 6)
+    sizes = (9, 11)
+    provers, refs, chs = [], [], []
+    for k, n in enumerate(sizes):
+        a, b, nl = shard_tables(pkg, ctx, pyref, n, rank, world, seeds=(51 + k, 61 + k))
+        g = pkg.matrix_multiplication.G(a, b)
+        ref, ch = reference(n, seeds=(51 + k, 61 + k))
+        refs.append(ref)
+        chs.append(ch)
+        dist.barrier()
+        provers.append((scp.Prover.new(g), g))
+        assert provers[-1][0].c_1() == ref["c_1"]
+    pts = (0, F.one, F.add(F.one, F.one))
+    for j in range(max(sizes)):
+        for k, (pr, g) in enumerate(provers):
+            if j < sizes[k]:
+                dist.barrier()
+                poly = pr.round(int(chs[k][j - 1]) if j else F.one, j)
+                assert [poly.evaluate(x) for x in pts] == [int(x) for x in refs[k]["evals"][j]], (k, j)
+                if j % 3 == 1:   # another sharded collective on the same context between the rounds
+                    assert g.hypercube_sum() == refs[k]["c_1"]
+    del provers
+    dist.barrier()
+    ctx.close()
+
+    # ---- 3. gathers longer than the arena go in chunks --------------------------------------------------------------
+    ctx = pkg.Context(F, device=0)
+    ctx.set_option("arena_log", 6)                 # 64 words per rank and chunk
+    D.attach_peer(ctx, rank, world)
+    ctx.set_option("grid_sharded", 0)
+    ctx.set_option("tail_log", 11)                 # gather 2^11-entry shards: 32 chunks per table
+    n = 11 + world.bit_length() - 1 + 2
+    a, b, nl = shard_tables(pkg, ctx, pyref, n, rank, world)
+    g = pkg.matrix_multiplication.G(a, b)
+    ref, ch = reference(n)
+    dist.barrier()
+    c1, evals, _ = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+    assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+    del a, b, g
+    dist.barrier()
+    ctx.close()
+
+    # ---- 4. a rank out of step (skips an exchange tag): every rank fails with SC_ERR_RCCL within the bound -----------
+    for gs in (1, 0):
+        ctx = pkg.Context(F, device=0)
+        ctx.set_option("peer_spin_ms", 400)
+        D.attach_peer(ctx, rank, world)
+        ctx.set_option("grid_sharded", gs)
+        ctx.set_option("tail_log", 4)
+        n = 14
+        a, b, nl = shard_tables(pkg, ctx, pyref, n, rank, world)
+        g = pkg.matrix_multiplication.G(a, b)
+        ref, ch = reference(n)
+        dist.barrier()
+        c1, evals, _ = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)       # in step: fine
+        assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+        if rank == world - 1:
+            ctx.set_option("dbg_skip_tag", 1)
+        dist.barrier()
+        t0 = time.perf_counter()
+        try:
+            pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+            raise AssertionError("a rank out of step went unnoticed")
+        except pkg.SumcheckHipError as e:
+            assert e.code == 3 and "did not arrive within 400 ms" in str(e), e
+        took = time.perf_counter() - t0
+        assert took < 5.0, took                                                    # bounded, not a hang
+        try:                                                                       # the context is unusable afterwards and says so
+            g.hypercube_sum()
+            raise AssertionError("poisoned context accepted a call")
+        except pkg.SumcheckHipError as e:
+            assert e.code == 5, e
+        dist.barrier()
+        del a, b, g
+        ctx.close()
+    print("FAULTS-OK rank %d" % rank, flush=True)
 
 
 def main():
@@ -22,62 +210,8 @@ def main():
     torch.cuda.set_device(0)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     pkg = ge.load_package()
-    D = pkg.distributed
-    for p in (pyref.GOLDILOCKS, 389):
-        o = Oracle(p)
-        ctx = pkg.Context(pkg.Field(p), device=0)
-        ctx.set_option("peer_spin_ms", 60000)   # a failure detector: generous (a cold box stalls ranks for many seconds)
-        D.attach_peer(ctx, rank, world)
-        assert ctx.rank_world() == (rank, world)
-        # grid_sharded 1: the shards go on with five-round passes (cells exchanged inside the kernel) down to one entry;
-        # 0: two-round passes with the exchange, gather at tail_log, unsharded tail
-        for n, tail_log, gs in [(1, 0, 1), (2, 0, 1), (5, 0, 1), (12, 0, 1), (12, 5, 0), (12, 0, 0), (16, 12, 1), (16, 12, 0), (20, 16, 1),
-                                (20, 16, 0), (22, 16, 1)]:
-            if n < world.bit_length() - 1:
-                continue            # fewer entries than ranks
-            ctx.set_option("tail_log", tail_log)
-            ctx.set_option("grid_sharded", gs)
-            start, length = D.shard_range(n, rank, world)
-            nl = length.bit_length() - 1
-            a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, nl, start=start)
-            b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, nl, start=start)
-            g = pkg.matrix_multiplication.G(a, b)
-            assert g.num_vars() == n
-            ctx.set_option("time_kernels", 1)
-            ctx.launch_log(reset=True)
-            c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
-            log = ctx.launch_log(reset=True)
-            ctx.set_option("time_kernels", 0)
-            if gs and nl >= 6:      # the shard's own variables are served five at a time, then one pass on the gathered table
-                assert [r["kind"] for r in log].count("grid_pass") >= 2 and log[-1]["log_in"] <= 5 + world.bit_length() - 1, log
-            oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
-            ref = o.prove(oa, ob, ch)
-            assert ref["status"] == 0
-            assert c1 == ref["c_1"], (p, n, tail_log, "c_1")
-            assert np.array_equal(evals, ref["evals"]), (p, n, tail_log, "round polynomials")
-            assert g.evaluate([int(x) for x in ch]) == ref["final_eval"], (p, n, "evaluate")
-            assert g.hypercube_sum() == ref["c_1"]
-            if nl >= 1:
-                assert g.round_evals() == [int(x) for x in ref["evals"][0]]
-            del a, b, g
-        # ranks fed different challenges must fail loudly (digest in the exchange), on every rank
-        n = 10
-        start, length = D.shard_range(n, rank, world)
-        nl = length.bit_length() - 1
-        a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, nl, start=start)
-        b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, nl, start=start)
-        g = pkg.matrix_multiplication.G(a, b)
-        ctx.set_option("tail_log", 0)
-        ctx.set_option("grid_sharded", 1)
-        try:
-            pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R + (7 if rank == 1 else 0))
-            raise AssertionError("different challenges were accepted")
-        except pkg.SumcheckHipError as e:
-            assert e.code == 5 and "different challenges" in str(e), e
-        dist.barrier()
-        del a, b, g
-        ctx.close()
-    print("PEER-OK rank %d" % rank, flush=True)
+    mode = os.environ.get("SC_PEER_WORKER_MODE", "parity")
+    (parity if mode == "parity" else faults)(pkg, dist, pyref, Oracle, rank, world)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -52,8 +52,9 @@ def test_launch_log_records_what_ran():
 def test_options_round_trip_and_validation():
     pkg = load_package()
     ctx = pkg.Context(pkg.Field(GOLD))
-    for key, good, bad in [("resident", 1, None), ("resident_log", 21, 99), ("park_ms", 5, 0), ("arena_log", 12, 2),
-                           ("peer_spin_ms", 100, 0), ("tail_log", 14, -1), ("vars_per_pass", 1, 3)]:
+    for key, good, bad in [("grid_pass", 0, None), ("grid_log", 21, 99), ("grid_max_vars", 3, 0), ("arena_log", 12, 2),
+                           ("peer_spin_ms", 100, 0), ("peer_connect_ms", 5000, 0), ("dbg_delay_ms", 3, -1),
+                           ("tail_log", 14, -1), ("vars_per_pass", 1, 3)]:
         ctx.set_option(key, good)
         assert ctx.get_option(key) == good
         if bad is not None:

@@ -51,10 +51,9 @@ def test_default_schedule_uses_grid_passes(pkg, p):
 
 @pytest.mark.parametrize("opts", [
     {"grid_max_vars": 1}, {"grid_max_vars": 2}, {"grid_max_vars": 3}, {"grid_max_vars": 4},
-    {"grid_log": 3}, {"grid_log": 8, "grid_vars5_log": 8, "grid_vars4_log": 8}, {"grid_log": 14, "grid_vars5_log": 11, "grid_vars4_log": 14},
-    {"grid_vars5_log": 14}, {"grid_vars5_log": 0, "grid_vars4_log": 0}, {"grid_log": 26},
-    {"grid_blocks": 1}, {"grid_blocks": 3}, {"grid_blocks": 33}, {"grid_blocks": 70, "grid_vars5_log": 13},
-    {"grid_pass": 0}, {"mid_pass": 0}, {"grid_pass": 0, "mid_pass": 0},
+    {"grid_log": 3}, {"grid_log": 8}, {"grid_log": 14, "grid_max_vars": 4}, {"grid_log": 26},
+    {"grid_blocks": 1}, {"grid_blocks": 3}, {"grid_blocks": 33}, {"grid_blocks": 70, "grid_max_vars": 3},
+    {"grid_pass": 0}, {"grid_pass": 0, "first_pass_vars": 2},
 ], ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()))
 def test_every_grid_schedule_matches_the_oracle(pkg, opts):
     for p in (GOLD, 1572869):
@@ -157,10 +156,9 @@ def test_random_schedules(pkg):
     for it in range(48):
         p = rng.choice([GOLD, GOLD, 389, 2**64 - 59])
         ctx = pkg.Context(pkg.Field(p))
-        opts = {"grid_pass": rng.choice([1, 1, 1, 0]), "mid_pass": rng.choice([1, 1, 0]), "grid_log": rng.randrange(0, 23),
-                "grid_max_vars": rng.randrange(1, 6), "grid_vars4_log": rng.randrange(0, 23), "grid_vars5_log": rng.randrange(0, 23),
+        opts = {"grid_pass": rng.choice([1, 1, 1, 0]), "grid_log": rng.randrange(0, 23), "grid_max_vars": rng.randrange(1, 6),
                 "grid_blocks": rng.choice([0, 0, 1, 2, 5, 31, 32, 33, 64, 100, 1024]), "first_pass_vars": rng.choice([0, 0, 1, 2, 3]),
-                "tail_pass_log": rng.choice([10, 19, 21]), "max_blocks": rng.choice([7, 64, 768])}
+                "max_blocks": rng.choice([7, 64, 768])}
         for k, v in opts.items():
             ctx.set_option(k, v)
         o = oracle(p)
@@ -174,7 +172,7 @@ def test_random_schedules(pkg):
 
 def test_option_ranges(pkg):
     ctx = pkg.Context(pkg.Field(GOLD))
-    for k, bad in [("grid_log", 27), ("grid_max_vars", 0), ("grid_max_vars", 6), ("grid_vars4_log", 27), ("grid_vars5_log", -1),
+    for k, bad in [("grid_log", 27), ("grid_max_vars", 0), ("grid_max_vars", 6),
                    ("grid_blocks", -1), ("grid_blocks", 1025)]:
         with pytest.raises(Exception):
             ctx.set_option(k, bad)

@@ -31,8 +31,7 @@ class ScLaunchRecord(ctypes.Structure):
                 ("bytes_read", u64), ("bytes_written", u64), ("ms", ctypes.c_double)]
 
 
-KIND_NAMES = {0: "pass", 1: "tail_pass", 2: "evaluate", 3: "fold", 4: "fix_low", 5: "fold_be", 6: "coldot", 7: "gkr",
-              8: "matsq", 9: "tail_resident", 10: "grid_pass"}
+KIND_NAMES = {0: "pass", 2: "evaluate", 3: "fold", 4: "fix_low", 5: "fold_be", 6: "coldot", 7: "gkr", 8: "matsq", 10: "grid_pass"}
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, voidp, u64p, size_t)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, voidp, u64p, u64p, size_t)

@@ -283,7 +283,9 @@ constexpr int kInboxWords = 64 + 512; // 64 for the passes with up to 27 cells (
 constexpr int kInboxWide = 64;       // first granule of the wide part: 2 x 243 limbs of a five-round pass
 constexpr int kInboxDigest = 56;     // granule index of the challenge digest
 constexpr int kInboxGather = 57;     // granule index of the table-gather flag
-constexpr int kXchgTimeout = 1, kXchgDigest = 2;
+// failure codes of an exchange (mailbox word kMailboxErr): a timeout carries the source rank it waited for in bits 8..15
+// and outranks a digest mismatch wherever codes are combined with max()
+constexpr int kXchgDigest = 2, kXchgTimeout = 0x40000000;
 struct PeerX {
   u64* inbox[kMaxPeers] = {};   // inbox[q]: rank q's inbox as this process maps it (q == rank: the local one)
   int world = 0;                // 0: no in-kernel exchange
@@ -350,7 +352,7 @@ __device__ __forceinline__ void exchange_and_publish(const PassOut& o, u64* xl) 
           }
           if ((++spins & 31) == 0 && wall_clock64() - t0 > px.spin_ticks) {
             // diagnosis for the host's message: which source, and the tag its slot still held
-            err = kXchgTimeout | (r << 8) | ((int)((g >> 32) & 0xFFFF) << 16);
+            err = kXchgTimeout | (r << 8) | ((int)((g >> 32) & 0x3FFF) << 16);
             break;
           }
           __builtin_amdgcn_s_sleep(1);
@@ -699,95 +701,13 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
 }
 
 // ------------------------------------------------------------------------------------
-// Three rounds per pass for SMALL tables (<= 2^19 entries, cache-resident): the tail of a proof
-// is a chain of latency-bound passes (launch + one tile + hand-off, ~15 us each whatever the
-// size), so serving three rounds instead of two per pass cuts a third of them.  Bandwidth does
-// not matter here, latency does: every thread folds ONE output per table (2^KF inputs, one
-// round of loads), leaves it in LDS, and one thread in eight then accumulates the 27-cell grid
-// of its octet.  Same arithmetic as pass_kernel<KF, 3> would do.
-template <class F, int KF>
-__global__ void __launch_bounds__(kBlock)
-small_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
-                   u64* __restrict__ B2, FoldW fw, size_t n_out, PassOut out) {
-  static_assert(KF >= 1 && KF <= 3, "pending variables folded by a tail pass");
-  constexpr int G = 1 << KF, NS = 27;
-  __shared__ u64 la[kBlock], lb[kBlock];
-  __shared__ typename F::Acc lacc[NS * (kBlock / 8)];
-  __shared__ u64 lsum[NS];
-  __shared__ int lds_flag;
-  typename F::Acc acc[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) f.acc_zero(acc[s]);
-
-  const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(A);
-  const ull2* __restrict__ Bp = reinterpret_cast<const ull2*>(B);
-  for (size_t base = (size_t)blockIdx.x * kBlock; base < n_out; base += (size_t)gridDim.x * kBlock) {
-    const size_t i = base + threadIdx.x;
-    u64 ta = 0, tb = 0;
-    if (i < n_out) {
-      ull2 pa[G / 2], pb[G / 2];
-#pragma unroll
-      for (int m = 0; m < G / 2; ++m) {
-        pa[m] = Ap[i * (G / 2) + m];
-        pb[m] = Bp[i * (G / 2) + m];
-      }
-      u64 va[G], vb[G];
-#pragma unroll
-      for (int m = 0; m < G / 2; ++m) {
-        va[2 * m] = pa[m].x; va[2 * m + 1] = pa[m].y;
-        vb[2 * m] = pb[m].x; vb[2 * m + 1] = pb[m].y;
-      }
-      fold_run<F, KF, G>(f, va, fw);
-      fold_run<F, KF, G>(f, vb, fw);
-      ta = va[0];
-      tb = vb[0];
-      A2[i] = ta;
-      B2[i] = tb;
-    }
-    la[threadIdx.x] = ta;
-    lb[threadIdx.x] = tb;
-    __syncthreads();
-    if (threadIdx.x < kBlock / 8 && base + 8 * threadIdx.x < n_out) {
-      u64 a[8], b[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        a[k] = la[8 * threadIdx.x + k];
-        b[k] = lb[8 * threadIdx.x + k];
-      }
-      accumulate_octet<F>(f, acc, a, b);
-    }
-    __syncthreads();
-  }
-
-  // Only the kBlock/8 = 32 accumulating threads (half of wave 0) hold anything.  Reducing 27
-  // sums across them with shuffles on one wave would cost ~5 us of issue time; instead the raw
-  // accumulators go through LDS and all 256 threads share the 27 x 32 reductions-to-residue,
-  // then each group of 32 consecutive threads sums one cell.
-  constexpr int kOct = kBlock / 8;
-  if (threadIdx.x < kOct) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) lacc[s * kOct + threadIdx.x] = acc[s];
-  }
-  __syncthreads();
-  for (int idx = threadIdx.x; idx < NS * kOct; idx += kBlock) {  // idx = cell * 32 + thread
-    u64 r = f.acc_get(lacc[idx]);
-#pragma unroll
-    for (int off = kOct / 2; off >= 1; off >>= 1) r = f.add(r, shfl_down_u64(r, off));
-    if ((idx & (kOct - 1)) == 0) lsum[idx / kOct] = r;
-  }
-  __syncthreads();
-  const u64 mine = (threadIdx.x < NS) ? lsum[threadIdx.x] : 0;
-  finish_pass<F, NS>(f, out, mine, &lds_flag);
-}
-
-// ------------------------------------------------------------------------------------
 // Up to FIVE rounds per pass on the smaller tables of a proof (folded size <= 2^20 entries).
 //
 // Below ~2^21 entries a pass is latency - launch, one dependent chain of work, hand-off to the host - and not
 // bytes; at 8 GPUs (2^25-entry shards) that is more than a third of the proof.  Two things shorten it: fewer
 // passes (a pass that serves KS rounds accumulates the 3^KS-cell grid in the {0,1,inf} basis; for KS = 4, 5 that is
 // 81 / 243 cells over groups of 16 / 32 folded entries - 5 to 7.6 products per entry, nothing at these sizes) and a
-// shorter dependent chain inside a pass (small_pass3_kernel lets one thread in eight walk all 27 cells of its
+// shorter dependent chain inside a pass (round 1's tail kernel let one thread in eight walk all 27 cells of its
 // octet, ~600 instructions on a wave that issues alone at half rate, tools/valu_rate.hip).
 //
 // Every WAVE works alone.  One wave iteration takes 32 consecutive folded entries of both tables:
@@ -805,12 +725,12 @@ small_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u6
 // ~120 VGPRs and 4 KiB of LDS per wave: four waves per SIMD cover each other's latencies.  KS is a template
 // parameter (constant strides), kf a run-time switch.  End: accumulators -> residues, waves and groups added through
 // LDS, thread c < 3^KS holds cell c of the block.
-//  * wgrid_pass_kernel (unsharded passes): rows of 256 words per block, two ticket levels (groups of 32 blocks,
-//    then the groups; Guideline 16 R1 as in finish_pass), each one round of up to 32 loads per thread; the block
-//    that finishes last resets the counters and publishes the cells as whole residues (no limb split) in the
-//    wide part of the host mailbox, then the sequence word.
-//  * grid_pass3_kernel (KS = 3; sharded tail passes, and unsharded ones when the five-round planner is off):
-//    the 27 cells leave through finish_pass like those of pass_kernel.
+// wgrid_pass_kernel: rows of 256 words per block, two ticket levels (groups of 32 blocks, then the groups;
+// Guideline 16 R1 as in finish_pass), each one round of up to 32 loads per thread; the block that finishes last resets
+// the counters and hands the cells on: as whole residues in the wide part of the host mailbox and then the sequence
+// word (unsharded passes, and sharded ones on a host transport - the host splits and sums the limbs); through the
+// in-kernel exchange (sharded passes on the peer transport, exchange_wide); or as split limbs in device memory for the
+// collective that follows on the stream (sharded passes on RCCL, WgOut::limbs_dev).
 constexpr int kGridChunk = 256;          // words per row of partials (>= 243 cells)
 constexpr int kGridMaxVars = 5;
 constexpr int kGridMaxCells = 243;
@@ -827,6 +747,7 @@ struct WgOut {
   unsigned* tickets; // [0]: groups done; [1 + g]: blocks of group g done; all zero between launches
   u64* mailbox;
   u64 seq;
+  u64* limbs_dev;    // non-null: leave the cells as 2 x 3^KS split limbs here (device memory) and publish nothing
   PeerX px;          // world > 0: a sharded pass - the cells are exchanged with the peers before they are published
 };
 // LDS hand-off between the lanes of ONE wave: a wave's LDS operations execute in order, so all that is needed is
@@ -1130,6 +1051,10 @@ wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
     exchange_wide<cells>(out, total);
     return;
   }
+  if (out.limbs_dev) {   // the stream's next operation (an all-reduce) reads them: kernel-boundary ordering
+    if (tid < cells) write_split(out.limbs_dev, tid, total);
+    return;
+  }
   if (tid < cells) __hip_atomic_store(out.mailbox + kMailboxWide + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   __syncthreads();
   if (tid == 0) __hip_atomic_store(out.mailbox + kMailboxSeq, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1242,396 +1167,6 @@ rank_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64*
   }
 }
 
-template <class F>
-__global__ void __launch_bounds__(kBlock)
-grid_pass3_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
-                  GridW gw, int kf, size_t n_out, PassOut out) {
-  __shared__ int lds_flag;
-  const u64 mine = wgrid_body<F, 3>(f, A, B, A2, B2, gw, kf, n_out);
-  finish_pass<F, 27>(f, out, mine, &lds_flag);
-}
-
-// ------------------------------------------------------------------------------------
-// The resident prover kernel: every pass after the first two of a proof in ONE launch.
-//
-// From the third pass on a proof is a chain of short passes (at n = 28: 2^25, 2^23, 2^21 entries
-// and then six cache-resident ones) whose cost is launch, drain and hand-off latency, not bytes:
-// 11 launches cost ~290 us of kernel time and ~60 us of launch gaps for 7 % of the traffic.  This
-// kernel stays on the chip for all of them.  A PHASE is what a pass was: fold the kf challenges
-// that arrived since the previous phase, write the folded tables, accumulate the 3^ks grid for the
-// next ks rounds, reduce across blocks (ticket), publish to the host mailbox.  Between phases the
-// blocks wait for the host's next command - the challenges the verifier drew for the rounds just
-// served (sum-check-protocol/src/lib.rs:283) - which block 0 reads from pinned host memory and
-// forwards through a device word every other block polls.  Blocks that have no tile in a phase
-// (and, since tables only shrink, in none after it) exit.
-//
-// Hand-off between phases follows cdna_hip_programming.md Guideline 16: folded tables are stored
-// write-through (`sc1`), every storing wave drains (s_waitcnt vmcnt(0)) before the block's ticket;
-// the next phase starts, in every block, with a relaxed poll of the command word, ONE agent-scope
-// acquire, the drain of that invalidate and a workgroup barrier, then plain loads.
-// Every spin is bounded: without a command for `park_ticks` (wall clock, 100 MHz) block 0 PARKS the
-// kernel - it tells the other blocks and the host, everything exits, and the host continues with
-// ordinary launches from the tables the last finished phase left (a caller that takes seconds
-// between rounds must not pin the GPU, and a lost command must not hang it).
-constexpr int kMaxResidentPhases = 16;
-constexpr u64 kCmdPark = 0x8000000000000000ull;   // command sequence word | this bit: "park before this phase" (host abort / timeout)
-constexpr int kMailboxParked = 61;                // host mailbox word: 0, or 1 + the phase the kernel parked before
-constexpr int kCmdWords = 8;                      // one 64-byte line: [0] = sequence, [1..3] = challenges
-struct ResidentPlan {
-  int n_phases;
-  int kf[kMaxResidentPhases], ks[kMaxResidentPhases], log_in[kMaxResidentPhases];
-  int big[kMaxResidentPhases];      // 1: streaming body (wave tiles through LDS), 0: one thread per output
-  int blocks[kMaxResidentPhases];   // blocks with work in the phase (non-increasing)
-};
-struct ResidentCtl {
-  const u64* host_cmd;   // pinned host line the host writes: challenges first, sequence word last
-  u64* dev_cmd;          // device line block 0 forwards it to
-  u64 cmd_base;          // phase p (>= 1) runs on the command with sequence cmd_base + p
-  u64 park_ticks;
-  u64* stamps;           // optional [phases][8] wall-clock stamps of block 0 (diagnostic builds of a run, else null)
-};
-#define SC_STAMP(k) do { if (ctl.stamps && blockIdx.x == 0 && threadIdx.x == 0) ctl.stamps[p * 8 + (k)] = wall_clock64(); } while (0)
-
-__device__ __forceinline__ void st16_sc1(ull2* p, ull2 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory");
-}
-
-// eq weights of the kf challenges of a phase (FoldW is computed on the host for launched passes; a
-// resident phase gets the raw challenges and every block derives the weights itself: 2^kf products)
-template <class F>
-__device__ __forceinline__ FoldW fold_weights_from(const F& f, const u64* r, int kf) {
-  FoldW fw;
-#pragma unroll
-  for (int c = 0; c < 8; ++c) fw.w[c] = 0;
-  fw.w[0] = f.one();
-  // fully unrolled with compile-time indices (a run-time index into fw.w would put it in scratch)
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    if (j < kf) {
-      const u64 rj = r[j], nrj = f.sub(f.one(), r[j]);
-#pragma unroll
-      for (int c = (1 << j) - 1; c >= 0; --c) {
-        const u64 base = fw.w[c];
-        fw.w[c + (1 << j)] = f.mul(base, rj);
-        fw.w[c] = f.mul(base, nrj);
-      }
-    }
-  }
-  return fw;
-}
-
-// finish_pass for a phase of the resident kernel: n_blocks = blocks active in the phase.  Every wave
-// has drained its table stores before the barrier in front of this call.
-template <class F, int NS>
-__device__ __forceinline__ void finish_phase(const F& f, const PassOut& o, int n_blocks, u64 my_res, int* lds_flag) {
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  if (n_blocks == 1) {
-    if (threadIdx.x < NS) publish_value(o, threadIdx.x, my_res);
-    __syncthreads();
-    publish_seq(o);
-    return;
-  }
-  if (threadIdx.x < NS)
-    __hip_atomic_store(o.partials + (size_t)threadIdx.x * o.n_rows + blockIdx.x, my_res, __ATOMIC_RELAXED,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  if (threadIdx.x == 0) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(o.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t - o.ticket_base == (unsigned)n_blocks - 1) ? 1 : 0;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    *lds_flag = last;
-  }
-  __syncthreads();
-  if (!*lds_flag) return;
-  constexpr int kWavesPerBlock = kBlock / kWave;
-  for (int s = wave; s < NS; s += kWavesPerBlock) {
-    const u64* row = o.partials + (size_t)s * o.n_rows;
-    u64 a0 = 0, a1 = 0;
-    int b = lane;
-    for (; b + kWave < n_blocks; b += 2 * kWave) {
-      const u64 x = __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const u64 y = __hip_atomic_load(row + b + kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      a0 = f.add(a0, x);
-      a1 = f.add(a1, y);
-    }
-    if (b < n_blocks) a0 = f.add(a0, __hip_atomic_load(row + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    u64 t = f.add(a0, a1);
-#pragma unroll
-    for (int off = kWave / 2; off >= 1; off >>= 1) t = f.add(t, shfl_down_u64(t, off));
-    if (lane == 0) publish_value(o, s, t);
-  }
-  __syncthreads();
-  publish_seq(o);
-}
-
-// Streaming body of a resident phase: pass_kernel<F,2,2>'s tile loop with plain loads (the phase's
-// acquire is behind us) and write-through stores.  Leaves the block's nine residues in thread s.
-template <class F>
-__device__ __attribute__((noinline)) u64 resident_big22(const F& f, const u64* __restrict__ A, const u64* __restrict__ B,
-                                              u64* __restrict__ A2, u64* __restrict__ B2, const FoldW& fw, size_t n_units,
-                                              int n_blocks, ull2* lds_t /*[4*64*8]*/, u64* lds_r /*[4*9]*/) {
-  constexpr int KF = 2, KS = 2, IN = 16, NP = 8, NPO = 2, NS = 9;
-  constexpr int kWaves = kBlock / kWave;
-  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  ull2* const my_lds = lds_t + wave * kWave * NP;
-  typename F::Acc acc[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) f.acc_zero(acc[s]);
-  const size_t n_tiles = (n_units + kWave - 1) / kWave;
-  const size_t in_pieces = n_units * NP, out_pieces = n_units * NPO;
-  const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(A);
-  const ull2* __restrict__ Bp = reinterpret_cast<const ull2*>(B);
-  ull2* A2p = reinterpret_cast<ull2*>(A2);
-  ull2* B2p = reinterpret_cast<ull2*>(B2);
-  for (size_t tile = (size_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (size_t)n_blocks * kWaves) {
-    ull2 pa[NP], pb[NP];
-    const size_t q0 = tile * kWave * NP;
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      const size_t q = q0 + (size_t)k * kWave + lane;
-      const ull2 zero = {0, 0};
-      pa[k] = (q < in_pieces) ? Ap[q] : zero;
-      pb[k] = (q < in_pieces) ? Bp[q] : zero;
-    }
-    transpose_to_runs<NP>(my_lds, pa, lane);
-    transpose_to_runs<NP>(my_lds, pb, lane);
-    u64 a[IN], b[IN];
-#pragma unroll
-    for (int k = 0; k < NP; ++k) {
-      a[2 * k] = pa[k].x; a[2 * k + 1] = pa[k].y;
-      b[2 * k] = pb[k].x; b[2 * k + 1] = pb[k].y;
-    }
-    fold_run<F, KF, IN>(f, a, fw);
-    fold_run<F, KF, IN>(f, b, fw);
-    ull2 oa[NPO], ob[NPO];
-#pragma unroll
-    for (int m = 0; m < NPO; ++m) {
-      oa[m].x = a[2 * m]; oa[m].y = a[2 * m + 1];
-      ob[m].x = b[2 * m]; ob[m].y = b[2 * m + 1];
-    }
-    transpose_to_pieces<NPO>(my_lds, oa, lane);
-    transpose_to_pieces<NPO>(my_lds, ob, lane);
-    const size_t o0 = tile * kWave * NPO;
-#pragma unroll
-    for (int k = 0; k < NPO; ++k) {
-      const size_t q = o0 + (size_t)k * kWave + lane;
-      if (q < out_pieces) {
-        st16_sc1(A2p + q, oa[k]);
-        st16_sc1(B2p + q, ob[k]);
-      }
-    }
-    accumulate_run<F, KS>(f, acc, a, b);
-  }
-  u64 res[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) res[s] = f.acc_get(acc[s]);
-  block_reduce<F, NS>(f, res, lds_r);
-  return res[0];
-}
-
-// One-thread-per-output body of a resident phase (small_pass3_kernel generalised over KS): each thread
-// folds 2^KF inputs of both tables into one output, stores it write-through and leaves it in LDS; one
-// thread in 2^KS then accumulates the 3^KS grid of its run of outputs; the raw accumulators go through
-// LDS so that all 256 threads share their reduction.  Returns the block's residue of sum s in thread s.
-template <class F, int KF, int KS>
-__device__ __attribute__((noinline)) u64 resident_small(const F& f, const u64* __restrict__ A, const u64* __restrict__ B,
-                                              u64* __restrict__ A2, u64* __restrict__ B2, const FoldW& fw, size_t n_out,
-                                              int n_blocks, u64* la, u64* lb, typename F::Acc* lacc, u64* lsum) {
-  constexpr int G = 1 << KF, RUN = 1 << KS, NS = (KS == 1) ? 3 : (KS == 2) ? 9 : 27;
-  constexpr int kAccThreads = kBlock / RUN;
-  typename F::Acc acc[NS];
-#pragma unroll
-  for (int s = 0; s < NS; ++s) f.acc_zero(acc[s]);
-  const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(A);
-  const ull2* __restrict__ Bp = reinterpret_cast<const ull2*>(B);
-  for (size_t base = (size_t)blockIdx.x * kBlock; base < n_out; base += (size_t)n_blocks * kBlock) {
-    const size_t i = base + threadIdx.x;
-    u64 ta = 0, tb = 0;
-    if (i < n_out) {
-      u64 va[G], vb[G];
-#pragma unroll
-      for (int m = 0; m < G / 2; ++m) {
-        const ull2 pa = Ap[i * (G / 2) + m], pb = Bp[i * (G / 2) + m];
-        va[2 * m] = pa.x; va[2 * m + 1] = pa.y;
-        vb[2 * m] = pb.x; vb[2 * m + 1] = pb.y;
-      }
-      fold_run<F, KF, G>(f, va, fw);
-      fold_run<F, KF, G>(f, vb, fw);
-      ta = va[0];
-      tb = vb[0];
-      __hip_atomic_store(A2 + i, ta, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // 8-byte sc1 store
-      __hip_atomic_store(B2 + i, tb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    la[threadIdx.x] = ta;
-    lb[threadIdx.x] = tb;
-    __syncthreads();
-    if (threadIdx.x < kAccThreads && base + RUN * threadIdx.x < n_out) {
-      u64 a[RUN], b[RUN];
-#pragma unroll
-      for (int k = 0; k < RUN; ++k) {
-        a[k] = la[RUN * threadIdx.x + k];
-        b[k] = lb[RUN * threadIdx.x + k];
-      }
-      if constexpr (KS == 3) accumulate_octet<F>(f, acc, a, b);
-      else accumulate_run<F, KS>(f, acc, a, b);
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x < kAccThreads) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) lacc[s * kAccThreads + threadIdx.x] = acc[s];
-  }
-  __syncthreads();
-  // NS * kAccThreads raw accumulators -> residues by all 256 threads; the kAccThreads partials of a cell
-  // are consecutive, so shuffles sum them inside a wave (W = min(kAccThreads, 64) lanes) and, for
-  // KS = 1 (128 partials per cell), the two half sums meet in LDS
-  constexpr int W = kAccThreads < kWave ? kAccThreads : kWave;
-  constexpr int kParts = kAccThreads / W;
-  for (int idx = threadIdx.x; idx < NS * kAccThreads; idx += kBlock) {
-    u64 r = f.acc_get(lacc[idx]);
-#pragma unroll
-    for (int off = W / 2; off >= 1; off >>= 1) r = f.add(r, shfl_down_u64(r, off));
-    if ((idx & (W - 1)) == 0) la[idx / W] = r;   // la is free again: the tile loop has ended
-  }
-  __syncthreads();
-  if (threadIdx.x < NS) {
-    u64 t = la[threadIdx.x * kParts];
-#pragma unroll
-    for (int w = 1; w < kParts; ++w) t = f.add(t, la[threadIdx.x * kParts + w]);
-    lsum[threadIdx.x] = t;
-  }
-  __syncthreads();
-  return (threadIdx.x < NS) ? lsum[threadIdx.x] : 0;
-}
-
-template <class F>
-__global__ void __launch_bounds__(kBlock, 2)
-resident_kernel(F f, const u64* __restrict__ A0, const u64* __restrict__ B0, u64* PA, u64* PB, u64* QA, u64* QB,
-                FoldW fw0, ResidentPlan plan, PassOut out, ResidentCtl ctl) {
-  constexpr int kWaves = kBlock / kWave;
-  // one LDS array, carved per body (cdna_hip_programming.md: a second __shared__ object can de-pipeline)
-  __shared__ ull2 smem[kWaves * kWave * 8 + 1024];
-  __shared__ u64 lds_cmd[4];
-  __shared__ int lds_flag;
-  ull2* const lds_t = smem;                                          // big body: 4 x 64 x 8 pieces (32 KiB)
-  u64* const lds_r = reinterpret_cast<u64*>(smem + kWaves * kWave * 8);   // 4 x 9 words
-  u64* const la = reinterpret_cast<u64*>(smem);                      // small body: 256 + 256 words,
-  u64* const lb = la + kBlock;                                       //   then 27 x 32 accumulators, 27 sums
-  typename F::Acc* const lacc = reinterpret_cast<typename F::Acc*>(lb + kBlock);
-  u64* const lsum = reinterpret_cast<u64*>(smem + kWaves * kWave * 8 + 512);
-
-  const u64* curA = A0;
-  const u64* curB = B0;
-  unsigned ticket_base = out.ticket_base;
-  FoldW fw = fw0;
-  for (int p = 0; p < plan.n_phases; ++p) {
-    const int n_blocks = plan.blocks[p];
-    if ((int)blockIdx.x >= n_blocks) return;   // no tile in this phase, hence in none after it
-    const int kf = plan.kf[p], ks = plan.ks[p], log_in = plan.log_in[p];
-    SC_STAMP(0);
-    if (p > 0) {
-      // ---- wait for the host's command: the challenges of the rounds the previous phase served ----
-      // The command is ONE 64-byte line {sequence, r0, r1, r2, check = seq ^ r0 ^ r1 ^ r2}: five lanes read
-      // it with one load instruction (one PCIe / L2 round trip) and the check word rejects a torn read.
-      if (threadIdx.x < kWave) {
-        const int lane = threadIdx.x;
-        const u64 want = ctl.cmd_base + (u64)p, park = kCmdPark | want;   // unique per launch AND phase
-        const unsigned long long t0 = wall_clock64();
-        unsigned spins = 0;
-        u64 mine = 0, seq = 0;
-        bool ok = false;
-        if (blockIdx.x == 0) {
-          while (true) {
-            mine = (lane < 5) ? __hip_atomic_load(ctl.host_cmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) : 0;
-            seq = shfl_u64(mine, 0);
-            if (seq == park) break;                       // the host's abort
-            if (seq == want) {
-              const u64 chk = seq ^ shfl_u64(mine, 1) ^ shfl_u64(mine, 2) ^ shfl_u64(mine, 3);
-              if (chk == shfl_u64(mine, 4)) { ok = true; break; }
-            }
-            if ((++spins & 63) == 0 && wall_clock64() - t0 > ctl.park_ticks) { seq = park; break; }
-            __builtin_amdgcn_s_sleep(1);
-          }
-          if (!ok && lane == 0)   // park: tell the host which phase was never started
-            __hip_atomic_store(out.mailbox + kMailboxParked, (u64)p + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-          // forward the line (or the park word) to the other blocks of the phase: one store instruction
-          if (n_blocks > 1 || !ok) {
-            const u64 fwd = ok ? mine : (lane == 0 ? park : (lane == 4 ? park : 0));
-            if (lane < 5) __hip_atomic_store(ctl.dev_cmd + lane, fwd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        } else {
-          while (true) {
-            mine = (lane < 5) ? __hip_atomic_load(ctl.dev_cmd + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
-            seq = shfl_u64(mine, 0);
-            const u64 chk = seq ^ shfl_u64(mine, 1) ^ shfl_u64(mine, 2) ^ shfl_u64(mine, 3);
-            if (chk == shfl_u64(mine, 4)) {
-              if (seq == want) { ok = true; break; }
-              if (seq == park) break;
-            }
-            // block 0 parks first; this bound only covers a block 0 that died
-            if ((++spins & 63) == 0 && wall_clock64() - t0 > 4 * ctl.park_ticks) break;
-            __builtin_amdgcn_s_sleep(2);
-          }
-        }
-        if (lane < 4) lds_cmd[lane] = (lane == 0) ? (ok ? want : park) : mine;
-        if (lane == 0) {
-          SC_STAMP(1);
-          // ONE agent-scope acquire per block: the folded tables other blocks stored write-through in the
-          // previous phase are read with plain loads from here on
-          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-      }
-      __syncthreads();
-      if (lds_cmd[0] != ctl.cmd_base + (u64)p) return;   // parked
-      u64 r[3] = {lds_cmd[1], lds_cmd[2], lds_cmd[3]};
-      fw = fold_weights_from(f, r, kf);
-      __syncthreads();   // lds_cmd is rewritten in the next phase
-    }
-    SC_STAMP(2);
-    u64* const outA = (p & 1) ? QA : PA;
-    u64* const outB = (p & 1) ? QB : PB;
-    PassOut o = out;
-    o.ticket_base = ticket_base;
-    o.seq = out.seq + (u64)p;
-    const size_t n_out = (size_t)1 << (log_in - kf);
-    u64 mine = 0;
-    int ns = (ks == 1) ? 3 : (ks == 2) ? 9 : 27;
-    if (plan.big[p]) {
-      mine = resident_big22<F>(f, curA, curB, outA, outB, fw, n_out >> 2, n_blocks, lds_t, lds_r);
-    } else {
-#define SC_SMALL(KF, KS) mine = resident_small<F, KF, KS>(f, curA, curB, outA, outB, fw, n_out, n_blocks, la, lb, lacc, lsum)
-      switch (kf * 4 + ks) {
-        case 1 * 4 + 1: SC_SMALL(1, 1); break;
-        case 1 * 4 + 2: SC_SMALL(1, 2); break;
-        case 1 * 4 + 3: SC_SMALL(1, 3); break;
-        case 2 * 4 + 1: SC_SMALL(2, 1); break;
-        case 2 * 4 + 2: SC_SMALL(2, 2); break;
-        case 2 * 4 + 3: SC_SMALL(2, 3); break;
-        case 3 * 4 + 1: SC_SMALL(3, 1); break;
-        case 3 * 4 + 2: SC_SMALL(3, 2); break;
-        default: SC_SMALL(3, 3); break;
-      }
-#undef SC_SMALL
-    }
-    SC_STAMP(3);
-    // every wave drains its write-through table stores, then the block signals (Guideline 16, R1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    SC_STAMP(4);
-    if (ns == 3) finish_phase<F, 3>(f, o, n_blocks, mine, &lds_flag);
-    else if (ns == 9) finish_phase<F, 9>(f, o, n_blocks, mine, &lds_flag);
-    else finish_phase<F, 27>(f, o, n_blocks, mine, &lds_flag);
-    SC_STAMP(5);
-    if (n_blocks > 1) ticket_base += (unsigned)n_blocks;
-    curA = outA;
-    curB = outB;
-    __syncthreads();
-  }
-}
 
 // ------------------------------------------------------------------------------------
 // Single-table kernels (DenseMultilinearExtension::fix_variables / evaluate on their own,
@@ -2392,6 +1927,19 @@ peer_gather_kernel(const u64* __restrict__ A, const u64* __restrict__ B, size_t 
   publish_seq(out);
 }
 
+// Connect-time hello of the peer transport: one granule {kHelloTag | rank + 1} into every peer's inbox (parity 0,
+// slot kInboxHello).  The host of each rank polls its own inbox until every peer's hello is there: by then every
+// peer has mapped this rank's region, loaded its code object and run a kernel, so the cold-start lag of a freshly
+// started job (seconds) is absorbed here and the per-pass waits can be bounded tightly (peer_spin_ms).
+constexpr int kInboxHello = 58;
+constexpr unsigned kHelloTag = 0x48454c4fu;
+__global__ void peer_hello_kernel(PeerX px) {
+  const int lane = threadIdx.x;
+  if (lane < px.world)
+    __hip_atomic_store(px.inbox[lane] + (size_t)px.rank * kInboxWords + kInboxHello, ((u64)kHelloTag << 32) | (u64)(px.rank + 1),
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // Cross-rank sum of limbs that a small kernel left in device memory (the degenerate paths that do not end
 // in finish_pass): one workgroup of one wave.
 template <int NS>
@@ -2408,6 +1956,16 @@ sum_limb_rows_kernel(const u64* __restrict__ in, int rows, size_t n, u64* __rest
     for (int r = 0; r < rows; ++r) t += in[(size_t)r * n + i];
     out[i] = t;
   }
+}
+
+// The same for the up to 486 limb totals of a five-round pass: into the wide part of the mailbox (one workgroup).
+__global__ void __launch_bounds__(kBlock)
+mailbox_copy_wide_kernel(const u64* __restrict__ sums, int count, u64* __restrict__ mailbox, u64 seq) {
+  for (int i = threadIdx.x; i < count; i += kBlock)
+    __hip_atomic_store(mailbox + kMailboxWide + i, sums[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every thread's stores have left before the barrier
+  __syncthreads();
+  if (threadIdx.x == 0) __hip_atomic_store(mailbox + kMailboxSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // After a device-side all-reduce: hand the summed limbs to the host mailbox (one wave).

@@ -23,6 +23,7 @@
 #include <map>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/sumcheck_hip.h"
@@ -41,6 +42,7 @@ struct RcclApi {
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t,
                             hipStream_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
@@ -68,6 +70,7 @@ bool load_rccl(std::string* why) {
   a.GetUniqueId = (decltype(a.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   a.CommInitRank = (decltype(a.CommInitRank))dlsym(h, "ncclCommInitRank");
   a.CommDestroy = (decltype(a.CommDestroy))dlsym(h, "ncclCommDestroy");
+  a.CommCount = (decltype(a.CommCount))dlsym(h, "ncclCommCount");
   a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
   a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
@@ -101,18 +104,13 @@ struct sc_ctx {
   // of >= 2^18 entries (it saves an eighth of the traffic of a large proof and a pass of a small
   // one), two below
   int first_pass_vars = 0;
-  // rounds served by a folding pass once its input is small (<= kTailPass3Log): 3, or 2 to keep
-  // two everywhere
-  int tail_pass_vars = 3;
-  int tail_pass_log = 19;  // largest input (log2 entries per table) that takes the three-round tail pass
-  // the passes on the smaller tables (kernels.hpp, wgrid_pass_kernel): up to five rounds each
+  // the passes on the smaller tables (kernels.hpp, wgrid_pass_kernel): up to five rounds each; 0: two rounds per pass
+  // all the way down
   int grid_pass = 1;
   int grid_log = 20;        // largest FOLDED table (log2 entries) they take (measured: 21 costs n = 28 10 us, 19 costs n = 25 18 us)
   int grid_max_vars = 5;    // most rounds one of them serves (1..5)
-  int grid_vars4_log = 26;  // largest folded table that gets four rounds ...
-  int grid_vars5_log = 26;  // ... and five (no limit below grid_log by default: the kernel's cost hardly grows with the rounds)
-  int grid_sharded = 1;     // sharded passes too (peer transport: the cells are exchanged inside the kernel), down to one-entry shards
-  int mid_pass = 1;         // three-round tail passes outside that planner (sharded ones) by grid_pass3_kernel instead of small_pass3_kernel
+  int grid_sharded = 1;     // sharded passes too (cells exchanged inside the kernel on the peer transport, summed by the
+                            // collective on the others), down to shards that hold only their pending challenges
   int wgrid_blocks = 0;     // resident grid of wgrid_pass_kernel (0 = not asked yet)
   int grid_blocks = 0;      // cap on the blocks of such a launch (0 = as many as are resident; tests use it to reach both ticket levels)
   u64* d_wg_partials = nullptr;   // [kWgMaxBlocks][kGridChunk]
@@ -126,7 +124,7 @@ struct sc_ctx {
   int max_blocks = 768;
   int num_cus = 256;
   // blocks of each pass-kernel instantiation that fit on the chip at once ([generic|goldilocks][kf][ks],
-  // 0 = not asked yet); [..][kf][0] with ks = 3, kf > 0 is the tail kernel
+  // 0 = not asked yet)
   int resident_blocks[2][4][4] = {};
   int time_kernels = 0;
   int nt_load_log = 22;   // tables of >= 2^this entries are loaded nontemporal (measured: 21-25 equal, 27 and off worse)
@@ -143,22 +141,6 @@ struct sc_ctx {
   u64* d_mailbox = nullptr;   // device alias of h_mailbox
   u64 mailbox_seq = 0;
   int use_mailbox = 1;
-  // resident prover kernel (kernels.hpp): command line the host writes and the kernel's block 0 polls
-  // (pinned, one 64-byte line), its device-side forward, and the sequence base of the next launch
-  u64* h_cmd = nullptr;
-  u64* d_cmd_host = nullptr;   // device alias of h_cmd
-  u64* d_cmd = nullptr;
-  u64 cmd_seq = 0;
-  int resident = 0;            // option "resident": serve the latency-bound passes from one resident launch
-                               // (off by default: measured equal to launches on one GPU)
-  int resident_log = 19;       // largest input (log2 entries per table) the resident kernel starts from
-  int park_ms = 20;            // the resident kernel parks itself after this long without a command
-  double dbg_host_ns = 0.0;    // diagnostic: host time between a phase's sums and the next command (resident_stamps)
-  std::chrono::steady_clock::time_point dbg_t_collect;
-  int resident_stamps = 0;     // option "resident_stamps": block 0 records wall-clock stamps per phase (diagnostic)
-  int resident_blocks_cap = 0; // blocks of resident_kernel that are resident at once (0 = not asked yet)
-  struct sc_prover* live_resident = nullptr;   // prover whose resident kernel is on the stream
-  bool in_resident_owner = false;
 
   // device-buffer pool (free blocks by capacity in words; live blocks by pointer)
   std::multimap<size_t, u64*> pool_free;
@@ -178,9 +160,19 @@ struct sc_ctx {
   bool peer_exported = false;
   u64* peer_base[sc::kMaxPeers] = {};
   bool peer_ipc_opened[sc::kMaxPeers] = {};
-  int arena_log = 17;          // a gather arena holds world * 2^arena_log words per table
-  unsigned xchg_tag = 0;       // exchange tag of the last sharded pass (the same on every rank)
-  int peer_spin_ms = 30000;    // bound of every in-kernel wait for a peer: a failure detector, so generous (a rank of a freshly started job can lag for seconds)
+  int arena_log = 17;          // a gather arena holds world * 2^arena_log words per table (longer gathers go in chunks)
+  unsigned xchg_tag = 0;       // exchange tag of the last sharded launch that reached the stream (the same on every rank)
+  unsigned xchg_next = 0;      // tag handed to the launch being prepared (fill_peer); committed by commit_peer()
+  unsigned gather_count = 0;   // gathers done: its parity selects the arena (NOT the tag's: passes advance the tag too)
+  // bound of every in-kernel wait for a peer: the skew between the ranks' launches of the same pass.  The cold-start
+  // lag of a freshly started job (seconds: code objects, first launches) is absorbed by the connect-time handshake
+  // (peer_connect_ms), so this can be a real failure detector
+  int peer_spin_ms = 2000;
+  int peer_connect_ms = 120000;   // how long sc_ctx_comm_peer_connect waits for every peer's hello
+  // fault injection (tests): delay every sharded launch of this rank by dbg_delay_ms on the host; dbg_skip_tag = 1
+  // makes the next sharded launch skip a tag (a rank that is out of step with its peers)
+  int dbg_delay_ms = 0;
+  int dbg_skip_tag = 0;
 
   // kernel timing
   // pass-kernel timing (option "time_kernels"): a ring of event pairs, read back only when the
@@ -320,12 +312,7 @@ int new_table(sc_ctx* ctx, size_t len, sc_table** out) {
   return SC_OK;
 }
 
-void resident_retire(sc_ctx* ctx);   // defined with the prover
-
 int set_device(sc_ctx* ctx) {
-  // any other work on this context goes to the stream the resident kernel occupies: end it first (the
-  // prover it belongs to carries on with ordinary launches)
-  if (ctx->live_resident && !ctx->in_resident_owner) resident_retire(ctx);
   if (ctx->poisoned)
     return fail(ctx, SC_ERR_STATE, "context is unusable after an earlier HIP failure (%s); destroy it", ctx->err.c_str());
   SC_HIP(ctx, hipSetDevice(ctx->device));
@@ -459,25 +446,17 @@ template <class F>
 int pass_resident_blocks_t(sc_ctx* ctx, int kf, int ks) {
   const void* fn = nullptr;
 #define SC_FN(KF, KS) fn = reinterpret_cast<const void*>(&sc::pass_kernel<F, KF, KS, 1>)
-  if (ks == 3 && kf > 0 && ctx->mid_pass) {
-    fn = reinterpret_cast<const void*>(&sc::grid_pass3_kernel<F>);
-  } else if (ks == 3 && kf > 0) {
-    if (kf == 1) fn = reinterpret_cast<const void*>(&sc::small_pass3_kernel<F, 1>);
-    else if (kf == 2) fn = reinterpret_cast<const void*>(&sc::small_pass3_kernel<F, 2>);
-    else fn = reinterpret_cast<const void*>(&sc::small_pass3_kernel<F, 3>);
-  } else {
-    switch (kf * 4 + ks) {
-      case 0 * 4 + 1: SC_FN(0, 1); break;
-      case 0 * 4 + 2: SC_FN(0, 2); break;
-      case 0 * 4 + 3: SC_FN(0, 3); break;
-      case 1 * 4 + 1: SC_FN(1, 1); break;
-      case 1 * 4 + 2: SC_FN(1, 2); break;
-      case 2 * 4 + 1: SC_FN(2, 1); break;
-      case 2 * 4 + 2: SC_FN(2, 2); break;
-      case 3 * 4 + 1: SC_FN(3, 1); break;
-      case 3 * 4 + 2: SC_FN(3, 2); break;
-      default: break;
-    }
+  switch (kf * 4 + ks) {
+    case 0 * 4 + 1: SC_FN(0, 1); break;
+    case 0 * 4 + 2: SC_FN(0, 2); break;
+    case 0 * 4 + 3: SC_FN(0, 3); break;
+    case 1 * 4 + 1: SC_FN(1, 1); break;
+    case 1 * 4 + 2: SC_FN(1, 2); break;
+    case 2 * 4 + 1: SC_FN(2, 1); break;
+    case 2 * 4 + 2: SC_FN(2, 2); break;
+    case 3 * 4 + 1: SC_FN(3, 1); break;
+    case 3 * 4 + 2: SC_FN(3, 2); break;
+    default: break;
   }
 #undef SC_FN
   int per_cu = 0;
@@ -490,7 +469,7 @@ int pass_resident_blocks_t(sc_ctx* ctx, int kf, int ks) {
 
 int pass_resident_blocks(sc_ctx* ctx, int kf, int ks) {
   const int fi = ctx->gold ? 1 : 0;
-  int& slot = ctx->resident_blocks[fi][kf][(ks == 3 && kf > 0) ? 0 : ks];
+  int& slot = ctx->resident_blocks[fi][kf][ks];
   if (slot == 0) {
     int v = 0;
     SC_DISPATCH_FIELD(ctx, F, f, { (void)f; v = pass_resident_blocks_t<F>(ctx, kf, ks); });
@@ -516,21 +495,6 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
     else                                                                                                           \
       hipLaunchKernelGGL((sc::pass_kernel<F, KF, KS, 0>), g, b, 0, s, f, A, B, A2, B2, fw, n_units, out);          \
   } while (0)
-  if (ks == 3 && kf > 0 && ctx->mid_pass) {  // tail pass by the grid-pass body (kernels.hpp, grid_pass3_kernel)
-    sc::GridW gw;
-    for (int c = 0; c < (1 << sc::kGridMaxVars); ++c) gw.w[c] = c < 8 ? fw.w[c] : 0;
-    hipLaunchKernelGGL((sc::grid_pass3_kernel<F>), g, b, 0, s, f, A, B, A2, B2, gw, kf, n_units * 8, out);
-    return;
-  }
-  if (ks == 3 && kf > 0) {  // tail pass: one thread per output (kernels.hpp, small_pass3_kernel)
-    const size_t n_out = n_units * 8;
-    switch (kf) {
-      case 1: hipLaunchKernelGGL((sc::small_pass3_kernel<F, 1>), g, b, 0, s, f, A, B, A2, B2, fw, n_out, out); break;
-      case 2: hipLaunchKernelGGL((sc::small_pass3_kernel<F, 2>), g, b, 0, s, f, A, B, A2, B2, fw, n_out, out); break;
-      default: hipLaunchKernelGGL((sc::small_pass3_kernel<F, 3>), g, b, 0, s, f, A, B, A2, B2, fw, n_out, out); break;
-    }
-    return;
-  }
   switch (kf * 4 + ks) {
     case 0 * 4 + 1: SC_PASS(0, 1); break;
     case 0 * 4 + 2: SC_PASS(0, 2); break;
@@ -547,6 +511,10 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
 }
 
 constexpr size_t kInboxRegionWords = 2 * (size_t)sc::kMaxPeers * sc::kInboxWords;   // two parities
+// a rank's exported region: [inbox (two parities) | header | two gather arenas of two tables].  The header lets a peer
+// check, when it maps the region, that both sides compute the same offsets: {magic, world, rank, arena_log}
+constexpr size_t kPeerHeaderWords = 8;
+constexpr u64 kPeerMagic = 0x7363706565723033ull;   // "scpeer03"
 
 // 32-bit digest of what a sharded pass folds: identical on every rank unless the ranks were fed
 // different challenges (FNV-1a over the words)
@@ -563,17 +531,28 @@ unsigned challenge_digest(const u64* r, int kf, int ks, int log_in) {
   return (unsigned)(h ^ (h >> 32));
 }
 
-// Exchange fields of a sharded launch on the peer transport.  The tag advances with every such launch,
-// in the same order on every rank.
+// Exchange fields of a sharded launch on the peer transport.  The tag advances with every such launch, in the
+// same order on every rank - but only once the launch is known to be in the stream (commit_peer): a launch that
+// failed locally must not leave this rank one tag ahead of its peers.
 void fill_peer(sc_ctx* ctx, sc::PeerX& px, unsigned digest) {
   for (int q = 0; q < ctx->world; ++q) px.inbox[q] = ctx->peer_base[q];
   px.world = ctx->world;
   px.rank = ctx->rank;
-  ctx->xchg_tag += 1;
-  if (ctx->xchg_tag == 0) ctx->xchg_tag = 1;
-  px.tag = ctx->xchg_tag;
+  unsigned tag = ctx->xchg_tag + 1;
+  if (ctx->dbg_skip_tag) {   // fault injection: this rank falls out of step
+    tag += 1;
+    ctx->dbg_skip_tag = 0;
+  }
+  if (tag == 0) tag = 1;
+  ctx->xchg_next = tag;
+  px.tag = tag;
   px.digest = digest;
-  px.spin_ticks = (u64)ctx->peer_spin_ms * 100000ull;
+  px.spin_ticks = (u64)ctx->peer_spin_ms * 100000ull;   // wall_clock64 runs at 100 MHz
+  if (ctx->dbg_delay_ms > 0) std::this_thread::sleep_for(std::chrono::milliseconds(ctx->dbg_delay_ms));   // fault injection: a late rank
+}
+inline void commit_peer(sc_ctx* ctx) {
+  if (ctx->xchg_next) ctx->xchg_tag = ctx->xchg_next;
+  ctx->xchg_next = 0;
 }
 
 // Launch one pass over tables of 2^log_in entries.  The 2*NS split limbs end up in the
@@ -581,11 +560,11 @@ void fill_peer(sc_ctx* ctx, sc::PeerX& px, unsigned digest) {
 // still have to be all-reduced on the device (RCCL transport).
 int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, const u64* r,
                 int log_in, bool across_ranks, bool* from_mailbox) {
-  if (kf < 0 || kf > 3 || ks < 1 || ks > 3 || log_in < kf + ks)
+  if (kf < 0 || kf > 3 || ks < 1 || ks > 3 || (ks == 3 && kf != 0) || log_in < kf + ks)
     return fail(ctx, SC_ERR_ARG, "launch_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
   const sc::FoldW fw = make_fold_weights(ctx, r, kf);
   size_t n_units = (size_t)1 << (log_in - kf - ks);
-  int grid = grid_for(ctx, (ks == 3 && kf > 0) ? n_units * 8 : n_units);
+  int grid = grid_for(ctx, n_units);
   grid = std::min(grid, pass_resident_blocks(ctx, kf, ks));
   const bool peer = across_ranks && ctx->transport == Transport::kPeer;
   const bool mailbox = (ctx->use_mailbox || peer) && !(across_ranks && ctx->transport == Transport::kRccl);
@@ -598,12 +577,12 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
   out.seq = mailbox ? ctx->mailbox_seq + 1 : 0;
   if (peer) fill_peer(ctx, out.px, challenge_digest(r, kf, ks, log_in));
-  SC_TRY(timer_begin(ctx, (ks == 3 && kf > 0) ? SC_KIND_TAIL_PASS : SC_KIND_PASS, kf, ks, log_in, (u64)16 << log_in,
-                     kf > 0 ? (u64)16 << (log_in - kf) : 0));
+  SC_TRY(timer_begin(ctx, SC_KIND_PASS, kf, ks, log_in, (u64)16 << log_in, kf > 0 ? (u64)16 << (log_in - kf) : 0));
   SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, fw, n_units, grid, log_in, out));
   SC_HIP(ctx, hipGetLastError());
-  // the launch is in the stream: only now do the ticket base and the mailbox sequence move (a failed
-  // launch must leave them where the device-side counter still is)
+  // the launch is in the stream: only now do the ticket base, the mailbox sequence and the exchange tag move (a
+  // failed launch must leave them where the device-side counter and the peers still are)
+  if (peer) commit_peer(ctx);
   if (mailbox) ctx->mailbox_seq += 1;
   if (grid > 1) ctx->ticket_base += (unsigned)grid;
   SC_TRY(timer_end(ctx));
@@ -613,8 +592,22 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
 
 int wait_mailbox(sc_ctx* ctx, u64 seq);
 
+// after the sequence word of a launch that exchanged with the peers: did the exchange succeed?
+int check_exchange(sc_ctx* ctx, const char* what) {
+  const u64 err = __atomic_load_n(ctx->h_mailbox + sc::kMailboxErr, __ATOMIC_ACQUIRE);
+  if (err == 0) return SC_OK;
+  if (err & (u64)sc::kXchgTimeout) {
+    poison(ctx);
+    return fail(ctx, SC_ERR_RCCL, "peer exchange: a rank's %s did not arrive within %d ms (rank %d waited for rank %d at tag %u; that rank's "
+                "slot held tag ..%04x)", what, ctx->peer_spin_ms, ctx->rank, (int)((err >> 8) & 0xFF), ctx->xchg_tag, (unsigned)((err >> 16) & 0x3FFF));
+  }
+  return fail(ctx, SC_ERR_STATE, "the ranks of this sharded prover were given different challenges");
+}
+
 // One pass by wgrid_pass_kernel: folds kf <= 5 pending challenges of tables of 2^log_in entries and leaves the 3^ks
-// cells of the next ks <= 5 rounds as whole residues in the wide mailbox (unsharded only).  Its counters rest at zero.
+// cells of the next ks <= 5 rounds in the wide mailbox (collect_grid).  Its counters rest at zero.  Sharded passes:
+// the peer transport exchanges the cells inside the kernel; RCCL sums their limbs on the stream behind the kernel and
+// a small kernel hands the totals to the mailbox; a host transport gets this rank's residues and sums them itself.
 int launch_grid_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2, u64* B2, const u64* r, int log_in, bool across_ranks) {
   if (kf < 0 || kf > sc::kGridMaxVars || ks < 1 || ks > sc::kGridMaxVars || log_in < kf + ks)
     return fail(ctx, SC_ERR_ARG, "launch_grid_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
@@ -635,16 +628,18 @@ int launch_grid_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u6
   const size_t n_iter = (n_out + sc::kWgEntries - 1) / sc::kWgEntries;   // one per wave
   const size_t cap = ctx->grid_blocks > 0 ? (size_t)std::min(ctx->grid_blocks, ctx->wgrid_blocks) : (size_t)ctx->wgrid_blocks;
   const int grid = (int)std::max<size_t>(1, std::min<size_t>((n_iter + kWaves - 1) / kWaves, cap));
+  const bool peer = across_ranks && ctx->transport == Transport::kPeer;
+  const bool rccl = across_ranks && ctx->transport == Transport::kRccl;
+  int cells = 1;
+  for (int i = 0; i < ks; ++i) cells *= 3;
   sc::WgOut wo;
   wo.partials = ctx->d_wg_partials;
   wo.group_rows = ctx->d_wg_groups;
   wo.tickets = ctx->d_wg_tickets;
   wo.mailbox = ctx->d_mailbox;
   wo.seq = ctx->mailbox_seq + 1;
-  if (across_ranks) {
-    if (ctx->transport != Transport::kPeer) return fail(ctx, SC_ERR_STATE, "a sharded five-round pass needs the peer transport");
-    fill_peer(ctx, wo.px, challenge_digest(r, kf, ks, log_in));
-  }
+  wo.limbs_dev = rccl ? ctx->d_sums : nullptr;
+  if (peer) fill_peer(ctx, wo.px, challenge_digest(r, kf, ks, log_in));
   SC_TRY(timer_begin(ctx, SC_KIND_GRID_PASS, kf, ks, log_in, (u64)16 << log_in, kf > 0 ? (u64)16 << (log_in - kf) : 0));
 #define SC_WG(KS) hipLaunchKernelGGL((sc::wgrid_pass_kernel<F, KS>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, A, B, A2, B2, gw, kf, n_out, wo)
   SC_DISPATCH_FIELD(ctx, F, f, {
@@ -658,8 +653,16 @@ int launch_grid_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u6
   });
 #undef SC_WG
   SC_HIP(ctx, hipGetLastError());
-  ctx->mailbox_seq += 1;
+  if (peer) commit_peer(ctx);
   SC_TRY(timer_end(ctx));
+  if (rccl) {
+    ncclResult_t nr = g_rccl.AllReduce(ctx->d_sums, ctx->d_sums, 2 * (size_t)cells, ncclUint64, ncclSum, ctx->comm, ctx->stream);
+    if (nr != ncclSuccess) return fail(ctx, SC_ERR_RCCL, "ncclAllReduce: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(nr) : "?");
+    hipLaunchKernelGGL(sc::mailbox_copy_wide_kernel, dim3(1), dim3(sc::kBlock), 0, ctx->stream, (const u64*)ctx->d_sums, 2 * cells,
+                       ctx->d_mailbox, wo.seq);
+    SC_HIP(ctx, hipGetLastError());
+  }
+  ctx->mailbox_seq += 1;
   return SC_OK;
 }
 // its cells: wait for the sequence word; the residues, or (sharded) the limb totals of all ranks recombined mod p
@@ -667,21 +670,26 @@ int collect_grid(sc_ctx* ctx, int ks, bool across_ranks, u64* out) {
   SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
   int cells = 1;
   for (int i = 0; i < ks; ++i) cells *= 3;
+  const u64* wide = ctx->h_mailbox + sc::kMailboxWide;
   if (!across_ranks) {
-    for (int c = 0; c < cells; ++c) out[c] = ctx->h_mailbox[sc::kMailboxWide + c];
+    for (int c = 0; c < cells; ++c) out[c] = wide[c];
     return SC_OK;
   }
-  const u64 err = __atomic_load_n(ctx->h_mailbox + sc::kMailboxErr, __ATOMIC_ACQUIRE);
-  if (err == (u64)sc::kXchgDigest)
-    return fail(ctx, SC_ERR_STATE, "the ranks of this sharded prover were given different challenges");
-  if (err != 0) {
-    poison(ctx);
-    return fail(ctx, SC_ERR_RCCL, "peer exchange: a rank's sums did not arrive within %d ms (rank %d waited for rank %d at tag %u)",
-                ctx->peer_spin_ms, ctx->rank, (int)((err >> 8) & 0xFF), ctx->xchg_tag);
-  }
   HostField hf(ctx->fp);
-  for (int c = 0; c < cells; ++c)
-    out[c] = hf.recombine(ctx->h_mailbox[sc::kMailboxWide + 2 * c], ctx->h_mailbox[sc::kMailboxWide + 2 * c + 1]);
+  if (ctx->transport == Transport::kHost) {
+    // this rank's residues: split, sum over the ranks on the host, recombine
+    std::vector<u64> limbs(2 * (size_t)cells);
+    for (int c = 0; c < cells; ++c) {
+      limbs[2 * c] = wide[c] & 0xFFFFFFFFull;
+      limbs[2 * c + 1] = wide[c] >> 32;
+    }
+    if (ctx->host_allreduce(ctx->host_user, limbs.data(), limbs.size()) != 0)
+      return fail(ctx, SC_ERR_RCCL, "host all-reduce callback failed");
+    for (int c = 0; c < cells; ++c) out[c] = hf.recombine(limbs[2 * c], limbs[2 * c + 1]);
+    return SC_OK;
+  }
+  if (ctx->transport == Transport::kPeer) SC_TRY(check_exchange(ctx, "sums"));
+  for (int c = 0; c < cells; ++c) out[c] = hf.recombine(wide[2 * c], wide[2 * c + 1]);
   return SC_OK;
 }
 
@@ -698,22 +706,17 @@ int rank_pass(sc_ctx* ctx, int kf, const u64* A, const u64* B, u64* A2, u64* B2,
   wo.tickets = ctx->d_wg_tickets;
   wo.mailbox = ctx->d_mailbox;
   wo.seq = ctx->mailbox_seq + 1;
+  wo.limbs_dev = nullptr;
   fill_peer(ctx, wo.px, challenge_digest(r, kf, ctx->log_world, kf) ^ 0x72616e6bu);
   SC_TRY(timer_begin(ctx, SC_KIND_GRID_PASS, kf, ctx->log_world, kf, (u64)16 << kf, (u64)16 << ctx->log_world));
   SC_DISPATCH_FIELD(ctx, F, f,
                     hipLaunchKernelGGL((sc::rank_pass_kernel<F>), dim3(1), dim3(sc::kBlock), 0, ctx->stream, f, A, B, A2, B2, gw, kf, wo));
   SC_HIP(ctx, hipGetLastError());
+  commit_peer(ctx);
   ctx->mailbox_seq += 1;
   SC_TRY(timer_end(ctx));
   SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
-  const u64 err = __atomic_load_n(ctx->h_mailbox + sc::kMailboxErr, __ATOMIC_ACQUIRE);
-  if (err == (u64)sc::kXchgDigest)
-    return fail(ctx, SC_ERR_STATE, "the ranks of this sharded prover were given different challenges");
-  if (err != 0) {
-    poison(ctx);
-    return fail(ctx, SC_ERR_RCCL, "peer exchange: a rank's entries did not arrive within %d ms (rank %d waited for rank %d at tag %u)",
-                ctx->peer_spin_ms, ctx->rank, (int)((err >> 8) & 0xFF), ctx->xchg_tag);
-  }
+  SC_TRY(check_exchange(ctx, "entries"));
   int cells = 1;
   for (int i = 0; i < ctx->log_world; ++i) cells *= 3;
   for (int c = 0; c < cells; ++c) out[c] = ctx->h_mailbox[sc::kMailboxWide + c];
@@ -763,7 +766,8 @@ int wait_mailbox(sc_ctx* ctx, u64 seq) {
         poison(ctx);
         return fail(ctx, SC_ERR_HIP, "pass kernel finished but its mailbox word never arrived");
       }
-      if (el > 120.0) {
+      // (a kernel may itself wait up to peer_spin_ms for its peers: the host must outlast it)
+      if (el > 120.0 + 1e-3 * ctx->peer_spin_ms) {
         poison(ctx);
         return fail(ctx, SC_ERR_HIP, "timed out waiting for the pass kernel");
       }
@@ -782,18 +786,8 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
   if (from_mailbox) {
     SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
     src = ctx->h_mailbox;
-    if (across_ranks && ctx->transport == Transport::kPeer) {
-      // the kernel exchanged the limbs with the peers itself; the mailbox holds the totals, or why not
-      const u64 err = __atomic_load_n(ctx->h_mailbox + sc::kMailboxErr, __ATOMIC_ACQUIRE);
-      if (err == (u64)sc::kXchgDigest)
-        return fail(ctx, SC_ERR_STATE, "the ranks of this sharded prover were given different challenges");
-      if (err != 0) {
-        poison(ctx);
-        return fail(ctx, SC_ERR_RCCL, "peer exchange: a rank's sums did not arrive within %d ms (rank %d waited for rank %d at tag %u; "
-                    "that rank's slot held tag ..%04x)", ctx->peer_spin_ms, ctx->rank, (int)((err >> 8) & 0xFF), ctx->xchg_tag,
-                    (unsigned)((err >> 16) & 0xFFFF));
-      }
-    }
+    // the kernel exchanged the limbs with the peers itself; the mailbox holds the totals, or why not
+    if (across_ranks && ctx->transport == Transport::kPeer) SC_TRY(check_exchange(ctx, "sums"));
   } else if (across_ranks && ctx->transport == Transport::kPeer) {
     // limbs left in d_sums by a small kernel: one wave exchanges them with the peers and publishes
     sc::PassOut po;
@@ -813,6 +807,7 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
       default: hipLaunchKernelGGL((sc::peer_exchange_kernel<27>), dim3(1), dim3(sc::kWave), 0, ctx->stream, limbs, po); break;
     }
     SC_HIP(ctx, hipGetLastError());
+    commit_peer(ctx);
     ctx->mailbox_seq += 1;
     return collect_sums(ctx, ns, true, true, out);
   } else {
@@ -851,38 +846,50 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
   return SC_OK;
 }
 
-// Peer transport: all-gather `len` words per rank of two device buffers (b may be null) into this rank's
-// arena; *fa / *fb point into the arena (world * len contiguous words each, rank order).  Two arenas are
-// used alternately (by the tag's parity), so a gathered table stays valid until the gather after next.
-int peer_gather(sc_ctx* ctx, const u64* a, const u64* b, size_t len, const u64** fa, const u64** fb) {
-  const size_t cap = (size_t)ctx->world << ctx->arena_log;   // words per table
-  if (len * ctx->world > cap)
-    return fail(ctx, SC_ERR_UNSUPPORTED, "peer gather of %zu words per rank exceeds the arena (arena_log = %d)", len, ctx->arena_log);
-  sc::PassOut out;
-  out.partials = ctx->d_partials;
-  out.n_rows = (int)ctx->partial_rows;
-  out.ticket = ctx->d_ticket;
-  out.ticket_base = ctx->ticket_base;
-  out.sums_dev = ctx->d_sums;
-  out.mailbox = ctx->d_mailbox;
-  out.seq = ctx->mailbox_seq + 1;
-  fill_peer(ctx, out.px, 0);
-  const size_t arena_off = kInboxRegionWords + (size_t)(out.px.tag & 1u) * 2 * cap;
-  sc::PeerG pg;
-  for (int q = 0; q < ctx->world; ++q) pg.arena[q] = ctx->peer_base[q] + arena_off;
-  pg.table_stride = cap;
-  int grid = (int)std::min<size_t>(std::max<size_t>((len / 2 + sc::kBlock - 1) / sc::kBlock, 1), 256);
-  hipLaunchKernelGGL(sc::peer_gather_kernel, dim3(grid), dim3(sc::kBlock), 0, ctx->stream, a, b ? b : a, len, pg, out);
-  SC_HIP(ctx, hipGetLastError());
-  ctx->mailbox_seq += 1;
-  if (grid > 1) ctx->ticket_base += (unsigned)grid;
-  SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
-  if (__atomic_load_n(ctx->h_mailbox + sc::kMailboxErr, __ATOMIC_ACQUIRE) != 0) {
-    poison(ctx);
-    return fail(ctx, SC_ERR_RCCL, "peer gather: a rank's tables did not arrive within %d ms", ctx->peer_spin_ms);
+// Peer transport: all-gather `len` words per rank of two device buffers (b may be null) into dst_a / dst_b
+// (world * len words each, rank order, ordinary device memory).  The peers write into this rank's arena - at most
+// 2^arena_log words per rank and table at a time, longer tables go in chunks - and every chunk is copied out on the
+// stream before the next gather can touch that arena: two arenas are used alternately by the parity of a dedicated
+// gather counter, and a peer can only be writing gather g + 1 once this rank's kernel of gather g has flagged, which
+// sits behind the copy-out of gather g - 1 (the previous user of g + 1's arena) on this stream.
+int peer_gather(sc_ctx* ctx, const u64* a, const u64* b, size_t len, u64* dst_a, u64* dst_b) {
+  const size_t chunk_cap = (size_t)1 << ctx->arena_log;         // words per rank, table and chunk
+  const size_t cap = (size_t)ctx->world << ctx->arena_log;      // words per table of an arena
+  for (size_t off = 0; off < len; off += chunk_cap) {
+    const size_t n = std::min(chunk_cap, len - off);
+    sc::PassOut out;
+    out.partials = ctx->d_partials;
+    out.n_rows = (int)ctx->partial_rows;
+    out.ticket = ctx->d_ticket;
+    out.ticket_base = ctx->ticket_base;
+    out.sums_dev = ctx->d_sums;
+    out.mailbox = ctx->d_mailbox;
+    out.seq = ctx->mailbox_seq + 1;
+    fill_peer(ctx, out.px, 0);
+    const size_t arena_off = kInboxRegionWords + kPeerHeaderWords + (size_t)(ctx->gather_count & 1u) * 2 * cap;
+    sc::PeerG pg;
+    for (int q = 0; q < ctx->world; ++q) pg.arena[q] = ctx->peer_base[q] + arena_off;
+    pg.table_stride = cap;
+    const int grid = (int)std::min<size_t>(std::max<size_t>((n / 2 + sc::kBlock - 1) / sc::kBlock, 1), 256);
+    hipLaunchKernelGGL(sc::peer_gather_kernel, dim3(grid), dim3(sc::kBlock), 0, ctx->stream, a + off, (b ? b : a) + off, n, pg, out);
+    SC_HIP(ctx, hipGetLastError());
+    commit_peer(ctx);
+    ctx->gather_count += 1;
+    ctx->mailbox_seq += 1;
+    if (grid > 1) ctx->ticket_base += (unsigned)grid;
+    SC_TRY(wait_mailbox(ctx, ctx->mailbox_seq));
+    if (__atomic_load_n(ctx->h_mailbox + sc::kMailboxErr, __ATOMIC_ACQUIRE) != 0) {
+      poison(ctx);
+      return fail(ctx, SC_ERR_RCCL, "peer gather: a rank's tables did not arrive within %d ms", ctx->peer_spin_ms);
+    }
+    // arena rows [rank][n] -> dst rows [rank][len] at column `off`
+    const u64* src = ctx->peer_base[ctx->rank] + arena_off;
+    SC_HIP(ctx, hipMemcpy2DAsync(dst_a + off, len * sizeof(u64), src, n * sizeof(u64), n * sizeof(u64), (size_t)ctx->world,
+                                 hipMemcpyDeviceToDevice, ctx->stream));
+    if (b && dst_b)
+      SC_HIP(ctx, hipMemcpy2DAsync(dst_b + off, len * sizeof(u64), src + cap, n * sizeof(u64), n * sizeof(u64), (size_t)ctx->world,
+                                   hipMemcpyDeviceToDevice, ctx->stream));
   }
-  *fa = ctx->peer_base[ctx->rank] + arena_off;
-  if (fb) *fb = *fa + cap;
   return SC_OK;
 }
 
@@ -890,7 +897,13 @@ int peer_gather(sc_ctx* ctx, const u64* a, const u64* b, size_t len, const u64**
 int gather_table(sc_ctx* ctx, const u64* local, size_t len, u64** out_full) {
   u64* full = nullptr;
   SC_TRY(pool_alloc(ctx, len * ctx->world, &full));
-  if (ctx->transport == Transport::kRccl) {
+  if (ctx->transport == Transport::kPeer) {
+    const int rc = peer_gather(ctx, local, nullptr, len, full, nullptr);
+    if (rc != SC_OK) {
+      pool_release(ctx, full);
+      return rc;
+    }
+  } else if (ctx->transport == Transport::kRccl) {
     ncclResult_t r = g_rccl.AllGather(local, full, len, ncclUint64, ctx->comm, ctx->stream);
     if (r != ncclSuccess) {
       pool_release(ctx, full);
@@ -918,13 +931,17 @@ int gather_table(sc_ctx* ctx, const u64* local, size_t len, u64** out_full) {
 // Sum `count` u64 words of a device buffer across ranks, in place (values are 32-bit limbs).
 int allreduce_device(sc_ctx* ctx, u64* buf, size_t count) {
   if (ctx->transport == Transport::kPeer) {
-    // gather every rank's vector into the arena, then sum the rows locally (plain u64 adds of limbs)
-    const u64* all = nullptr;
-    SC_TRY(peer_gather(ctx, buf, nullptr, count, &all, nullptr));
-    hipLaunchKernelGGL(sc::sum_limb_rows_kernel, dim3(grid_for(ctx, count)), dim3(sc::kBlock), 0, ctx->stream, all, ctx->world,
-                       count, buf);
-    SC_HIP(ctx, hipGetLastError());
-    return SC_OK;
+    // gather every rank's vector, then sum the rows locally (plain u64 adds of limbs)
+    u64* all = nullptr;
+    SC_TRY(pool_alloc(ctx, count * ctx->world, &all));
+    int rc = peer_gather(ctx, buf, nullptr, count, all, nullptr);
+    if (rc == SC_OK) {
+      hipLaunchKernelGGL(sc::sum_limb_rows_kernel, dim3(grid_for(ctx, count)), dim3(sc::kBlock), 0, ctx->stream, (const u64*)all, ctx->world,
+                         count, buf);
+      if (hipGetLastError() != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "sum_limb_rows_kernel launch failed");
+    }
+    pool_release(ctx, all);   // stream-ordered reuse
+    return rc;
   }
   if (ctx->transport == Transport::kRccl) {
     ncclResult_t r = g_rccl.AllReduce(buf, buf, count, ncclUint64, ncclSum, ctx->comm, ctx->stream);
@@ -1246,8 +1263,8 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
   }
   ctx->partial_rows = 4096;
   SC_CREATE_HIP(hipMalloc(&ctx->d_partials, ctx->partial_rows * 32 * sizeof(u64)));
-  SC_CREATE_HIP(hipMalloc(&ctx->d_sums, 64 * sizeof(u64)));
-  SC_CREATE_HIP(hipHostMalloc(&ctx->h_sums, 64 * sizeof(u64), hipHostMallocDefault));
+  SC_CREATE_HIP(hipMalloc(&ctx->d_sums, 512 * sizeof(u64)));   // up to 2 x 243 split limbs of a five-round pass
+  SC_CREATE_HIP(hipHostMalloc(&ctx->h_sums, 512 * sizeof(u64), hipHostMallocDefault));
   SC_CREATE_HIP(hipMalloc(&ctx->d_ticket, 64));
   SC_CREATE_HIP(hipMemset(ctx->d_ticket, 0, 64));
   SC_CREATE_HIP(hipHostMalloc(&ctx->h_mailbox, sc::kMailboxWords * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
@@ -1257,11 +1274,6 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
   SC_CREATE_HIP(hipMalloc(&ctx->d_wg_tickets, 64 * sizeof(unsigned)));
   SC_CREATE_HIP(hipMemset(ctx->d_wg_tickets, 0, 64 * sizeof(unsigned)));
   SC_CREATE_HIP(hipHostGetDevicePointer((void**)&ctx->d_mailbox, ctx->h_mailbox, 0));
-  SC_CREATE_HIP(hipHostMalloc(&ctx->h_cmd, 64 * sizeof(u64), hipHostMallocMapped | hipHostMallocCoherent));
-  memset(ctx->h_cmd, 0, 64 * sizeof(u64));
-  SC_CREATE_HIP(hipHostGetDevicePointer((void**)&ctx->d_cmd_host, ctx->h_cmd, 0));
-  SC_CREATE_HIP(hipMalloc(&ctx->d_cmd, (64 + 128) * sizeof(u64)));   // command line + diagnostic stamps
-  SC_CREATE_HIP(hipMemset(ctx->d_cmd, 0, (64 + 128) * sizeof(u64)));
   SC_CREATE_HIP(hipDeviceSynchronize());
   for (int i = 0; i < sc_ctx::kTimerRing; ++i) {
     SC_CREATE_HIP(hipEventCreate(&ctx->kt_ev[i][0]));
@@ -1275,7 +1287,6 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
 extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
   if (!ctx) return SC_OK;
   (void)hipSetDevice(ctx->device);
-  if (ctx->live_resident) resident_retire(ctx);
   if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
   if (ctx->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(ctx->comm);
   for (int q = 0; q < sc::kMaxPeers; ++q)
@@ -1290,8 +1301,6 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
   if (ctx->d_sums) (void)hipFree(ctx->d_sums);
   if (ctx->h_sums) (void)hipHostFree(ctx->h_sums);
   if (ctx->h_mailbox) (void)hipHostFree(ctx->h_mailbox);
-  if (ctx->h_cmd) (void)hipHostFree(ctx->h_cmd);
-  if (ctx->d_cmd) (void)hipFree(ctx->d_cmd);
   if (ctx->d_ticket) (void)hipFree(ctx->d_ticket);
   for (int i = 0; i < sc_ctx::kTimerRing; ++i)
     for (int k = 0; k < 2; ++k)
@@ -1314,12 +1323,6 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "first_pass_vars") {
     if (value < 0 || value > 3) return fail(ctx, SC_ERR_ARG, "first_pass_vars must be 0 (auto), 1, 2 or 3");
     ctx->first_pass_vars = (int)value;
-  } else if (k == "tail_pass_vars") {
-    if (value != 2 && value != 3) return fail(ctx, SC_ERR_ARG, "tail_pass_vars must be 2 or 3");
-    ctx->tail_pass_vars = (int)value;
-  } else if (k == "tail_pass_log") {
-    if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "tail_pass_log out of range");
-    ctx->tail_pass_log = (int)value;
   } else if (k == "grid_pass") {
     ctx->grid_pass = value ? 1 : 0;
   } else if (k == "grid_log") {
@@ -1328,17 +1331,8 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "grid_max_vars") {
     if (value < 1 || value > sc::kGridMaxVars) return fail(ctx, SC_ERR_ARG, "grid_max_vars must be 1..5");
     ctx->grid_max_vars = (int)value;
-  } else if (k == "grid_vars4_log") {
-    if (value < 0 || value > 26) return fail(ctx, SC_ERR_ARG, "grid_vars4_log out of range (0..26)");
-    ctx->grid_vars4_log = (int)value;
-  } else if (k == "grid_vars5_log") {
-    if (value < 0 || value > 26) return fail(ctx, SC_ERR_ARG, "grid_vars5_log out of range (0..26)");
-    ctx->grid_vars5_log = (int)value;
   } else if (k == "grid_sharded") {
     ctx->grid_sharded = value ? 1 : 0;
-  } else if (k == "mid_pass") {
-    ctx->mid_pass = value ? 1 : 0;
-    memset(ctx->resident_blocks, 0, sizeof(ctx->resident_blocks));   // the cached grids of the tail passes belong to the other kernel
   } else if (k == "grid_blocks") {
     if (value < 0 || value > kWgMaxBlocks) return fail(ctx, SC_ERR_ARG, "grid_blocks must be 0..%d", kWgMaxBlocks);
     ctx->grid_blocks = (int)value;
@@ -1359,16 +1353,14 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
   } else if (k == "peer_spin_ms") {
     if (value < 1 || value > 600000) return fail(ctx, SC_ERR_ARG, "peer_spin_ms out of range");
     ctx->peer_spin_ms = (int)value;
-  } else if (k == "resident") {
-    ctx->resident = value ? 1 : 0;
-  } else if (k == "resident_stamps") {
-    ctx->resident_stamps = value ? 1 : 0;
-  } else if (k == "resident_log") {
-    if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "resident_log out of range");
-    ctx->resident_log = (int)value;
-  } else if (k == "park_ms") {
-    if (value < 1 || value > 10000) return fail(ctx, SC_ERR_ARG, "park_ms must be in [1, 10000]");
-    ctx->park_ms = (int)value;
+  } else if (k == "peer_connect_ms") {
+    if (value < 1 || value > 3600000) return fail(ctx, SC_ERR_ARG, "peer_connect_ms out of range");
+    ctx->peer_connect_ms = (int)value;
+  } else if (k == "dbg_delay_ms") {
+    if (value < 0 || value > 10000) return fail(ctx, SC_ERR_ARG, "dbg_delay_ms out of range");
+    ctx->dbg_delay_ms = (int)value;
+  } else if (k == "dbg_skip_tag") {
+    ctx->dbg_skip_tag = value ? 1 : 0;
   } else if (k == "nt_load_log") {
     ctx->nt_load_log = (int)value;
   } else if (k == "nt_store_log") {
@@ -1384,14 +1376,9 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   std::string k(key);
   if (k == "vars_per_pass") *value = ctx->vars_per_pass;
   else if (k == "first_pass_vars") *value = ctx->first_pass_vars;
-  else if (k == "tail_pass_vars") *value = ctx->tail_pass_vars;
-  else if (k == "tail_pass_log") *value = ctx->tail_pass_log;
   else if (k == "grid_pass") *value = ctx->grid_pass;
   else if (k == "grid_log") *value = ctx->grid_log;
   else if (k == "grid_max_vars") *value = ctx->grid_max_vars;
-  else if (k == "grid_vars4_log") *value = ctx->grid_vars4_log;
-  else if (k == "grid_vars5_log") *value = ctx->grid_vars5_log;
-  else if (k == "mid_pass") *value = ctx->mid_pass;
   else if (k == "grid_sharded") *value = ctx->grid_sharded;
   else if (k == "grid_blocks") *value = ctx->grid_blocks;
   else if (k == "tail_log") *value = ctx->tail_log;
@@ -1400,21 +1387,20 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   else if (k == "use_mailbox") *value = ctx->use_mailbox;
   else if (k == "arena_log") *value = ctx->arena_log;
   else if (k == "peer_spin_ms") *value = ctx->peer_spin_ms;
-  else if (k == "resident") *value = ctx->resident;
-  else if (k == "resident_log") *value = ctx->resident_log;
-  else if (k == "resident_stamps") *value = ctx->resident_stamps;
-  else if (k == "resident_host_ns") *value = (int64_t)ctx->dbg_host_ns;
-  else if (k == "park_ms") *value = ctx->park_ms;
   else if (k == "nt_load_log") *value = ctx->nt_load_log;
   else if (k == "nt_store_log") *value = ctx->nt_store_log;
-  else if (k.rfind("resident_stamp_", 0) == 0) {
-    // diagnostic: stamp i of the last resident launch (after it has left the stream)
-    const int i = atoi(k.c_str() + 15);
-    if (i < 0 || i >= 128) return fail(ctx, SC_ERR_ARG, "stamp index out of range");
-    u64 v = 0;
-    if (hipMemcpy(&v, ctx->d_cmd + 64 + i, sizeof(u64), hipMemcpyDeviceToHost) != hipSuccess)
-      return fail(ctx, SC_ERR_HIP, "reading a stamp failed");
-    *value = (int64_t)v;
+  else if (k == "peer_connect_ms") *value = ctx->peer_connect_ms;
+  else if (k == "dbg_delay_ms") *value = ctx->dbg_delay_ms;
+  else if (k == "transport") *value = (int64_t)ctx->transport;   // 0 none, 1 RCCL, 2 host callbacks, 3 peer
+  else if (k == "comm_nranks") {
+    // how many ranks the data plane really spans: RCCL's own count (ncclCommCount) when it is the transport
+    int n = ctx->world;
+    if (ctx->transport == Transport::kRccl) {
+      n = 0;
+      if (!g_rccl.CommCount || !ctx->comm || g_rccl.CommCount(ctx->comm, &n) != ncclSuccess)
+        return fail(ctx, SC_ERR_RCCL, "ncclCommCount failed");
+    }
+    *value = n;
   }
   else return fail(ctx, SC_ERR_ARG, "unknown option '%s'", key);
   return SC_OK;
@@ -1516,7 +1502,8 @@ extern "C" int sc_ctx_comm_peer_export(sc_ctx* ctx, int rank, int world, uint8_t
   if (ctx->peer_region) return fail(ctx, SC_ERR_STATE, "sc_ctx_comm_peer_export: already exported");
   SC_TRY(set_world(ctx, rank, world));
   static_assert(sizeof(hipIpcMemHandle_t) == 64, "hipIpcMemHandle_t is 64 bytes");
-  const size_t words = kInboxRegionWords + 2 * 2 * ((size_t)world << ctx->arena_log);   // inbox + two arenas of two tables
+  // inbox + header + two arenas of two tables
+  const size_t words = kInboxRegionWords + kPeerHeaderWords + 2 * 2 * ((size_t)world << ctx->arena_log);
   // fine-grained device memory: written by the peers over xGMI while kernels of this rank poll it
   // (no coarse-grained fallback: a peer's stores into ordinary device memory are not guaranteed to be seen by
   // this device's caches across launches; a caller without fine-grained memory uses another transport)
@@ -1528,7 +1515,9 @@ extern "C" int sc_ctx_comm_peer_export(sc_ctx* ctx, int rank, int world, uint8_t
     return fail(ctx, SC_ERR_OOM, "peer region of %zu bytes: %s", words * sizeof(u64), hipGetErrorString(e));
   }
   ctx->peer_region_words = words;
-  e = hipMemset(ctx->peer_region, 0, kInboxRegionWords * sizeof(u64));
+  e = hipMemset(ctx->peer_region, 0, (kInboxRegionWords + kPeerHeaderWords) * sizeof(u64));
+  const u64 header[4] = {kPeerMagic, (u64)world, (u64)rank, (u64)ctx->arena_log};
+  if (e == hipSuccess) e = hipMemcpy(ctx->peer_region + kInboxRegionWords, header, sizeof(header), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipDeviceSynchronize();
   hipIpcMemHandle_t h;
   if (e == hipSuccess) e = hipIpcGetMemHandle(&h, ctx->peer_region);
@@ -1543,8 +1532,92 @@ extern "C" int sc_ctx_comm_peer_export(sc_ctx* ctx, int rank, int world, uint8_t
   return SC_OK;
 }
 
+// Every peer region is mapped.  Before the transport is declared usable:
+//  1. each mapped region's header must name the same world and arena size and the rank it is mapped as (offsets into a
+//     peer's region are computed locally);
+//  2. hello: one granule into every peer's inbox; the HOST then polls its own inbox until every peer's hello is there
+//     (up to peer_connect_ms).  A peer that said hello has mapped this region, loaded its code object and run a kernel,
+//     so from here on the ranks are in step and the in-kernel waits can be short (peer_spin_ms);
+//  3. a self-test through the real paths - an in-kernel exchange of known limbs and a gather of known words - so that a
+//     node whose fine-grained memory does not behave as the kernels assume (peer stores visible to a polling kernel,
+//     gathered data visible to the next launch) fails HERE, with SC_ERR_RCCL, and not inside a proof.
 static int peer_finish_connect(sc_ctx* ctx) {
+  for (int q = 0; q < ctx->world; ++q) {
+    u64 header[4] = {0, 0, 0, 0};
+    SC_HIP(ctx, hipMemcpyAsync(header, ctx->peer_base[q] + kInboxRegionWords, sizeof(header), hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (header[0] != kPeerMagic || header[1] != (u64)ctx->world || header[2] != (u64)q || header[3] != (u64)ctx->arena_log)
+      return fail(ctx, SC_ERR_ARG, "peer %d's region was exported as rank %llu of %llu with arena_log %llu (expected rank %d of %d, arena_log %d)",
+                  q, (unsigned long long)header[2], (unsigned long long)header[1], (unsigned long long)header[3], q, ctx->world, ctx->arena_log);
+  }
   ctx->transport = Transport::kPeer;
+  auto unusable = [ctx](int rc) {
+    ctx->transport = Transport::kNone;
+    return rc;
+  };
+  sc::PeerX px;
+  for (int q = 0; q < ctx->world; ++q) px.inbox[q] = ctx->peer_base[q];
+  px.world = ctx->world;
+  px.rank = ctx->rank;
+  hipLaunchKernelGGL(sc::peer_hello_kernel, dim3(1), dim3(sc::kWave), 0, ctx->stream, px);
+  if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess)
+    return unusable(fail(ctx, SC_ERR_HIP, "peer hello launch failed"));
+  {
+    std::vector<u64> inbox((size_t)sc::kMaxPeers * sc::kInboxWords);
+    const auto t0 = std::chrono::steady_clock::now();
+    while (true) {
+      if (hipMemcpyAsync(inbox.data(), ctx->peer_region, (size_t)ctx->world * sc::kInboxWords * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+          hipStreamSynchronize(ctx->stream) != hipSuccess)
+        return unusable(fail(ctx, SC_ERR_HIP, "reading the inbox failed"));
+      int missing = -1;
+      for (int q = 0; q < ctx->world; ++q)
+        if (inbox[(size_t)q * sc::kInboxWords + sc::kInboxHello] != (((u64)sc::kHelloTag << 32) | (u64)(q + 1))) missing = q;
+      if (missing < 0) break;
+      const double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+      if (el * 1e3 > ctx->peer_connect_ms)
+        return unusable(fail(ctx, SC_ERR_RCCL, "peer connect: rank %d did not say hello within %d ms", missing, ctx->peer_connect_ms));
+      std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+  }
+  // self-test 1: in-kernel exchange.  limbs (rank + 1, 7) -> totals (world (world + 1) / 2, 7 world)
+  {
+    const u64 mine[2] = {(u64)ctx->rank + 1, 7};
+    SC_HIP(ctx, hipMemcpyAsync(ctx->d_sums, mine, sizeof(mine), hipMemcpyHostToDevice, ctx->stream));
+    u64 got = 0;
+    const int keep_delay = ctx->dbg_delay_ms;
+    ctx->dbg_delay_ms = 0;
+    const int rc = collect_sums(ctx, 1, true, false, &got);
+    ctx->dbg_delay_ms = keep_delay;
+    if (rc != SC_OK) return unusable(rc == SC_ERR_STATE ? fail(ctx, SC_ERR_RCCL, "peer self-test: digest mismatch") : rc);
+    HostField hf(ctx->fp);
+    const u64 want = hf.recombine((u64)ctx->world * (ctx->world + 1) / 2, 7 * (u64)ctx->world);
+    if (got != want) return unusable(fail(ctx, SC_ERR_RCCL, "peer self-test: the in-kernel exchange summed to the wrong value"));
+  }
+  // self-test 2: gather (two chunk-sized rounds, so both arenas are exercised)
+  {
+    const size_t len = 64;
+    u64 *src = nullptr, *dst = nullptr;
+    SC_TRY(pool_alloc(ctx, len, &src));
+    int rc = pool_alloc(ctx, len * ctx->world, &dst);
+    std::vector<u64> host(len * ctx->world);
+    for (int round = 0; round < 2 && rc == SC_OK; ++round) {
+      for (size_t i = 0; i < len; ++i) host[i] = ((u64)(ctx->rank + 1) << 32) | ((u64)round << 16) | i;
+      if (hipMemcpyAsync(src, host.data(), len * sizeof(u64), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "self-test upload failed");
+      if (rc == SC_OK) rc = peer_gather(ctx, src, nullptr, len, dst, nullptr);
+      if (rc == SC_OK && (hipMemcpyAsync(host.data(), dst, len * ctx->world * sizeof(u64), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                          hipStreamSynchronize(ctx->stream) != hipSuccess))
+        rc = fail(ctx, SC_ERR_HIP, "self-test download failed");
+      for (int q = 0; q < ctx->world && rc == SC_OK; ++q)
+        for (size_t i = 0; i < len; ++i)
+          if (host[(size_t)q * len + i] != (((u64)(q + 1) << 32) | ((u64)round << 16) | i)) {
+            rc = fail(ctx, SC_ERR_RCCL, "peer self-test: gathered word %zu of rank %d is wrong", i, q);
+            break;
+          }
+    }
+    pool_release(ctx, src);
+    pool_release(ctx, dst);
+    if (rc != SC_OK) return unusable(rc);
+  }
   return SC_OK;
 }
 
@@ -1558,6 +1631,7 @@ extern "C" int sc_ctx_comm_peer_connect(sc_ctx* ctx, const uint8_t* handles) {
       ctx->peer_base[q] = ctx->peer_region;
       continue;
     }
+    if (ctx->peer_ipc_opened[q]) continue;   // a retried connect
     hipIpcMemHandle_t h;
     memcpy(&h, handles + 64 * (size_t)q, 64);
     void* p = nullptr;
@@ -1573,10 +1647,21 @@ extern "C" int sc_ctx_comm_peer_connect_local(sc_ctx* ctx, sc_ctx* const* peers)
   if (!ctx || !peers) return SC_ERR_ARG;
   if (!ctx->peer_exported || ctx->transport != Transport::kNone)
     return fail(ctx, SC_ERR_STATE, "sc_ctx_comm_peer_connect_local: call sc_ctx_comm_peer_export first (once)");
+  SC_TRY(set_device(ctx));
   for (int q = 0; q < ctx->world; ++q) {
     const sc_ctx* pq = (q == ctx->rank) ? ctx : peers[q];
     if (!pq || !pq->peer_region || pq->world != ctx->world || pq->rank != q || pq->arena_log != ctx->arena_log)
       return fail(ctx, SC_ERR_ARG, "peer %d is not an exported context of the same world", q);
+    if (pq->device != ctx->device) {
+      // contexts of one process on different GPUs: this device must be allowed to reach the peer's memory
+      int can = 0;
+      if (hipDeviceCanAccessPeer(&can, ctx->device, pq->device) != hipSuccess || !can)
+        return fail(ctx, SC_ERR_UNSUPPORTED, "device %d cannot access device %d's memory", ctx->device, pq->device);
+      const hipError_t e = hipDeviceEnablePeerAccess(pq->device, 0);
+      if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled)
+        return fail(ctx, SC_ERR_HIP, "hipDeviceEnablePeerAccess(%d): %s", pq->device, hipGetErrorString(e));
+      (void)hipGetLastError();
+    }
     ctx->peer_base[q] = pq->peer_region;
   }
   return peer_finish_connect(ctx);
@@ -2029,16 +2114,6 @@ struct sc_prover {
   mutable int g_known = -1;
   u64 S[sc::kGridMaxCells];
   u64 c1 = 0;
-  // resident kernel serving this prover's remaining passes (kernels.hpp, resident_kernel)
-  struct {
-    bool live = false;
-    sc::ResidentPlan plan;
-    int next_phase = 0;         // first phase whose sums the host has not consumed yet
-    u64 seq0 = 0;               // mailbox sequence of phase 0
-    u64 cmd_base = 0;
-    unsigned ticket0 = 0;       // ticket base of phase 0
-    u64 *PA = nullptr, *PB = nullptr, *QA = nullptr, *QB = nullptr;
-  } res;
 };
 
 namespace {
@@ -2047,7 +2122,7 @@ namespace {
 // 22 0.204 / 0.198, 24 0.307 / 0.294, 26 0.75 / 0.68, 28 2.36 / 2.13
 constexpr int kFirstPass3Log = 18;
 
-// rounds a pass at round j serves (the schedule of DESIGN.md section 4), given the table size and what is pending
+// rounds a pass_kernel launch at round j serves (the schedule of DESIGN.md section 4)
 int pass_rounds(const sc_ctx* ctx, size_t num_vars, size_t j, int kf, int cur_log) {
   const size_t remaining = num_vars - j;  // variables left including round j's
   int ks = (ctx->vars_per_pass == 2 && remaining >= 2) ? 2 : 1;
@@ -2056,361 +2131,68 @@ int pass_rounds(const sc_ctx* ctx, size_t num_vars, size_t j, int kf, int cur_lo
     if (ctx->vars_per_pass == 2 && remaining >= 3 && first == 3) ks = 3;
     if (first < ks) ks = first;
   }
-  // tail: once the input is small every pass is latency-bound, so serve three rounds with each
-  if (kf > 0 && ctx->vars_per_pass == 2 && ctx->tail_pass_vars == 3 && remaining >= 3 && cur_log <= ctx->tail_pass_log)
-    ks = 3;
   return ks;
 }
 
 // Rounds a grid pass (kernels.hpp, wgrid_pass_kernel) serves when `vars` variables are left, i.e. the folded table
-// has 2^vars entries: as few passes as the size limits allow (five rounds on tables of <= 2^grid_vars5_log entries,
-// four up to 2^grid_vars4_log, else three), the rounds shared evenly among them where the limits permit.
-int grid_max_rounds(const sc_ctx* ctx, int vars) {
-  int m = vars <= ctx->grid_vars5_log ? 5 : vars <= ctx->grid_vars4_log ? 4 : 3;
-  m = std::min(m, ctx->grid_max_vars);
-  return std::max(1, std::min(m, vars));
-}
-int grid_passes_needed(const sc_ctx* ctx, int vars) {
-  int n = 0;
-  while (vars > 0) {
-    vars -= grid_max_rounds(ctx, vars);
-    ++n;
-  }
-  return n;
-}
+// has 2^vars entries: as few passes as grid_max_vars allows, the rounds shared evenly among them.
+int grid_passes_needed(const sc_ctx* ctx, int vars) { return (vars + ctx->grid_max_vars - 1) / ctx->grid_max_vars; }
 int grid_rounds(const sc_ctx* ctx, int vars) {
-  const int need = grid_passes_needed(ctx, vars), most = grid_max_rounds(ctx, vars);
-  for (int ks = std::min(most, (vars + need - 1) / need); ks < most; ++ks)   // an even share, if the rest still fits
-    if (1 + grid_passes_needed(ctx, vars - ks) == need) return ks;
-  return most;
+  const int need = grid_passes_needed(ctx, vars);
+  return std::max(1, std::min((vars + need - 1) / need, vars));
 }
-// does the pass at round j go to wgrid_pass_kernel?  Unsharded: folded table small enough.  Sharded: the same on the
-// local shard, with the in-kernel exchange of the peer transport, while the shard keeps at least one variable.
-// (the one-round-per-pass mode, a two-round tail, an explicit first_pass_vars and the resident kernel are requests
-// for those schedules)
+// does the pass at round j go to wgrid_pass_kernel?  The folded table (on a sharded prover: the folded shard) must be
+// small enough and keep at least one variable.  (The one-round-per-pass mode and an explicit first_pass_vars are
+// requests for those schedules.)
 bool takes_grid_pass(const sc_ctx* ctx, bool sharded, int cur_log, int kf, size_t j) {
-  if (!ctx->grid_pass || ctx->resident || !ctx->use_mailbox || ctx->vars_per_pass != 2 || ctx->tail_pass_vars != 3) return false;
-  if (sharded && (ctx->transport != Transport::kPeer || !ctx->grid_sharded)) return false;
+  if (!ctx->grid_pass || !ctx->use_mailbox || ctx->vars_per_pass != 2) return false;
+  if (sharded && !ctx->grid_sharded) return false;
   if (j == 0 && kf == 0 && ctx->first_pass_vars != 0) return false;
   return cur_log - kf >= 1 && cur_log - kf <= ctx->grid_log;
 }
 
-int resident_capacity(sc_ctx* ctx) {
-  if (ctx->resident_blocks_cap == 0) {
-    int per_cu = 0;
-    const void* fn = ctx->gold ? reinterpret_cast<const void*>(&sc::resident_kernel<sc::GoldilocksMont>)
-                               : reinterpret_cast<const void*>(&sc::resident_kernel<sc::MontGeneric>);
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, sc::kBlock, 0) != hipSuccess) {
-      (void)hipGetLastError();
-      per_cu = 0;
+// all-gather both tables of a sharded prover into pool buffers (any transport)
+int gather_pair(sc_ctx* ctx, const u64* a, const u64* b, size_t len, u64** fa, u64** fb) {
+  if (ctx->transport == Transport::kPeer) {
+    u64 *ga = nullptr, *gb = nullptr;
+    SC_TRY(pool_alloc(ctx, len * ctx->world, &ga));
+    int rc = pool_alloc(ctx, len * ctx->world, &gb);
+    if (rc == SC_OK) rc = peer_gather(ctx, a, b, len, ga, gb);
+    if (rc != SC_OK) {
+      pool_release(ctx, ga);
+      pool_release(ctx, gb);
+      return rc;
     }
-    // the kernel needs every block of its grid on the chip at once; the occupancy query can over-report by
-    // one block per CU for SGPR-heavy kernels (MI355X_MICROARCH.md, residency), so never ask for more than
-    // two per CU and only when the query grants at least that
-    ctx->resident_blocks_cap = per_cu >= 2 ? 2 * ctx->num_cus : (per_cu == 1 ? 0 : -1);
-    if (ctx->resident_blocks_cap <= 0) ctx->resident_blocks_cap = -1;
-  }
-  return ctx->resident_blocks_cap;
-}
-
-// The resident kernel has left the stream, or is leaving it with nothing more to read (all phases done):
-// settle the context's counters from what the DEVICE executed, and the prover's buffers from what the
-// HOST consumed.  `executed` < 0: read it off the mailbox (only valid once the stream is idle).
-void resident_settle(sc_prover* pr, int executed) {
-  sc_ctx* ctx = pr->ctx;
-  const int n = pr->res.plan.n_phases;
-  if (executed < 0) {
-    const u64 last = __atomic_load_n(ctx->h_mailbox + sc::kMailboxSeq, __ATOMIC_ACQUIRE);
-    executed = (last >= pr->res.seq0 && last < pr->res.seq0 + (u64)n) ? (int)(last - pr->res.seq0) + 1 : 0;
-    if (executed < pr->res.next_phase) executed = pr->res.next_phase;
-  }
-  unsigned used = 0;
-  for (int q = 0; q < executed; ++q)
-    if (pr->res.plan.blocks[q] > 1) used += (unsigned)pr->res.plan.blocks[q];
-  ctx->ticket_base = pr->res.ticket0 + used;
-  ctx->mailbox_seq = pr->res.seq0 + (u64)executed - 1;
-  // tables: the outputs of the last phase the host consumed are the prover's current tables
-  if (pr->res.next_phase > 0) {
-    const int lp = pr->res.next_phase - 1;
-    u64* ca = (lp & 1) ? pr->res.QA : pr->res.PA;
-    u64* cb = (lp & 1) ? pr->res.QB : pr->res.PB;
-    if (pr->own_a != ca) pool_release(ctx, pr->own_a);
-    if (pr->own_b != cb) pool_release(ctx, pr->own_b);
-    pr->own_a = ca;
-    pr->own_b = cb;
-  }
-  u64** bufs[4] = {&pr->res.PA, &pr->res.PB, &pr->res.QA, &pr->res.QB};
-  for (u64** bp : bufs) {
-    if (*bp && *bp != pr->own_a && *bp != pr->own_b) pool_release(ctx, *bp);
-    *bp = nullptr;
-  }
-  pr->res.live = false;
-  if (ctx->live_resident == pr) ctx->live_resident = nullptr;
-}
-
-// End a live resident kernel early (another call needs the stream, or the prover is destroyed): the
-// abort command parks it before its next phase; the prover continues with ordinary launches.
-void resident_retire(sc_ctx* ctx) {
-  sc_prover* pr = ctx->live_resident;
-  if (!pr || !pr->res.live) {
-    ctx->live_resident = nullptr;
-    return;
-  }
-  // the kernel may be in any phase >= next_phase - 1; an abort word for EVERY later phase would be needed to
-  // stop it at once, so write the one it will look for next and let the park timeout cover the rest
-  for (int q = std::max(pr->res.next_phase, 1); q < pr->res.plan.n_phases; ++q) {
-    __atomic_store_n(ctx->h_cmd, sc::kCmdPark | (pr->res.cmd_base + (u64)q), __ATOMIC_RELEASE);   // block 0 acts on word 0 alone
-    if (hipStreamQuery(ctx->stream) == hipSuccess) break;
-    // give the kernel a moment to see it before trying the next phase's abort word
-    auto t0 = std::chrono::steady_clock::now();
-    while (hipStreamQuery(ctx->stream) == hipErrorNotReady &&
-           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 200e-6) {
-      __builtin_ia32_pause();
-    }
-    if (hipStreamQuery(ctx->stream) == hipSuccess) break;
-  }
-  (void)hipStreamSynchronize(ctx->stream);
-  resident_settle(pr, -1);
-}
-
-// consume phase p's sums from the mailbox; returns 1 if the kernel parked before phase p instead
-int resident_collect(sc_prover* pr, int p, int* parked) {
-  sc_ctx* ctx = pr->ctx;
-  const u64 seq = pr->res.seq0 + (u64)p;
-  const u64* flag = ctx->h_mailbox + sc::kMailboxSeq;
-  const u64* park = ctx->h_mailbox + sc::kMailboxParked;
-  unsigned spins = 0;
-  auto t0 = std::chrono::steady_clock::now();
-  *parked = 0;
-  while (__atomic_load_n(flag, __ATOMIC_ACQUIRE) != seq) {
-    if (__atomic_load_n(park, __ATOMIC_ACQUIRE) == (u64)p + 1) {
-      *parked = 1;
-      return SC_OK;
-    }
-    if ((++spins & 0x3FFF) == 0) {
-      hipError_t q = hipStreamQuery(ctx->stream);
-      double el = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-      if ((q != hipSuccess && q != hipErrorNotReady) || (q == hipSuccess && el > 2.0) || el > 120.0) {
-        // a finished stream with neither word set can still be a park whose store we raced with
-        if (__atomic_load_n(park, __ATOMIC_ACQUIRE) == (u64)p + 1) {
-          *parked = 1;
-          return SC_OK;
-        }
-        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
-        poison(ctx);
-        return fail(ctx, SC_ERR_HIP, "resident kernel: phase %d never reported (%s)", p,
-                    q == hipSuccess || q == hipErrorNotReady ? "timed out" : hipGetErrorString(q));
-      }
-    }
-    __builtin_ia32_pause();
-  }
-  const int ks = pr->res.plan.ks[p];
-  const int ns = ks == 1 ? 3 : ks == 2 ? 9 : 27;
-  HostField hf(ctx->fp);
-  for (int s = 0; s < ns; ++s) pr->S[s] = hf.recombine(ctx->h_mailbox[2 * s], ctx->h_mailbox[2 * s + 1]);
-  return SC_OK;
-}
-
-// bookkeeping after phase p's sums arrived: the tables are the phase's outputs now
-void resident_advance(sc_prover* pr, int p, size_t j) {
-  u64* oa = (p & 1) ? pr->res.QA : pr->res.PA;
-  u64* ob = (p & 1) ? pr->res.QB : pr->res.PB;
-  // the previous current tables stay allocated while the kernel may still read them: own_* of the launch
-  // (phase 0's inputs) are released when the kernel has left the stream
-  pr->cur_a = oa;
-  pr->cur_b = ob;
-  pr->cur_log -= pr->res.plan.kf[p];
-  pr->pending.clear();
-  pr->cache_ks = pr->res.plan.ks[p];
-  pr->g_known = -1;
-  pr->cache_round = j;
-  pr->res.next_phase = p + 1;
-}
-
-// Try to hand the rest of the proof to the resident kernel.  *started = false: not applicable here.
-int resident_start(sc_prover* pr, size_t j, bool* started) {
-  sc_ctx* ctx = pr->ctx;
-  *started = false;
-  const int kf0 = (int)pr->pending.size();
-  if (!ctx->resident || !ctx->use_mailbox || ctx->vars_per_pass != 2 || pr->sharded || kf0 < 1 || kf0 > 3 ||
-      pr->cur_log > ctx->resident_log || ctx->live_resident)
+    *fa = ga;
+    *fb = gb;
     return SC_OK;
-  const int cap = resident_capacity(ctx);
-  if (cap < 1) return SC_OK;
-  sc::ResidentPlan plan;
-  memset(&plan, 0, sizeof(plan));
-  int cur_log = pr->cur_log, kf = kf0, n = 0;
-  size_t jj = j;
-  const int grid_cap = std::min(cap, (int)ctx->partial_rows);
-  while (jj < pr->num_vars) {
-    if (n == sc::kMaxResidentPhases) return SC_OK;
-    const int ks = pass_rounds(ctx, pr->num_vars, jj, kf, cur_log);
-    if (cur_log < kf + ks) return SC_OK;
-    plan.kf[n] = kf;
-    plan.ks[n] = ks;
-    plan.log_in[n] = cur_log;
-    const size_t n_out = (size_t)1 << (cur_log - kf);
-    // streaming body: the (2,2) pass on tables too large for one thread per output to keep up
-    plan.big[n] = (kf == 2 && ks == 2 && cur_log > ctx->tail_pass_log) ? 1 : 0;
-    const size_t want = plan.big[n] ? ((n_out / 4 + sc::kWave - 1) / sc::kWave + 3) / 4 : (n_out + sc::kBlock - 1) / sc::kBlock;
-    int blocks = (int)std::min<size_t>(std::max<size_t>(want, 1), (size_t)grid_cap);
-    if (n > 0) blocks = std::min(blocks, plan.blocks[n - 1]);
-    plan.blocks[n] = blocks;
-    cur_log -= kf;
-    kf = ks;
-    jj += ks;
-    ++n;
   }
-  if (n < 2) return SC_OK;   // a single pass left: nothing to save
-  plan.n_phases = n;
-
-  u64 *PA = nullptr, *PB = nullptr, *QA = nullptr, *QB = nullptr;
-  const size_t lenP = (size_t)1 << (plan.log_in[0] - plan.kf[0]);
-  const size_t lenQ = (size_t)1 << (plan.log_in[1] - plan.kf[1]);
-  int rc = pool_alloc(ctx, lenP, &PA);
-  if (rc == SC_OK) rc = pool_alloc(ctx, lenP, &PB);
-  if (rc == SC_OK) rc = pool_alloc(ctx, lenQ, &QA);
-  if (rc == SC_OK) rc = pool_alloc(ctx, lenQ, &QB);
+  SC_TRY(gather_table(ctx, a, len, fa));
+  const int rc = gather_table(ctx, b, len, fb);
   if (rc != SC_OK) {
-    pool_release(ctx, PA);
-    pool_release(ctx, PB);
-    pool_release(ctx, QA);
-    pool_release(ctx, QB);
-    return rc;
+    pool_release(ctx, *fa);
+    *fa = nullptr;
   }
-  const sc::FoldW fw0 = make_fold_weights(ctx, pr->pending.data(), kf0);
-  sc::PassOut out;
-  out.partials = ctx->d_partials;
-  out.n_rows = (int)ctx->partial_rows;
-  out.ticket = ctx->d_ticket;
-  out.ticket_base = ctx->ticket_base;
-  out.sums_dev = ctx->d_sums;
-  out.mailbox = ctx->d_mailbox;
-  out.seq = ctx->mailbox_seq + 1;
-  sc::ResidentCtl ctl;
-  ctl.host_cmd = ctx->d_cmd_host;
-  ctl.dev_cmd = ctx->d_cmd;
-  ctl.cmd_base = ctx->cmd_seq;
-  ctl.park_ticks = (u64)ctx->park_ms * 100000ull;   // wall_clock64 runs at 100 MHz
-  ctl.stamps = ctx->resident_stamps ? ctx->d_cmd + 64 : nullptr;
-  __atomic_store_n(ctx->h_mailbox + sc::kMailboxParked, (u64)0, __ATOMIC_RELEASE);
-  u64 bytes_r = 0, bytes_w = 0;
-  int rounds = 0;
-  for (int q = 0; q < n; ++q) {
-    bytes_r += (u64)16 << plan.log_in[q];
-    bytes_w += (u64)16 << (plan.log_in[q] - plan.kf[q]);
-    rounds += plan.ks[q];
-  }
-  rc = timer_begin(ctx, SC_KIND_TAIL_RESIDENT, n, rounds, plan.log_in[0], bytes_r, bytes_w);
-  if (rc == SC_OK) {
-    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::resident_kernel<F>), dim3(plan.blocks[0]), dim3(sc::kBlock), 0,
-                                                    ctx->stream, f, pr->cur_a, pr->cur_b, PA, PB, QA, QB, fw0, plan, out, ctl));
-    hipError_t le = hipGetLastError();
-    if (le != hipSuccess) {
-      poison(ctx);
-      rc = fail(ctx, SC_ERR_HIP, "resident kernel launch: %s", hipGetErrorString(le));
-    }
-  }
-  if (rc == SC_OK) rc = timer_end(ctx);
-  if (rc != SC_OK) {
-    pool_release(ctx, PA);
-    pool_release(ctx, PB);
-    pool_release(ctx, QA);
-    pool_release(ctx, QB);
-    return rc;
-  }
-  pr->res.live = true;
-  pr->res.plan = plan;
-  pr->res.next_phase = 0;
-  pr->res.seq0 = out.seq;
-  pr->res.cmd_base = ctl.cmd_base;
-  pr->res.ticket0 = ctx->ticket_base;
-  pr->res.PA = PA;
-  pr->res.PB = PB;
-  pr->res.QA = QA;
-  pr->res.QB = QB;
-  ctx->cmd_seq += (u64)n;
-  ctx->live_resident = pr;
-  // until the kernel has left the stream the context's counters are the kernel's: park them past its range
-  unsigned total = 0;
-  for (int q = 0; q < n; ++q)
-    if (plan.blocks[q] > 1) total += (unsigned)plan.blocks[q];
-  ctx->ticket_base += total;
-  ctx->mailbox_seq += (u64)n;
-  *started = true;
-  return SC_OK;
-}
-
-// next phase of a live resident kernel (p >= 1): send the pending challenges, collect the sums.
-// *served = false: the kernel parked; the caller continues with an ordinary pass.
-int resident_next(sc_prover* pr, size_t j, bool* served) {
-  sc_ctx* ctx = pr->ctx;
-  *served = false;
-  const int p = pr->res.next_phase;
-  if (p >= pr->res.plan.n_phases || (int)pr->pending.size() != pr->res.plan.kf[p] ||
-      pass_rounds(ctx, pr->num_vars, j, pr->res.plan.kf[p], pr->cur_log) != pr->res.plan.ks[p]) {
-    // the caller left the planned schedule (an option changed mid-proof): fall back
-    resident_retire(ctx);
-    return SC_OK;
-  }
-  if (p > 0) {
-    // one 64-byte line: challenges and check word first, the sequence word last (release)
-    const u64 seq = pr->res.cmd_base + (u64)p;
-    u64 chk = seq;
-    for (size_t i = 0; i < 3; ++i) {
-      const u64 r = i < pr->pending.size() ? pr->pending[i] : 0;
-      ctx->h_cmd[1 + i] = r;
-      chk ^= r;
-    }
-    ctx->h_cmd[4] = chk;
-    __atomic_store_n(ctx->h_cmd, seq, __ATOMIC_RELEASE);
-    if (ctx->resident_stamps) ctx->dbg_host_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - ctx->dbg_t_collect).count();
-  }
-  int parked = 0;
-  SC_TRY(resident_collect(pr, p, &parked));
-  if (parked) {
-    (void)hipStreamSynchronize(ctx->stream);
-    resident_settle(pr, -1);
-    return SC_OK;
-  }
-  resident_advance(pr, p, j);
-  if (ctx->resident_stamps) ctx->dbg_t_collect = std::chrono::steady_clock::now();
-  // last phase: the kernel has nothing left to read and is leaving the stream by itself
-  if (pr->res.next_phase == pr->res.plan.n_phases) resident_settle(pr, pr->res.plan.n_phases);
-  *served = true;
-  return SC_OK;
+  return rc;
 }
 
 int prover_pass(sc_prover* pr, size_t j) {
   sc_ctx* ctx = pr->ctx;
-  if (pr->res.live) {
-    bool served = false;
-    SC_TRY(resident_next(pr, j, &served));
-    if (served) return SC_OK;
-  } else {
-    bool started = false;
-    SC_TRY(resident_start(pr, j, &started));
-    if (started) {
-      bool served = false;
-      SC_TRY(resident_next(pr, j, &served));
-      if (served) return SC_OK;
-    }
-  }
   const int kf = (int)pr->pending.size();
   int ks = pass_rounds(ctx, pr->num_vars, j, kf, pr->cur_log);
   if (kf > sc::kGridMaxVars) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges", kf);
 
-  // Sharded: pairs (2b, 2b+1) stay shard-local while the local table still has the kf+ks
-  // variables this pass touches; below tail_log the latency of a collective per pass costs
-  // more than finishing redundantly on every rank, so gather once and go on unsharded.
-  const int gather_log = ctx->transport == Transport::kPeer ? std::min(ctx->tail_log, ctx->arena_log) : ctx->tail_log;
-  // (a shard that can go on with five-round passes and their in-kernel exchange is gathered only when it is down to
-  // its pending challenges: 2^kf <= 32 entries)
+  // Sharded: pairs (2b, 2b+1) stay shard-local while the local table still has the kf+ks variables this pass
+  // touches.  A shard that can go on with five-round passes (exchange inside the kernel / one collective per pass)
+  // is gathered only when it is down to its pending challenges: 2^kf <= 32 entries.  Otherwise (grid_sharded 0)
+  // it is gathered at tail_log: below that the latency of a collective per two-round pass costs more than finishing
+  // redundantly on every rank.
   const bool shard_grid = pr->sharded && takes_grid_pass(ctx, true, pr->cur_log, kf, j);
-  // ... and when nothing but those is left, the rounds of the rank bits are one small launch: fold, exchange the
-  // single entries (the gather), cells - instead of a gather launch and a pass on the gathered table
-  if (pr->sharded && !shard_grid && pr->cur_log == kf && ctx->log_world >= 1 && ctx->log_world <= 3 &&
-      pr->num_vars - j == (size_t)ctx->log_world && takes_grid_pass(ctx, true, pr->cur_log + 1, kf, j)) {
+  // ... and on the peer transport, when nothing but the pending challenges is left, the rounds of the rank bits are
+  // one small launch: fold, exchange the single entries (the gather), cells - instead of a gather launch and a pass
+  // on the gathered table
+  if (pr->sharded && !shard_grid && ctx->transport == Transport::kPeer && pr->cur_log == kf && ctx->log_world >= 1 &&
+      ctx->log_world <= 3 && pr->num_vars - j == (size_t)ctx->log_world && takes_grid_pass(ctx, true, pr->cur_log + 1, kf, j)) {
     u64 *na = nullptr, *nb = nullptr;
     SC_TRY(pool_alloc(ctx, (size_t)ctx->world, &na));
     int rc = pool_alloc(ctx, (size_t)ctx->world, &nb);
@@ -2434,28 +2216,9 @@ int prover_pass(sc_prover* pr, size_t j) {
     pr->g_known = -1;
     return SC_OK;
   }
-  if (pr->sharded && !shard_grid && ctx->transport == Transport::kPeer && (pr->cur_log < kf + ks || pr->cur_log <= gather_log)) {
-    // the peers write their shards straight into this rank's arena; the gathered tables live there
-    const u64 *fa = nullptr, *fb = nullptr;
-    SC_TRY(peer_gather(ctx, pr->cur_a, pr->cur_b, (size_t)1 << pr->cur_log, &fa, &fb));
-    pool_release(ctx, pr->own_a);
-    pool_release(ctx, pr->own_b);
-    pr->own_a = nullptr;
-    pr->own_b = nullptr;
-    pr->cur_a = fa;
-    pr->cur_b = fb;
-    pr->cur_log += ctx->log_world;
-    pr->sharded = false;
-  }
-  if (pr->sharded && ctx->transport != Transport::kPeer && (pr->cur_log < kf + ks || pr->cur_log <= ctx->tail_log)) {
+  if (pr->sharded && !shard_grid && (pr->cur_log < kf + ks || pr->cur_log <= ctx->tail_log)) {
     u64 *fa = nullptr, *fb = nullptr;
-    size_t len = (size_t)1 << pr->cur_log;
-    SC_TRY(gather_table(ctx, pr->cur_a, len, &fa));
-    int rc = gather_table(ctx, pr->cur_b, len, &fb);
-    if (rc != SC_OK) {
-      pool_release(ctx, fa);
-      return rc;
-    }
+    SC_TRY(gather_pair(ctx, pr->cur_a, pr->cur_b, (size_t)1 << pr->cur_log, &fa, &fb));
     pool_release(ctx, pr->own_a);
     pool_release(ctx, pr->own_b);
     pr->own_a = fa;
@@ -2558,17 +2321,6 @@ void prover_answer(const sc_prover* pr, size_t j, u64 e[3]) {
   e[2] = eval2_from_inf(hf, h[0], h[1], h[2]);
 }
 
-// marks a call as coming from the prover that owns the context's live resident kernel (set_device()
-// retires the kernel for every other caller); nests
-struct ResidentOwner {
-  sc_ctx* ctx;
-  bool prev;
-  ResidentOwner(sc_ctx* c, const sc_prover* pr) : ctx(c), prev(c->in_resident_owner) {
-    c->in_resident_owner = prev || (c->live_resident != nullptr && c->live_resident == pr);
-  }
-  ~ResidentOwner() { ctx->in_resident_owner = prev; }
-};
-
 bool cache_covers(const sc_prover* pr, size_t j) {
   if (pr->cache_ks == 0 || j < pr->cache_round) return false;
   const size_t known = j - pr->cache_round;
@@ -2638,7 +2390,6 @@ extern "C" int sc_prover_round(sc_prover* pr, uint64_t r_prev, size_t j, uint64_
     return fail(ctx, SC_ERR_STATE, "sc_prover_round: expected round %zu, got %zu", pr->next_round, j);
   if (j >= pr->num_vars) return fail(ctx, SC_ERR_STATE, "sc_prover_round: all %zu rounds done", pr->num_vars);
   if (r_prev >= ctx->fp.p && j != 0) return fail(ctx, SC_ERR_ARG, "sc_prover_round: challenge is not reduced");
-  ResidentOwner own(ctx, pr);   // this call may talk to the prover's own resident kernel
   SC_TRY(set_device(ctx));
   if (j != 0) pr->pending.push_back(r_prev);  // sum-check-protocol/src/lib.rs:106-109
   if (!cache_covers(pr, j)) {
@@ -2655,10 +2406,6 @@ extern "C" int sc_prover_round(sc_prover* pr, uint64_t r_prev, size_t j, uint64_
 
 extern "C" int sc_prover_destroy(sc_prover* pr) {
   if (!pr) return SC_OK;
-  if (pr->res.live && pr->ctx->live_resident == pr) {
-    (void)hipSetDevice(pr->ctx->device);
-    resident_retire(pr->ctx);
-  }
   pool_release(pr->ctx, pr->own_a);
   pool_release(pr->ctx, pr->own_b);
   delete pr;
@@ -3049,30 +2796,12 @@ int gkr_start_phase(sc_gkr_prover* pr, int which) {
       if (rc == SC_OK) rc = fold_chain(ctx, pr->mul, pr->add_len, pr->r.data(), (size_t)pr->kb, SC_ORDER_LE, &Y, &lm);
       if (rc == SC_OK && sharded_dense) {
         // every rank holds its rows of c: gather the whole 2^kc-entry tables
-        if (ctx->transport == Transport::kPeer) {
-          const u64 *fa = nullptr, *fb = nullptr;
-          u64 *gx = nullptr, *gy = nullptr;
-          rc = peer_gather(ctx, X, Y, la, &fa, &fb);
-          if (rc == SC_OK) rc = pool_alloc(ctx, n, &gx);
-          if (rc == SC_OK) rc = pool_alloc(ctx, n, &gy);
-          if (rc == SC_OK) {
-            hipError_t e = hipMemcpyAsync(gx, fa, n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipMemcpyAsync(gy, fb, n * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream);
-            if (e != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "gkr gather copy: %s", hipGetErrorString(e));
-          }
-          pool_release(ctx, X);
-          pool_release(ctx, Y);
-          X = gx;
-          Y = gy;
-        } else {
-          u64 *gx = nullptr, *gy = nullptr;
-          rc = gather_table(ctx, X, la, &gx);
-          if (rc == SC_OK) rc = gather_table(ctx, Y, lm, &gy);
-          pool_release(ctx, X);
-          pool_release(ctx, Y);
-          X = gx;
-          Y = gy;
-        }
+        u64 *gx = nullptr, *gy = nullptr;
+        rc = gather_pair(ctx, X, Y, la, &gx, &gy);
+        pool_release(ctx, X);
+        pool_release(ctx, Y);
+        X = gx;
+        Y = gy;
       }
     }
   }
@@ -3192,7 +2921,6 @@ extern "C" int sc_gkr_prover_round(sc_gkr_prover* pr, uint64_t r_prev, size_t j,
   if (j != pr->next_round) return fail(ctx, SC_ERR_STATE, "sc_gkr_prover_round: expected round %zu, got %zu", pr->next_round, j);
   if (j >= pr->num_vars) return fail(ctx, SC_ERR_STATE, "sc_gkr_prover_round: all %zu rounds done", pr->num_vars);
   if (j != 0 && r_prev >= ctx->fp.p) return fail(ctx, SC_ERR_ARG, "sc_gkr_prover_round: challenge is not reduced");
-  ResidentOwner own(ctx, pr->sub);
   SC_TRY(set_device(ctx));
   HostField hf(ctx->fp);
   if (j != 0) pr->r.push_back(r_prev);
@@ -3371,7 +3099,6 @@ namespace {
 // Fold the challenges the sub-prover has not applied yet plus `r_last`; hand back its tables.
 int prover_finish(sc_prover* pr, u64 r_last, u64** a_out, u64** b_out, size_t* len_out) {
   sc_ctx* ctx = pr->ctx;
-  if (pr->res.live) resident_retire(ctx);   // the tables must be at rest
   std::vector<u64> rs(pr->pending);   // the sub-prover's own state is left untouched
   rs.push_back(r_last);
   const size_t len = (size_t)1 << pr->cur_log;
@@ -3401,24 +3128,6 @@ int tri_start_phase(sc_tri_prover* tp, const u64* a, const u64* b, size_t len) {
 
 }  // namespace
 
-// All-gather `len` words per rank into a pool buffer of len * world words (any transport)
-static int gather_to_pool(sc_ctx* ctx, const u64* local, size_t len, u64** out_full) {
-  if (ctx->transport == Transport::kPeer) {
-    const u64* fa = nullptr;
-    SC_TRY(peer_gather(ctx, local, nullptr, len, &fa, nullptr));
-    u64* full = nullptr;
-    SC_TRY(pool_alloc(ctx, len * ctx->world, &full));
-    hipError_t e = hipMemcpyAsync(full, fa, len * ctx->world * sizeof(u64), hipMemcpyDeviceToDevice, ctx->stream);
-    if (e != hipSuccess) {
-      pool_release(ctx, full);
-      return fail(ctx, SC_ERR_HIP, "gather copy: %s", hipGetErrorString(e));
-    }
-    *out_full = full;
-    return SC_OK;
-  }
-  return gather_table(ctx, local, len, out_full);
-}
-
 // On a sharded context `adj` is this rank's rows of the adjacency table (top log2(world) bits of the row index
 // = rank).  The n^3 work - the matrix square - is split by rows of P across the ranks; the adjacency table and
 // P are gathered (n^2 words each) and the three product sumchecks on 2^(2k)- and 2^k-entry tables run
@@ -3440,7 +3149,7 @@ extern "C" int sc_tri_prover_create(sc_ctx* ctx, const sc_table* adj, size_t var
   tp->k = (int)var_len;
   int rc = SC_OK;
   if (sharded) {
-    rc = gather_to_pool(ctx, adj->d, adj->len, &tp->adj_full);
+    rc = gather_table(ctx, adj->d, adj->len, &tp->adj_full);
     tp->adj = tp->adj_full;
   }
   const size_t n = (size_t)1 << var_len;
@@ -3465,7 +3174,7 @@ extern "C" int sc_tri_prover_create(sc_ctx* ctx, const sc_table* adj, size_t var
   if (rc == SC_OK && sharded) {
     // every rank computed its rows of P: gather the whole square
     u64* full = nullptr;
-    rc = gather_to_pool(ctx, tp->P + z_begin * n, z_rows * n, &full);
+    rc = gather_table(ctx, tp->P + z_begin * n, z_rows * n, &full);
     if (rc == SC_OK) {
       pool_release(ctx, tp->P);
       tp->P = full;
@@ -3495,7 +3204,6 @@ extern "C" int sc_tri_prover_round(sc_tri_prover* tp, uint64_t r_prev, size_t j,
   if (j != tp->next_round) return fail(ctx, SC_ERR_STATE, "sc_tri_prover_round: expected round %zu, got %zu", tp->next_round, j);
   if (j >= 3 * k) return fail(ctx, SC_ERR_STATE, "sc_tri_prover_round: all %zu rounds done", 3 * k);
   if (j != 0 && r_prev >= ctx->fp.p) return fail(ctx, SC_ERR_ARG, "sc_tri_prover_round: challenge is not reduced");
-  ResidentOwner own(ctx, tp->sub);
   SC_TRY(set_device(ctx));
   if (j != 0) tp->r.push_back(r_prev);
   // a failed round leaves the challenge list as it was, so the round can be retried

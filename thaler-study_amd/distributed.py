@@ -8,6 +8,8 @@ rank produces partial sums; they are summed across ranks as 32-bit limbs in uint
 (a plain u64 sum would wrap mod 2^64, which is wrong mod p) and recombined mod p.
 
 Transports for that sum:
+  * peer (`attach_peer`): the last workgroup of each sharded pass exchanges the limbs with the peers itself
+    through HIP-IPC-mapped inboxes - no collective launch.
   * RCCL inside the library (`Context.comm_init_rccl`): ncclAllReduce on the context's
     stream.  torch.distributed is only the control plane that broadcasts the unique id.
   * host callbacks (`Context.comm_init_host`) - e.g. torch.distributed all_reduce on CPU
@@ -100,18 +102,48 @@ def attach_rccl(ctx, rank, world, group=None):
 
 def attach_peer(ctx, rank, world, group=None):
     """peer transport: export this rank's region, all-gather the IPC handles over the control plane
-    (torch.distributed, any backend that moves Python objects), map the peers' regions"""
+    (torch.distributed, any backend that moves Python objects), map the peers' regions.  The connect ends with the
+    library's hello handshake (every rank has mapped, loaded its code and run a kernel) and self-test.  Every rank
+    takes part in the all-gather whatever happened locally, so a one-sided failure raises on every rank."""
     import torch.distributed as dist
-    handle = ctx.comm_peer_export(rank, world)
+    handle, err = None, None
+    try:
+        handle = ctx.comm_peer_export(rank, world)
+    except Exception as e:
+        err = e
     if world == 1:
         handles = [handle]
     else:
         handles = [None] * world
         dist.all_gather_object(handles, handle, group=group)
+    if err is not None:
+        raise err
+    if any(h is None for h in handles):
+        raise RuntimeError("a peer could not export its region")
     ctx.comm_peer_connect(handles)
 
 
-def attach_default(ctx, rank, world, group=None):
-    """the data-plane transport a multi-GPU run uses unless told otherwise; returns its name"""
-    attach_peer(ctx, rank, world, group)
-    return "peer"
+def attach_default(ctx_factory, rank, world, group=None):
+    """The data-plane transport a multi-GPU run uses unless told otherwise.  `ctx_factory()` makes a fresh Context for
+    this rank.  First choice: the peer transport (no collective launch); its connect runs a hello handshake and an
+    exchange / gather self-test inside the library, and the ranks then agree over the control plane - if it failed on
+    ANY rank (e.g. fine-grained peer memory that does not behave as the kernels assume on this node), every rank
+    falls back to RCCL together.  Returns (ctx, "peer" | "rccl")."""
+    import torch
+    import torch.distributed as dist
+    ctx = ctx_factory()
+    ok = True
+    try:
+        attach_peer(ctx, rank, world, group)
+    except Exception:
+        ok = False
+    if world > 1:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+        ok = int(flag.item()) == 1
+    if ok:
+        return ctx, "peer"
+    ctx.close()
+    ctx = ctx_factory()
+    attach_rccl(ctx, rank, world, group)
+    return ctx, "rccl"
