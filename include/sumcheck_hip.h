@@ -158,13 +158,19 @@ typedef int (*sc_allgather_fn)(void* user, const uint64_t* send, uint64_t* recv,
 int sc_ctx_comm_init_host(sc_ctx* ctx, int rank, int world, sc_allreduce_fn allreduce,
                           sc_allgather_fn allgather, void* user);
 /* Peer transport: the data plane of a one-node run without any collective launch.  Every rank exports a
- * small region of its HBM (an inbox for the per-pass round sums + arenas for the tail gather), maps every
+ * small region of its HBM (an inbox for the per-pass round sums + arenas for gathers), maps every
  * other rank's region (HIP IPC, written over xGMI), and from then on the last workgroup of each sharded
  * pass exchanges its sums with the peers itself and hands the totals to its host (kernels.hpp, PeerX).
  * Up to 8 ranks.  Usage: export on every rank -> all-gather the 64-byte handles by any means (they are
- * plain bytes) -> connect with the world x 64 bytes in rank order.  Sharding semantics are those of
- * sc_ctx_comm_init_rccl.  The challenges every rank feeds to sc_prover_round / returns from `draw` must
- * be identical; the exchange carries a digest of them and a mismatch fails the pass with SC_ERR_STATE. */
+ * plain bytes) -> connect with the world x 64 bytes in rank order.  connect verifies each mapped region's header
+ * (same world and arena size, the expected rank), says hello to every peer and waits (up to "peer_connect_ms") until
+ * every peer has said hello - by then all ranks have mapped, loaded their code and run a kernel - and then runs a
+ * self-test through the real paths (an in-kernel exchange and a gather of known words); a node whose fine-grained
+ * peer memory does not behave as the kernels assume fails here with SC_ERR_RCCL and the caller picks another
+ * transport.  Afterwards the ranks must call the library in lockstep: an in-kernel wait for a peer is bounded by
+ * "peer_spin_ms" (default 2 s).  Sharding semantics are those of sc_ctx_comm_init_rccl.  The challenges every rank
+ * feeds to sc_prover_round / returns from `draw` must be identical; the exchange carries a digest of them and a
+ * mismatch fails the pass with SC_ERR_STATE. */
 int sc_ctx_comm_peer_export(sc_ctx* ctx, int rank, int world, uint8_t handle[64]);
 int sc_ctx_comm_peer_connect(sc_ctx* ctx, const uint8_t* handles);
 /* the same for ranks that are contexts of ONE process (threads; tests): peers[q] = rank q's context */
@@ -255,9 +261,13 @@ int sc_prove(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_draw_fn draw,
  * (gkr-protocol/src/round_polynomial.rs:13-44).  add/mul: tables of kb+kc variables indexed
  * (c << kb) | b; w_b: kb variables, w_c: kc variables (kb = kc = k_{i+1} when the sumcheck
  * starts; b variables are fixed first).
- * Sharded contexts: the prover (sc_gkr_prover_*) is available - add/mul are this rank's rows of c (top
- * log2(world) index bits = rank), w_b and w_c whole on every rank; the generic trait methods (sc_gkr_w_*) and
- * sc_gkr_wiring are single-rank only. */
+ * Sharded contexts: add/mul are this rank's rows of c (top log2(world) index bits = rank), w_b and w_c whole on
+ * every rank.  sc_gkr_wiring builds exactly those shards (every rank passes the whole gate list and keeps the gates
+ * of its rows: no exchange), the prover (sc_gkr_prover_*) and sc_gkr_w_round_sums / _fix_variables / _evaluate work
+ * on them (sums exchanged like a pass's; fix_variables while the variables fixed stay shard-local, i.e. all of b
+ * and all but the top log2(world) of c).  sc_gkr_w_to_evaluations is single-rank only: the reference's output
+ * order is b-major, so a sharded result would need an all-to-all nobody consumes (Prover::new only sums it:
+ * sc_gkr_prover_c1 gives that). */
 
 /* add_i(r_i,.,.) and mul_i(r_i,.,.) of Prover::start_round (gkr-protocol/src/lib.rs:388-416)
  * straight from the gate list of layer i (2^k_i gates: type 0 = add, 1 = mul; inputs index
@@ -313,8 +323,11 @@ int sc_table_restrict_to_line(sc_ctx* ctx, const sc_table* t, const uint64_t* b,
  * three copies f1, f2, f3 of the adjacency MLE (2*var_len variables each before any fixing,
  * idx(i,j,nv) = (i << nv) | j, :168-172).  Variable counts of a partially fixed G follow
  * :53-67.  Sharded contexts: the prover (sc_tri_prover_*) is available - adj is this rank's rows of the
- * adjacency table; the matrix square is split across the ranks, everything else runs replicated.  The generic
- * trait methods (sc_tri_*) are single-rank only. */
+ * adjacency table; the matrix square (the n^3 work) is split across the ranks, the sumchecks on the 2^(2k)- and
+ * 2^k-entry tables run replicated on every rank.  The generic trait methods (sc_tri_*) are single-rank only:
+ * they serve arbitrary partially fixed states by walking all 2^(3k) evaluations like the reference, and a caller on a
+ * sharded node runs them on an unsharded context of any one rank (the replicated fallback; SC_ERR_UNSUPPORTED
+ * otherwise, never a silent wrong answer). */
 
 /* G::to_evaluations (:138-165), order x outer, z inner */
 int sc_tri_to_evaluations(sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const sc_table* f3, size_t var_len,

@@ -1573,9 +1573,12 @@ template <class F>
 __global__ void __launch_bounds__(kBlock)
 gkr_wiring_scatter_kernel(F f, const u64* __restrict__ eq, const int* __restrict__ gate_type,
                           const unsigned* __restrict__ in0, const unsigned* __restrict__ in1, size_t n_gates, int k_next,
-                          u64* __restrict__ add_out, u64* __restrict__ mul_out) {
+                          unsigned row_lo, unsigned rows, u64* __restrict__ add_out, u64* __restrict__ mul_out) {
+  // the outputs hold rows [row_lo, row_lo + rows) of c (all of them unsharded; a rank's shard otherwise)
   for (size_t a = (size_t)blockIdx.x * kBlock + threadIdx.x; a < n_gates; a += (size_t)gridDim.x * kBlock) {
-    u64* slot = (gate_type[a] == 0 ? add_out : mul_out) + (((size_t)in1[a] << k_next) | in0[a]);
+    const unsigned c = in1[a] - row_lo;
+    if (c >= rows) continue;
+    u64* slot = (gate_type[a] == 0 ? add_out : mul_out) + (((size_t)c << k_next) | in0[a]);
     const u64 w = eq[a];
     unsigned long long old = __hip_atomic_load((unsigned long long*)slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     while (true) {

@@ -723,22 +723,28 @@ int rank_pass(sc_ctx* ctx, int kf, const u64* A, const u64* B, u64* A2, u64* B2,
   return SC_OK;
 }
 
-// PassOut of the next launch with `grid` blocks that publishes to the mailbox (unsharded paths).
+// PassOut of the next launch that ends in finish_pass.  across_ranks: its sums are summed over the ranks - inside the
+// kernel on the peer transport (digest = what the ranks must agree on), by a collective on the stream for RCCL (the
+// limbs stay in d_sums), by the host for a host transport.  *from_mailbox tells collect_sums where the limbs are.
 // Nothing is committed here: call commit_pass_out() once the launch is known to be in the stream.
-sc::PassOut next_pass_out(sc_ctx* ctx, int grid) {
-  (void)grid;
+sc::PassOut next_pass_out(sc_ctx* ctx, bool across_ranks = false, unsigned digest = 0, bool* from_mailbox = nullptr) {
+  const bool peer = across_ranks && ctx->transport == Transport::kPeer;
+  const bool mailbox = (ctx->use_mailbox || peer) && !(across_ranks && ctx->transport == Transport::kRccl);
   sc::PassOut out;
   out.partials = ctx->d_partials;
   out.n_rows = (int)ctx->partial_rows;
   out.ticket = ctx->d_ticket;
   out.ticket_base = ctx->ticket_base;
   out.sums_dev = ctx->d_sums;
-  out.mailbox = ctx->use_mailbox ? ctx->d_mailbox : nullptr;
-  out.seq = ctx->use_mailbox ? ctx->mailbox_seq + 1 : 0;
+  out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
+  out.seq = mailbox ? ctx->mailbox_seq + 1 : 0;
+  if (peer) fill_peer(ctx, out.px, digest);
+  if (from_mailbox) *from_mailbox = mailbox;
   return out;
 }
 int commit_pass_out(sc_ctx* ctx, const sc::PassOut& out, int grid) {
   SC_HIP(ctx, hipGetLastError());
+  if (out.px.world > 0) commit_peer(ctx);
   if (out.mailbox) ctx->mailbox_seq += 1;
   if (grid > 1) ctx->ticket_base += (unsigned)grid;
   return SC_OK;
@@ -2446,7 +2452,8 @@ namespace {
 
 struct WView {
   const u64 *add, *mul, *w_b, *w_c;
-  int kb, kc;
+  int kb, kc;       // variables of b and c (global)
+  size_t rows = 0;  // values of c this rank holds (2^kc unsharded)
 };
 
 int check_w(const sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b, const sc_table* w_c,
@@ -2455,11 +2462,15 @@ int check_w(const sc_ctx* ctx, const sc_table* add, const sc_table* mul, const s
   SC_TRY(check_table(ctx, mul, "gkr W"));
   SC_TRY(check_table(ctx, w_b, "gkr W"));
   SC_TRY(check_table(ctx, w_c, "gkr W"));
-  if (is_sharded(ctx)) return fail(ctx, SC_ERR_UNSUPPORTED, "gkr W on a sharded context");
+  // sharded contexts: add and mul are this rank's rows of c (top log2(world) bits of the index = rank), w_b and w_c are
+  // whole on every rank - the layout of sc_gkr_prover_create
   v->kb = log2_of(w_b->len);
   v->kc = log2_of(w_c->len);
-  if (add->len != mul->len || add->len != ((size_t)1 << (v->kb + v->kc)))
-    return fail(ctx, SC_ERR_ARG, "gkr W: add/mul must have num_vars(w_b) + num_vars(w_c) variables");
+  if (add->len != mul->len || add->len * (size_t)ctx->world != ((size_t)1 << (v->kb + v->kc)))
+    return fail(ctx, SC_ERR_ARG, "gkr W: add/mul must have num_vars(w_b) + num_vars(w_c) variables (over all ranks)");
+  if (ctx->world > 1 && v->kc < ctx->log_world)
+    return fail(ctx, SC_ERR_UNSUPPORTED, "sharded gkr W: fewer rows of c than ranks");
+  v->rows = add->len >> v->kb;
   v->add = add->d;
   v->mul = mul->d;
   v->w_b = w_b->d;
@@ -2467,40 +2478,53 @@ int check_w(const sc_ctx* ctx, const sc_table* add, const sc_table* mul, const s
   return SC_OK;
 }
 
-// (H(0), H(1), H(2)) of the current round; the summed variable is w_b's while it has any
+// (H(0), H(1), H(2)) of the current round; the summed variable is w_b's while it has any.  Sharded: every rank sums
+// over its own rows of c (the pairs of the summed variable are shard-local: index bit 0), the limbs are added across
+// the ranks like a pass's.
 int w_round_sums(sc_ctx* ctx, const WView& w, u64 e[3]) {
   if (w.kb + w.kc < 1) return fail(ctx, SC_ERR_ARG, "gkr W: no variable left");
-  const u64* V = w.kb >= 1 ? w.w_b : w.w_c;
-  const int logV = w.kb >= 1 ? w.kb : w.kc;
-  const u64* Fx = w.kb >= 1 ? w.w_c : w.w_b;
-  const size_t n_pieces = ((size_t)1 << (w.kb + w.kc)) / 2;
+  const bool across = is_sharded(ctx);
+  const size_t c0 = across ? (size_t)ctx->rank * w.rows : 0;   // first value of c on this rank
+  const u64 *V, *Fx;
+  int logV;
+  if (w.kb >= 1) {
+    V = w.w_b;
+    logV = w.kb;
+    Fx = w.w_c + c0;
+  } else {
+    if (w.rows < 2) return fail(ctx, SC_ERR_UNSUPPORTED, "sharded gkr W: the summed variable crosses shards");
+    V = w.w_c + c0;
+    logV = log2_of(w.rows);
+    Fx = w.w_b;
+  }
+  const size_t n_pieces = (w.rows << w.kb) / 2;
   int grid = grid_for(ctx, n_pieces);
-  sc::PassOut out;
-  out.partials = ctx->d_partials;
-  out.n_rows = (int)ctx->partial_rows;
-  out.ticket = ctx->d_ticket;
-  out.ticket_base = ctx->ticket_base;
-  out.sums_dev = ctx->d_sums;
-  out.mailbox = ctx->use_mailbox ? ctx->d_mailbox : nullptr;
-  out.seq = ctx->use_mailbox ? ctx->mailbox_seq + 1 : 0;
+  bool mb = false;
+  const u64 dg[1] = {(u64)w.kb << 32 | (u64)w.kc};
+  sc::PassOut out = next_pass_out(ctx, across, challenge_digest(dg, 1, 0, 77), &mb);
   SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_sums_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
                                                   w.add, w.mul, V, logV, Fx, n_pieces, out));
   SC_TRY(commit_pass_out(ctx, out, grid));
-  SC_TRY(collect_sums(ctx, 3, false, ctx->use_mailbox != 0, e));
+  SC_TRY(collect_sums(ctx, 3, across, mb, e));
   HostField hf(ctx->fp);
   e[2] = eval2_from_inf(hf, e[0], e[1], e[2]);
   return SC_OK;
 }
+
+int evaluate_replicated(sc_ctx* ctx, const u64* d, size_t len, const u64* pt, u64* out);
 
 }  // namespace
 
 extern "C" int sc_gkr_wiring(sc_ctx* ctx, const int32_t* gate_type, const uint32_t* in0, const uint32_t* in1, size_t k_i,
                              size_t k_next, const uint64_t* r_i, sc_table** add_out, sc_table** mul_out) {
   if (!ctx || !gate_type || !in0 || !in1 || (k_i && !r_i) || !add_out || !mul_out) return SC_ERR_ARG;
-  if (is_sharded(ctx)) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_gkr_wiring on a sharded context");
   if (k_i > 30 || k_next > 15) return fail(ctx, SC_ERR_ARG, "sc_gkr_wiring: layer too large");
+  if (ctx->world > 1 && k_next < (size_t)ctx->log_world) return fail(ctx, SC_ERR_UNSUPPORTED, "sc_gkr_wiring: fewer rows of c than ranks");
   SC_TRY(set_device(ctx));
-  const size_t n_gates = (size_t)1 << k_i, n_next = (size_t)1 << k_next, len = n_next * n_next;
+  // sharded: every rank gets the whole gate list and keeps the gates whose c (= in1) falls into its rows - the shard
+  // (top log2(world) index bits = rank) of the tables, with no exchange
+  const size_t n_gates = (size_t)1 << k_i, n_next = (size_t)1 << k_next, rows = n_next / (size_t)ctx->world, len = rows * n_next;
+  const unsigned row_lo = (unsigned)((size_t)ctx->rank * rows);
   for (size_t a = 0; a < n_gates; ++a) {
     if ((gate_type[a] != 0 && gate_type[a] != 1) || in0[a] >= n_next || in1[a] >= n_next)
       return fail(ctx, SC_ERR_ARG, "sc_gkr_wiring: gate %zu is malformed", a);
@@ -2525,7 +2549,7 @@ extern "C" int sc_gkr_wiring(sc_ctx* ctx, const int32_t* gate_type, const uint32
       SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_wiring_scatter_kernel<F>), dim3(grid_for_wide(ctx, n_gates)),
                                                       dim3(sc::kBlock), 0, ctx->stream, f, (const u64*)eq, (const int*)d_type,
                                                       (const unsigned*)d_in0, (const unsigned*)d_in1, n_gates, (int)k_next,
-                                                      ta->d, tm->d));
+                                                      row_lo, (unsigned)rows, ta->d, tm->d));
       e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
@@ -2548,6 +2572,9 @@ extern "C" int sc_gkr_w_to_evaluations(sc_ctx* ctx, const sc_table* add, const s
   if (!ctx || !out) return SC_ERR_ARG;
   WView w;
   SC_TRY(check_w(ctx, add, mul, w_b, w_c, &w));
+  // the reference's output order is b-major while the shards are rows of c: a sharded result would need an all-to-all
+  // nobody consumes (Prover::new only sums it: sc_gkr_prover_c1 / the round sums give that)
+  if (is_sharded(ctx) && ctx->world > 1) return fail(ctx, SC_ERR_UNSUPPORTED, "gkr W to_evaluations on a sharded context");
   SC_TRY(set_device(ctx));
   sc_table* t = nullptr;
   SC_TRY(new_table(ctx, add->len, &t));
@@ -2609,8 +2636,8 @@ extern "C" int sc_gkr_w_evaluate(sc_ctx* ctx, const sc_table* add, const sc_tabl
   u64 ae = 0, me = 0, wb = 0, wc = 0;
   SC_TRY(sc_table_evaluate(ctx, add, point, n, SC_ORDER_LE, &ae));
   SC_TRY(sc_table_evaluate(ctx, mul, point, n, SC_ORDER_LE, &me));
-  SC_TRY(sc_table_evaluate(ctx, w_b, point, (size_t)w.kb, SC_ORDER_LE, &wb));
-  SC_TRY(sc_table_evaluate(ctx, w_c, point + w.kb, (size_t)w.kc, SC_ORDER_LE, &wc));
+  SC_TRY(evaluate_replicated(ctx, w_b->d, w_b->len, point, &wb));          // whole on every rank
+  SC_TRY(evaluate_replicated(ctx, w_c->d, w_c->len, point + w.kb, &wc));
   HostField hf(ctx->fp);
   *out = hf.add(hf.mul(ae, hf.add(wb, wc)), hf.mul(me, hf.mul(wb, wc)));   // round_polynomial.rs:56
   return SC_OK;
@@ -3022,7 +3049,7 @@ extern "C" int sc_tri_round_sums(sc_ctx* ctx, const sc_table* f1, const sc_table
   if (v.xv + v.yv + v.zv < 1) return fail(ctx, SC_ERR_ARG, "triangle G: no variable left");
   const size_t total = (size_t)1 << (v.xv + v.yv + v.zv - 1);
   const int grid = grid_for_wide(ctx, total);
-  sc::PassOut out = next_pass_out(ctx, grid);
+  sc::PassOut out = next_pass_out(ctx);
   SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::tri_sums_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
                                                   v.f1, v.f2, v.f3, v.xv, v.yv, v.zv, out));
   SC_TRY(commit_pass_out(ctx, out, grid));
