@@ -19,6 +19,11 @@ barrier-bracketed region of exactly K proofs: the in-kernel exchange through pee
 (one ncclAllReduce of the pass's split limbs, the collective BASELINE.json names); `value` is the faster one,
 `config.transports` carries both with the rank count each transport reports (ncclCommCount for RCCL).
 
+--workload gkr | gnew | triangle.  The callers either side of the path (BASELINE configs[4] names gkr and the
+matrix-multiplication prover): one GKR layer's W sumcheck at k = 13, matrix_multiplication::G::new at n = 14, the
+triangle-counting prover at k = 10 - each with its own roofline object from the launch log, a parity gate inside the run
+and the oracle's reference-shaped CPU run of a bounded sample as cpu_baseline.
+
 --workload mle.  BASELINE.json configs[1]: multilinear-extensions evaluate + fix_variable on ONE table
 of 2^n entries (n = 24 by default; --num-vars 28 for the large shape).  One step = evaluate (LE),
 evaluate (BE = vsbw_/cti_multilinear_from_evaluations), fix_variables of k = 1, 3 and n/2 low variables.
@@ -69,18 +74,20 @@ def kernel_name(rec):
     k = rec["kind"]
     if k == "pass":
         return "sc::pass_kernel<GoldilocksMont,%d,%d> on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
-    if k == "tail_pass":
-        return "sc::grid_pass3_kernel<GoldilocksMont> (kf=%d, ks=3; small_pass3_kernel with mid_pass=0) on 2^%d-entry tables" % (rec["kf"], rec["log_in"])
     if k == "grid_pass":
         return "sc::wgrid_pass_kernel<GoldilocksMont,ks> (kf=%d, ks=%d) on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
-    if k == "tail_resident":
-        return "sc::tail_resident_kernel<GoldilocksMont> from 2^%d-entry tables (%d rounds)" % (rec["log_in"], rec["ks"])
     if k == "evaluate":
         return "sc::evaluate_kernel<GoldilocksMont> on a 2^%d-entry table" % rec["log_in"]
     if k == "fold":
         return "sc::fold_kernel<GoldilocksMont,%d> on a 2^%d-entry table" % (rec["kf"], rec["log_in"])
     if k == "fix_low":
         return "sc::fix_low_kernel<GoldilocksMont> (%d variables) on a 2^%d-entry table" % (rec["kf"], rec["log_in"])
+    if k == "gkr":
+        return "sc::gkr_phase1_kernel<GoldilocksMont> (P and L over 2^%d rows of c) on 2^%d-entry add/mul tables" % (rec["kf"], rec["log_in"])
+    if k == "coldot":
+        return "sc::coldot_kernel<GoldilocksMont> (2^%d rows) on a 2^%d-entry table" % (rec["kf"], rec["log_in"])
+    if k == "matsq":
+        return "sc::matsq_tiled_kernel<GoldilocksMont> on a 2^%d-entry adjacency table" % rec["log_in"]
     return "%s kf=%d ks=%d 2^%d" % (k, rec["kf"], rec["ks"], rec["log_in"])
 
 
@@ -626,6 +633,292 @@ def run_mle(args, pkg, torch, dist, rank, world, local_rank):
     return result
 
 
+def roofline_from_log(log, steps, dominant_kind, traffic_key, note, kernel_ms, n_launch, ms_per_step, alg_bytes):
+    """the `roofline` object of a single-GPU workload whose every launch is timed: dominant kernel = the group of
+    `dominant_kind` launches with the largest share of the step"""
+    kernels = aggregate_launches(log, steps)
+    moved = sum(k["bytes_per_launch"] * k["launches_per_step"] for k in kernels)
+    kernel_ms_per_step = kernel_ms / steps
+    dom = next((k for k in kernels if k["_key"][0] == dominant_kind), kernels[0])
+    tj = load_traffic(traffic_key)
+    traffic = None
+    if tj and dom["kernel"] in tj.get("kernels", {}):
+        traffic = tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
+    return {
+        "bound": "hbm",
+        "kernel": dom["kernel"],
+        "achieved": dom["GBps"],
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "frac": dom["GBps"] / HBM_PEAK_GBS if dom["GBps"] else None,
+        "traffic": traffic,
+        "bytes_per_launch": dom["bytes_per_launch"],
+        "avg_launch_us": dom["avg_us"],
+        "step": {"bytes_moved": moved, "kernel_ms": kernel_ms_per_step, "launches": n_launch / steps,
+                 "frac_of_kernel_time": moved / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms_per_step else None,
+                 "frac_of_wall_time": moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                 "sec8d_algorithmic_bytes": alg_bytes},
+        "kernels": [{k: v for k, v in kk.items() if k != "_key"} for kk in kernels],
+        "note": note,
+    }
+
+
+def timed_steps(args, torch, ctx, step):
+    """W untimed + K timed calls of step() with every launch event-timed; returns (elapsed_s, step_ms, n_launch, kernel_ms, log, last)"""
+    ctx.set_option("time_kernels", 1)
+    for _ in range(args.warmup):
+        step()
+    ctx.launch_log(reset=True)
+    ctx.kernel_time(reset=True)
+    step_ms, last = [], None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        ts = time.perf_counter()
+        last = step()
+        step_ms.append((time.perf_counter() - ts) * 1e3)
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    ctx.set_option("time_kernels", 0)
+    n_launch, kernel_ms = ctx.kernel_time(reset=True)
+    log = ctx.launch_log(reset=True)
+    return elapsed, step_ms, n_launch, kernel_ms, log, last
+
+
+def widened_line(args, metric, value, elapsed, step_ms, config, roofline, cpu):
+    return {"metric": metric, "value": value, "unit": "field mul-adds/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_median": statistics.median(step_ms), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic", "config": config, "roofline": roofline,
+            "cpu_baseline": cpu}
+
+
+def random_layer(pkg, rng, k):
+    gp = pkg.gkr_protocol
+    n = 1 << k
+    kinds = ("add", "mul")
+    return gp.Circuit([gp.CircuitLayer([gp.Gate(kinds[rng.getrandbits(1)], [rng.randrange(n), rng.randrange(n)]) for _ in range(n)])], n)
+
+
+def quadratic_at(F, e, r):
+    return lagrange_at(F, e, r)
+
+
+def run_gkr(args, pkg, torch, dist, rank, world, local_rank):
+    """BASELINE configs[4]'s inner loop on one GPU: the sumcheck of ONE GKR layer (gkr-protocol/src/lib.rs:373-456 drives
+    SumCheckProver<F, W<F>>) with 2^k gates over 2^k values - add_i(r_i,.,.) / mul_i(r_i,.,.) are 4^k-entry tables
+    (k = 13: 2 x 512 MiB), built before the timed region as the reference builds W in start_round.  One step = Prover::new
+    + 2k rounds, every challenge drawn on the host after its round's sums were read back."""
+    import random
+    import numpy as np
+    if world != 1:
+        raise SystemExit("--workload gkr is a single-GPU workload")
+    gp = pkg.gkr_protocol
+    k = args.num_vars if args.num_vars > 0 else 13
+    F = pkg.Field(pkg.GOLDILOCKS)
+    ctx = pkg.Context(F, device=local_rank)
+    rng = random.Random(2026)
+    circuit = random_layer(pkg, rng, k)
+    inputs = [F.from_int(rng.randrange(F.p)) for _ in range(1 << k)]
+    evaluation = circuit.evaluate(F, inputs)
+    r_i = [F.from_int(rng.randrange(F.p)) for _ in range(k)]
+    w = gp.start_round_w(ctx, circuit, evaluation, 0, r_i)
+    seed = pkg.synthetic.SEED_R
+
+    elapsed, step_ms, n_launch, kernel_ms, log, last = timed_steps(args, torch, ctx, lambda: gp.prove_w(ctx, w, seed))
+    c1, evals, ch = last
+
+    # ---- parity gates (outside the timed region) -----------------------------------------------
+    wi = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, k, np.array(evaluation[0], dtype=np.uint64))
+    if c1 != wi.evaluate(r_i):
+        raise SystemExit("PARITY FAILURE: c_1 != W_i~(r_i) at k=%d" % k)
+    problem = check_identities(F, c1, evals, ch, w.evaluate([int(x) for x in ch]))
+    if problem:
+        raise SystemExit("PARITY FAILURE at k=%d: %s" % (k, problem))
+    sparse = gp.SparseLayerProver(ctx, circuit, evaluation, 0, r_i)          # the gate-list prover: same rounds
+    if sparse.c1() != c1 or any(sparse.round_evals(int(ch[j - 1]) if j else F.one, j) != [int(x) for x in evals[j]] for j in range(2 * k)):
+        raise SystemExit("PARITY FAILURE: dense and sparse W provers disagree at k=%d" % k)
+    parity = ["k=%d: c_1 == W_i~(r_i), verifier identities, final W::evaluate, dense == sparse prover every round" % k]
+    # the same layer shape at a size the oracle finishes in seconds, bit for bit; that run is the CPU baseline
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import Oracle
+    o = Oracle(pkg.GOLDILOCKS)
+    kc = min(k, args.cpu_num_vars if args.cpu_num_vars > 0 else 12)
+    crng = random.Random(7)
+    ccirc = random_layer(pkg, crng, kc)
+    cev = ccirc.evaluate(F, [F.from_int(crng.randrange(F.p)) for _ in range(1 << kc)])
+    cr = [F.from_int(crng.randrange(F.p)) for _ in range(kc)]
+    cw = gp.start_round_w(ctx, ccirc, cev, 0, cr)
+    gc1, gev, gch = gp.prove_w(ctx, cw, seed)
+    oadd, omul = cw.add_i.to_evaluations(), cw.mul_i.to_evaluations()
+    ow = np.array(cev[1], dtype=np.uint64)
+    tc = time.perf_counter()
+    ref = o.w_prove(oadd, omul, ow, ow, [int(x) for x in gch])
+    cpu_s = time.perf_counter() - tc
+    if ref["status"] != 0 or ref["c_1"] != gc1 or not np.array_equal(ref["evals"], gev):
+        raise SystemExit("PARITY FAILURE: GPU W prover and the CPU oracle disagree at k=%d" % kc)
+    parity.append("bit-exact vs CPU oracle (sco_w_prove) at k=%d" % kc)
+
+    # algorithmic work of a layer in the two-phase form: P, L: 2 mul-adds per table entry; add(r_b,.), mul(r_b,.): 2 per
+    # entry; two product sumchecks on 2^(k+1)-entry tables.  Bytes: both 4^k-entry tables read twice (DESIGN.md section 5)
+    muladds = lambda kk: 4 * 4**kk + 2 * (5 * 2**(kk + 1) - 7)      # noqa: E731
+    alg_bytes = 32 * 4**k
+    note = ("dominant kernel = gkr_phase1_kernel: one streaming pass over add_i and mul_i (2 x 8 x 4^k bytes) producing P and L; "
+            "bytes from the launch log of this run, duration = HIP events on the library's stream")
+    roof = roofline_from_log(log, args.steps, "gkr", "gkr_k%d" % k, note, kernel_ms, n_launch, elapsed / args.steps * 1e3, alg_bytes)
+    config = {"workload": "GKR layer sumcheck (W round polynomial, dense two-phase prover), 2^%d gates over 2^%d values, add/mul tables "
+                          "of 4^%d entries, Goldilocks (BASELINE configs[4] inner loop on 1 GPU)" % (k, k, k),
+              "k": k, "num_vars": 2 * k, "field_mul_adds_per_step": muladds(k), "algorithmic_bytes_per_step": alg_bytes,
+              "parity_gate": "; ".join(parity),
+              "schedule": [[r["kind"], r["kf"], r["ks"], r["log_in"]] for r in log[: len(log) // args.steps]]}
+    cpu = {"value": muladds(kc) / cpu_s, "unit": "field mul-adds/s", "cores": 1, "host_cores_total": os.cpu_count(), "kind": "port",
+           "sample": "one layer at k=%d (%.1f s): oracle/sc_oracle.c sco_w_prove, the reference-shaped single-thread restatement of "
+                     "W::to_univariate / fix_variables (walks all remaining evaluations every round), credited with the same "
+                     "algorithmic mul-add count" % (kc, cpu_s)}
+    return widened_line(args, "field mul-adds/sec, GKR layer sumcheck (W), k=%d" % k, muladds(k) * args.steps / elapsed, elapsed, step_ms,
+                        config, roof, cpu)
+
+
+def run_gnew(args, pkg, torch, dist, rank, world, local_rank):
+    """BASELINE configs[4]'s polynomial construction on one GPU: matrix_multiplication::G::new
+    (matrix-multiplication/src/lib.rs:77-92) on two 2^n x 2^n matrices (n = 14: 2 GiB each) at a random point: f_a =
+    MLE(A).relabel(0,n,n).fix_variables(point[..n]) as ONE column-dot pass, f_b = MLE(B).fix_variables(point[n..]) as ONE
+    segment-dot pass.  One step = one G::new."""
+    import numpy as np
+    if world != 1:
+        raise SystemExit("--workload gnew is a single-GPU workload")
+    mm, syn = pkg.matrix_multiplication, pkg.synthetic
+    n = args.num_vars if args.num_vars > 0 else 14
+    F = pkg.Field(pkg.GOLDILOCKS)
+    ctx = pkg.Context(F, device=local_rank)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import Oracle
+    o = Oracle(pkg.GOLDILOCKS)
+    A = pkg.DenseMultilinearExtension.generate(ctx, 11, 2 * n)
+    B = pkg.DenseMultilinearExtension.generate(ctx, 12, 2 * n)
+    pt = [int(o.challenge(syn.SEED_PT, t)) for t in range(2 * n)]
+
+    def step():
+        g = mm.G.new_from_tables(ctx, n, A, B, pt)
+        return g
+
+    elapsed, step_ms, n_launch, kernel_ms, log, g = timed_steps(args, torch, ctx, step)
+
+    # ---- parity (outside the timed region) -----------------------------------------------------
+    side = 1 << n
+    bits = lambda v: [F.one if (v >> t) & 1 else F.zero for t in range(n)]   # noqa: E731
+    fa, fb = g.f_a.to_evaluations(), g.f_b.to_evaluations()
+    for z in (0, 1, side - 1, 0x1234 & (side - 1)):
+        if int(fa[z]) != A.evaluate(bits(z) + pt[:n]) or int(fb[z]) != B.evaluate(pt[n:] + bits(z)):
+            raise SystemExit("PARITY FAILURE: G::new entry %d is not the matrix MLE at (z, r) at n=%d" % (z, n))
+    c1, evals, ch = mm.prove(ctx, g, syn.SEED_R)
+    problem = check_identities(F, c1, evals, ch, g.evaluate([int(x) for x in ch]))
+    if problem:
+        raise SystemExit("PARITY FAILURE at n=%d: %s" % (n, problem))
+    parity = ["n=%d: f_a[z] == A~(r1, z), f_b[z] == B~(z, r2) at sampled z; the proof on (f_a, f_b) passes the verifier identities" % n]
+    nc = min(n, args.cpu_num_vars if args.cpu_num_vars > 0 else 12)
+    oa, ob = o.generate(11, 2 * nc), o.generate(12, 2 * nc)
+    opt = np.array(pt[:nc] + pt[n:n + nc], dtype=np.uint64)
+    tc = time.perf_counter()
+    ofa, ofb = o.g_new(nc, oa, ob, opt)
+    cpu_s = time.perf_counter() - tc
+    Ac = pkg.DenseMultilinearExtension.generate(ctx, 11, 2 * nc)
+    Bc = pkg.DenseMultilinearExtension.generate(ctx, 12, 2 * nc)
+    gc = mm.G.new_from_tables(ctx, nc, Ac, Bc, [int(x) for x in opt])
+    if not np.array_equal(gc.f_a.to_evaluations(), ofa) or not np.array_equal(gc.f_b.to_evaluations(), ofb):
+        raise SystemExit("PARITY FAILURE: GPU G::new and the CPU oracle disagree at n=%d" % nc)
+    parity.append("bit-exact vs CPU oracle (sco_g_new) at n=%d" % nc)
+
+    muladds = lambda nn: 2 * 4**nn                     # noqa: E731  every entry of A and of B enters one multiply-add
+    alg_bytes = 16 * 4**n + 16 * 2**n
+    note = ("dominant kernel = coldot_kernel (f_a: one pass over A against eq(point[..n]), no transposed copy); fix_low_kernel is the "
+            "f_b half; bytes from the launch log of this run")
+    roof = roofline_from_log(log, args.steps, "coldot", "gnew_n%d" % n, note, kernel_ms, n_launch, elapsed / args.steps * 1e3, alg_bytes)
+    config = {"workload": "matrix_multiplication::G::new on two 2^%d x 2^%d Goldilocks matrices (2^%d entries each) at a random point "
+                          "(BASELINE configs[4] polynomial construction on 1 GPU)" % (n, n, 2 * n),
+              "n": n, "num_vars": 2 * n, "field_mul_adds_per_step": muladds(n), "algorithmic_bytes_per_step": alg_bytes,
+              "parity_gate": "; ".join(parity),
+              "schedule": [[r["kind"], r["kf"], r["ks"], r["log_in"]] for r in log[: len(log) // args.steps]]}
+    cpu = {"value": muladds(nc) / cpu_s, "unit": "field mul-adds/s", "cores": 1, "host_cores_total": os.cpu_count(), "kind": "port",
+           "sample": "G::new at n=%d (%.1f s): oracle/sc_oracle.c sco_g_new, the reference-shaped single-thread restatement (relabel = "
+                     "full-table swap pass, then n one-variable folds with per-call table copies)" % (nc, cpu_s)}
+    return widened_line(args, "field mul-adds/sec, matrix_multiplication::G::new, n=%d" % n, muladds(n) * args.steps / elapsed, elapsed,
+                        step_ms, config, roof, cpu)
+
+
+def run_triangle(args, pkg, torch, dist, rank, world, local_rank):
+    """triangle_counting::G (SURVEY 8f rank 2) on one GPU: Prover<F, G> for G::new_adj_matrix on a 2^k-vertex graph
+    (k = 10), all 3k rounds.  One step = Prover::new (the n^3 matrix square) + 3k rounds."""
+    import numpy as np
+    if world != 1:
+        raise SystemExit("--workload triangle is a single-GPU workload")
+    tc_mod = pkg.triangle_counting
+    k = args.num_vars if args.num_vars > 0 else 10
+    F = pkg.Field(pkg.GOLDILOCKS)
+    ctx = pkg.Context(F, device=local_rank)
+    seed = pkg.synthetic.SEED_R
+
+    def graph(kk, s):
+        nn = 1 << kk
+        upper = np.triu(np.random.default_rng(s).random((nn, nn)) < 0.25, 1)
+        return upper | upper.T
+
+    def table(m, kk):
+        ev = np.where(m.flatten(), np.uint64(F.one), np.uint64(0)).astype(np.uint64)
+        t = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2 * kk, ev)
+        return tc_mod.G(t, t, t, kk)
+
+    m = graph(k, 77)
+    g = table(m, k)
+    elapsed, step_ms, n_launch, kernel_ms, log, last = timed_steps(args, torch, ctx, lambda: tc_mod.prove(ctx, g, seed))
+    c1, evals, ch = last
+
+    a = m.astype(np.int64)
+    tri = int(np.trace(a @ a @ a)) // 6
+    if F.to_int(c1) != (6 * tri) % F.p:
+        raise SystemExit("PARITY FAILURE: c_1 != 6 x triangles at k=%d" % k)
+    problem = check_identities(F, c1, evals, ch, g.evaluate([int(x) for x in ch]))
+    if problem:
+        raise SystemExit("PARITY FAILURE at k=%d: %s" % (k, problem))
+    parity = ["k=%d: c_1 == 6 x %d triangles (numpy), verifier identities, final G::evaluate" % (k, tri)]
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    from oracle import Oracle
+    o = Oracle(pkg.GOLDILOCKS)
+    kc = min(k, args.cpu_num_vars if args.cpu_num_vars > 0 else 9)
+    mc = graph(kc, 78)
+    gc = table(mc, kc)
+    gc1, gev, gch = tc_mod.prove(ctx, gc, seed)
+    oadj = np.where(mc.flatten(), np.uint64(F.one), np.uint64(0)).astype(np.uint64)
+    t0 = time.perf_counter()
+    ref = o.tri_prove(oadj, kc, [int(x) for x in gch])
+    cpu_s = time.perf_counter() - t0
+    if ref["status"] != 0 or ref["c_1"] != gc1 or not np.array_equal(ref["evals"], gev):
+        raise SystemExit("PARITY FAILURE: GPU triangle prover and the CPU oracle disagree at k=%d" % kc)
+    parity.append("bit-exact vs CPU oracle (sco_tri_prove) at k=%d" % kc)
+
+    # n^3 multiply-adds of the matrix square, then three product sumchecks (x: 4^k-entry tables, y and z: 2^k), one
+    # column-dot and two k-variable folds over the 4^k-entry table
+    muladds = lambda kk: 8**kk + (5 * 4**kk - 7) + 2 * (5 * 2**kk - 7) + 3 * 4**kk      # noqa: E731
+    alg_bytes = 8 * 4**k * 6
+    note = ("dominant kernel by time is matsq_tiled_kernel (the n^3 multiply-adds of the adjacency square: integer VALU-bound, "
+            "its bytes are n^2 words and say nothing); the roofline object is therefore taken on the dominant STREAMING "
+            "kernel of the proof, the first product-sumcheck pass over the 4^k-entry tables; matsq is reported in `matsq`")
+    roof = roofline_from_log(log, args.steps, "pass", "triangle_k%d" % k, note, kernel_ms, n_launch, elapsed / args.steps * 1e3, alg_bytes)
+    ms_rec = [r for r in log if r["kind"] == "matsq"]
+    if ms_rec:
+        us = sum(r["ms"] for r in ms_rec) / len(ms_rec) * 1e3
+        roof["matsq"] = {"kernel": "sc::matsq_tiled_kernel<GoldilocksMont> on a 2^%d x 2^%d matrix" % (k, k), "avg_launch_us": us,
+                         "field_mul_adds": 8**k, "mul_adds_per_s": 8**k / (us * 1e-6), "bound": "integer VALU (64x64->128 products)"}
+    config = {"workload": "triangle_counting::G prover, 2^%d vertices (adjacency MLE of 2^%d entries), Goldilocks" % (k, 2 * k),
+              "k": k, "num_vars": 3 * k, "field_mul_adds_per_step": muladds(k), "algorithmic_bytes_per_step": alg_bytes,
+              "parity_gate": "; ".join(parity),
+              "schedule": [[r["kind"], r["kf"], r["ks"], r["log_in"]] for r in log[: len(log) // args.steps]]}
+    cpu = {"value": muladds(kc) / cpu_s, "unit": "field mul-adds/s", "cores": 1, "host_cores_total": os.cpu_count(), "kind": "port",
+           "sample": "one proof at k=%d (%.1f s): oracle/sc_oracle.c sco_tri_prove, the reference-shaped single-thread restatement "
+                     "(walks all 2^(3k) evaluations every round), credited with the same algorithmic mul-add count" % (kc, cpu_s)}
+    return widened_line(args, "field mul-adds/sec, triangle_counting::G prover, k=%d" % k, muladds(k) * args.steps / elapsed, elapsed,
+                        step_ms, config, roof, cpu)
+
+
 def self_launch(n_ranks):
     """`python bench.py --gpus N` without a launcher: run `python -m torch.distributed.run ... bench.py <same flags>` as a
     child process (one rank per GPU), relay its stdout and return its exit code"""
@@ -650,9 +943,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", choices=["prover", "mle"], default=os.environ.get("SC_BENCH_WORKLOAD", "prover"))
+    ap.add_argument("--workload", choices=["prover", "mle", "gkr", "gnew", "triangle"], default=os.environ.get("SC_BENCH_WORKLOAD", "prover"))
     ap.add_argument("--num-vars", type=int, default=int(os.environ.get("SC_BENCH_N", "0")),
-                    help="0 = the workload's BASELINE size (prover 28, mle 24)")
+                    help="0 = the workload's BASELINE size (prover n=28, mle n=24, gkr k=13, gnew n=14, triangle k=10)")
     ap.add_argument("--cpu-num-vars", type=int, default=int(os.environ.get("SC_BENCH_CPU_N", "-1")),
                     help="size of the bounded CPU-baseline sample (0 disables; -1 = as large as host memory allows, <= 28)")
     ap.add_argument("--vars-per-pass", type=int, default=2)
@@ -685,7 +978,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)  # control plane only
 
-    run = run_prover if args.workload == "prover" else run_mle
+    run = {"prover": run_prover, "mle": run_mle, "gkr": run_gkr, "gnew": run_gnew, "triangle": run_triangle}[args.workload]
     result = run(args, pkg, torch, dist, rank, world, local_rank)
     if rank == 0:
         print(json.dumps(result), flush=True)

@@ -306,6 +306,10 @@ int sc_gkr_prover_create(sc_ctx* ctx, const sc_table* add, const sc_table* mul, 
 int sc_gkr_prover_create_sparse(sc_ctx* ctx, const int32_t* gate_type, const uint32_t* in0, const uint32_t* in1,
                                 size_t k_i, size_t k_next, const uint64_t* r_i, const sc_table* w_next,
                                 sc_gkr_prover** out);
+/* the whole 2k-round W sumcheck in one call, challenges as in sc_prove (draw == NULL: the synthetic challenger);
+ * evals has 3 * (kb + kc) words, challenges kb + kc */
+int sc_gkr_prove(sc_ctx* ctx, const sc_table* add, const sc_table* mul, const sc_table* w_b, const sc_table* w_c,
+                 sc_draw_fn draw, void* user, uint64_t seed_r, uint64_t* c1, uint64_t* evals, uint64_t* challenges);
 int sc_gkr_prover_c1(const sc_gkr_prover* pr, uint64_t* out);
 int sc_gkr_prover_round(sc_gkr_prover* pr, uint64_t r_prev, size_t j, uint64_t out_e[3]);
 int sc_gkr_prover_destroy(sc_gkr_prover* pr);
@@ -348,6 +352,9 @@ int sc_tri_evaluate(sc_ctx* ctx, const sc_table* f1, const sc_table* f2, const s
  * (f2(r_y,.), f3(r_x,.)) scaled by f1(r_x,r_y).  Same contract as sc_prover_*. */
 typedef struct sc_tri_prover sc_tri_prover;
 int sc_tri_prover_create(sc_ctx* ctx, const sc_table* adj, size_t var_len, sc_tri_prover** out);
+/* all 3 * var_len rounds in one call, challenges as in sc_prove */
+int sc_tri_prove(sc_ctx* ctx, const sc_table* adj, size_t var_len, sc_draw_fn draw, void* user, uint64_t seed_r,
+                 uint64_t* c1, uint64_t* evals, uint64_t* challenges);
 int sc_tri_prover_c1(const sc_tri_prover* pr, uint64_t* out);
 int sc_tri_prover_round(sc_tri_prover* pr, uint64_t r_prev, size_t j, uint64_t out_e[3]);
 int sc_tri_prover_destroy(sc_tri_prover* pr);

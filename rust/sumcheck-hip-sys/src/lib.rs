@@ -256,6 +256,19 @@ extern "C" {
         w_next: *const sc_table,
         out: *mut *mut sc_gkr_prover,
     ) -> c_int;
+    pub fn sc_gkr_prove(
+        ctx: *mut sc_ctx,
+        add: *const sc_table,
+        mul: *const sc_table,
+        w_b: *const sc_table,
+        w_c: *const sc_table,
+        draw: sc_draw_fn,
+        user: *mut c_void,
+        seed_r: u64,
+        c1: *mut u64,
+        evals: *mut u64,
+        challenges: *mut u64,
+    ) -> c_int;
     pub fn sc_gkr_prover_c1(pr: *const sc_gkr_prover, out: *mut u64) -> c_int;
     pub fn sc_gkr_prover_round(pr: *mut sc_gkr_prover, r_prev: u64, j: usize, out_e: *mut u64) -> c_int;
     pub fn sc_gkr_prover_destroy(pr: *mut sc_gkr_prover) -> c_int;
@@ -312,6 +325,17 @@ extern "C" {
         adj: *const sc_table,
         var_len: usize,
         out: *mut *mut sc_tri_prover,
+    ) -> c_int;
+    pub fn sc_tri_prove(
+        ctx: *mut sc_ctx,
+        adj: *const sc_table,
+        var_len: usize,
+        draw: sc_draw_fn,
+        user: *mut c_void,
+        seed_r: u64,
+        c1: *mut u64,
+        evals: *mut u64,
+        challenges: *mut u64,
     ) -> c_int;
     pub fn sc_tri_prover_c1(pr: *const sc_tri_prover, out: *mut u64) -> c_int;
     pub fn sc_tri_prover_round(pr: *mut sc_tri_prover, r_prev: u64, j: usize, out_e: *mut u64) -> c_int;

@@ -60,3 +60,27 @@ def test_bench_mle_workload():
     assert "fold_kernel" in kinds and "fix_low_kernel" in kinds and "evaluate_kernel" in kinds
     assert d["cpu_baseline"]["value"] > 0
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,size,cpu_size,kernel", [("gkr", 7, 6, "gkr_phase1_kernel"), ("gnew", 9, 8, "coldot_kernel"),
+                                                           ("triangle", 6, 5, "")])
+def test_bench_widened_workloads(workload, size, cpu_size, kernel):
+    """--workload gkr | gnew | triangle: the same JSON contract (roofline from the launch log, cpu_baseline from the oracle
+    on a bounded sample, parity gate inside the run) for the callers either side of the hot path"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", workload, "--num-vars", str(size), "--steps", "4",
+                          "--warmup", "1", "--cpu-num-vars", str(cpu_size)], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["dtype"] == "u64"
+    assert "bit-exact vs CPU oracle" in d["config"]["parity_gate"] and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and 0 < r["frac"] <= 1.0 and kernel in r["kernel"]
+    assert abs(sum(k["bytes_per_launch"] * k["launches_per_step"] for k in r["kernels"]) - r["step"]["bytes_moved"]) < 1
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0

@@ -92,6 +92,7 @@ SIGNATURES = {
     "sc_gkr_prover_create_sparse": (ctypes.c_int, [voidp, ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_uint32),
                                                     ctypes.POINTER(ctypes.c_uint32), size_t, size_t, u64p, voidp,
                                                     ctypes.POINTER(voidp)]),
+    "sc_gkr_prove": (ctypes.c_int, [voidp, voidp, voidp, voidp, voidp, DRAW_FN, voidp, u64, u64p, u64p, u64p]),
     "sc_gkr_prover_c1": (ctypes.c_int, [voidp, u64p]),
     "sc_gkr_prover_round": (ctypes.c_int, [voidp, u64, size_t, u64p]),
     "sc_gkr_prover_destroy": (ctypes.c_int, [voidp]),
@@ -101,6 +102,7 @@ SIGNATURES = {
     "sc_tri_fix_variables": (ctypes.c_int, [voidp, voidp, voidp, voidp, size_t, u64p, size_t] + [ctypes.POINTER(voidp)] * 3),
     "sc_tri_evaluate": (ctypes.c_int, [voidp, voidp, voidp, voidp, size_t, u64p, size_t, u64p]),
     "sc_tri_prover_create": (ctypes.c_int, [voidp, voidp, size_t, ctypes.POINTER(voidp)]),
+    "sc_tri_prove": (ctypes.c_int, [voidp, voidp, size_t, DRAW_FN, voidp, u64, u64p, u64p, u64p]),
     "sc_tri_prover_c1": (ctypes.c_int, [voidp, u64p]),
     "sc_tri_prover_round": (ctypes.c_int, [voidp, u64, size_t, u64p]),
     "sc_tri_prover_destroy": (ctypes.c_int, [voidp]),

@@ -42,6 +42,7 @@ __device__ __forceinline__ void st16(ull2* __restrict__ p, ull2 v) {
 // computed exactly on the host (Montgomery words).  KF = 1 uses w[1] = r0.
 struct FoldW {
   u64 w[8];
+  int reverse = 0;   // pass_kernel: walk the tiles from the end of the tables (see sc_ctx::reverse_log)
 };
 
 // Fold KF variables (LE) of a run of IN entries in registers; the first IN >> KF entries
@@ -676,17 +677,25 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     else accumulate_run<F, KS>(f, acc, a, b);
   };
 
+  // walk order: tile t of the walk is tile t of the tables, or (reverse) tile n_tiles - 1 - t: a folding pass that
+  // starts where the previous pass over the same tables ended finds that end still in the Infinity Cache
   const size_t tile_stride = (size_t)gridDim.x * kWaves;
-  size_t tile = (size_t)blockIdx.x * kWaves + wave;
+  const size_t last = n_tiles - 1;
+  const bool rev = fw.reverse != 0;
+  size_t t = (size_t)blockIdx.x * kWaves + wave;
   if constexpr (kPrefetch) {
     ull2 pa[NP], pb[NP];
-    if (tile < n_tiles) load_tile(tile, pa, pb);
-    for (; tile < n_tiles; tile += tile_stride) process_tile(tile, tile + tile_stride, pa, pb);
+    if (t < n_tiles) load_tile(rev ? last - t : t, pa, pb);
+    for (; t < n_tiles; t += tile_stride) {
+      const size_t nx = t + tile_stride;
+      process_tile(rev ? last - t : t, nx < n_tiles ? (rev ? last - nx : nx) : n_tiles, pa, pb);
+    }
   } else {
-    for (; tile < n_tiles; tile += tile_stride) {
+    for (; t < n_tiles; t += tile_stride) {
       ull2 pa[NP], pb[NP];
+      const size_t tile = rev ? last - t : t;
       load_tile(tile, pa, pb);
-      process_tile(tile, tile + tile_stride, pa, pb);
+      process_tile(tile, n_tiles, pa, pb);
     }
   }
 
@@ -1295,15 +1304,25 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int tb = n - 7 - ta;
-  build_eq_weights(f, rv.v + 7, ta, eqA);   // the tile-in-segment weights
   const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
   const size_t n_tiles = (size_t)1 << (n - 7);
   const size_t n_chunks = n_tiles >> chunk_log;
   const int C = 1 << chunk_log;
+  const size_t chunk_first = (size_t)blockIdx.x * kWaves + wave;
+  // the wave's first eight loads go out BEFORE the weights are built (they do not depend on them): on a 2^24-entry
+  // table the ~1 us of build_eq_weights is otherwise 5 % of the launch with the memory pipe idle
+  ull2 pc[8];
+  bool preloaded = false;
+  if (chunk_first < n_chunks && C >= 8) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) pc[k] = ld16<NT>(Tp + ((chunk_first << chunk_log) + k) * kWave + lane);
+    preloaded = true;
+  }
+  build_eq_weights(f, rv.v + 7, ta, eqA);   // the tile-in-segment weights
   typename F::Acc o0, o1;
   f.acc_zero(o0);
   f.acc_zero(o1);
-  for (size_t chunk = (size_t)blockIdx.x * kWaves + wave; chunk < n_chunks; chunk += (size_t)gridDim.x * kWaves) {
+  for (size_t chunk = chunk_first; chunk < n_chunks; chunk += (size_t)gridDim.x * kWaves) {
     const size_t tile0 = chunk << chunk_log;
     const size_t seg = tile0 >> ta;
     const int in_seg = (int)(tile0 & (((size_t)1 << ta) - 1));
@@ -1314,12 +1333,14 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
     // unroller does not touch loops that contain inline assembly (acc_mac)
     int i = 0;
     for (; i + 8 <= C; i += 8) {
-      ull2 pc[8];
+      if (!preloaded) {
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const size_t q = (tile0 + i + k) * kWave + lane;
-        pc[k] = ld16<NT>(Tp + q);
+        for (int k = 0; k < 8; ++k) {
+          const size_t q = (tile0 + i + k) * kWave + lane;
+          pc[k] = ld16<NT>(Tp + q);
+        }
       }
+      preloaded = false;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const u64 w = eqA[in_seg + i + k];
@@ -1329,10 +1350,10 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
     }
     for (; i < C; ++i) {
       const size_t q = (tile0 + i) * kWave + lane;
-      const ull2 pc = ld16<NT>(Tp + q);
+      const ull2 p1 = ld16<NT>(Tp + q);
       const u64 w = eqA[in_seg + i];
-      f.acc_mac(a0, pc.x, w);
-      f.acc_mac(a1, pc.y, w);
+      f.acc_mac(a0, p1.x, w);
+      f.acc_mac(a1, p1.y, w);
     }
     u64 wB = f.one();  // segment weight, wave-uniform: tb factors per chunk of 2*C products
     for (int j = 0; j < tb; ++j) {
@@ -1370,6 +1391,17 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int ta = k - 7;
+  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+  const int tiles = 1 << ta;
+  const size_t seg_first = (size_t)blockIdx.x * kWaves + wave;
+  // the first eight loads of the wave's first segment go out before the weights are built (see evaluate_kernel)
+  ull2 pc[8];
+  bool preloaded = false;
+  if (seg_first < n_out && tiles >= 8) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) pc[q] = ld16<NT>(Tp + (seg_first << (k - 1)) + lane + (size_t)q * kWave);
+    preloaded = true;
+  }
   build_eq_weights(f, rv.v + 7, ta, eqA);
   u64 wl = f.one();
 #pragma unroll
@@ -1379,18 +1411,18 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
   }
   const u64 r0 = rv.v[0], one_minus_r0 = f.sub(f.one(), r0);
   __syncthreads();
-  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
-  const int tiles = 1 << ta;
-  for (size_t seg = (size_t)blockIdx.x * kWaves + wave; seg < n_out; seg += (size_t)gridDim.x * kWaves) {
+  for (size_t seg = seg_first; seg < n_out; seg += (size_t)gridDim.x * kWaves) {
     const ull2* __restrict__ Sp = Tp + (seg << (k - 1)) + lane;
     typename F::Acc a0, a1;
     f.acc_zero(a0);
     f.acc_zero(a1);
     int i = 0;
     for (; i + 8 <= tiles; i += 8) {
-      ull2 pc[8];
+      if (!preloaded) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) pc[q] = ld16<NT>(Sp + (size_t)(i + q) * kWave);
+        for (int q = 0; q < 8; ++q) pc[q] = ld16<NT>(Sp + (size_t)(i + q) * kWave);
+      }
+      preloaded = false;
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const u64 w = eqA[i + q];
@@ -1399,10 +1431,10 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
       }
     }
     for (; i < tiles; ++i) {
-      const ull2 pc = Sp[(size_t)i * kWave];
+      const ull2 p1 = Sp[(size_t)i * kWave];
       const u64 w = eqA[i];
-      f.acc_mac(a0, pc.x, w);
-      f.acc_mac(a1, pc.y, w);
+      f.acc_mac(a0, p1.x, w);
+      f.acc_mac(a1, p1.y, w);
     }
     u64 v = f.add(f.mul(one_minus_r0, f.acc_get(a0)), f.mul(r0, f.acc_get(a1)));
     v = f.mul(v, wl);
@@ -1620,19 +1652,24 @@ gkr_phase1_kernel(F f, const u64* __restrict__ add, const u64* __restrict__ mul,
     f.acc_zero(p0); f.acc_zero(p1); f.acc_zero(l0); f.acc_zero(l1);
     u64 s0 = 0, s1 = 0;   // sum_c add: plain modular adds
     size_t i = i0;
-    for (; i + 2 <= i1; i += 2) {   // fixed-count inner loop (acc_mac is inline asm: no runtime unrolling)
-      ull2 a[2], m[2];
+    // four rows (eight 16-byte loads) in flight per thread; wiring tables are mostly zero (one non-zero per gate in 4^k
+    // entries), and a piece whose four words are all zero adds nothing: where a whole wave sees zeros the ~70
+    // instructions of a row are skipped (gkr_sums_kernel does the same)
+    for (; i + 4 <= i1; i += 4) {   // fixed-count inner loop (acc_mac is inline asm: no runtime unrolling)
+      ull2 a[4], m[4];
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
+      for (int k = 0; k < 4; ++k) {
         a[k] = ld16<NT>(Ap + (i + k) * mp + pc);
         m[k] = ld16<NT>(Mp + (i + k) * mp + pc);
       }
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const u64 wi = w[i + k];
-        s0 = f.add(s0, a[k].x); s1 = f.add(s1, a[k].y);
-        f.acc_mac(p0, m[k].x, wi); f.acc_mac(p1, m[k].y, wi);
-        f.acc_mac(l0, a[k].x, wi); f.acc_mac(l1, a[k].y, wi);
+      for (int k = 0; k < 4; ++k) {
+        if ((a[k].x | a[k].y | m[k].x | m[k].y) != 0) {
+          const u64 wi = w[i + k];
+          s0 = f.add(s0, a[k].x); s1 = f.add(s1, a[k].y);
+          f.acc_mac(p0, m[k].x, wi); f.acc_mac(p1, m[k].y, wi);
+          f.acc_mac(l0, a[k].x, wi); f.acc_mac(l1, a[k].y, wi);
+        }
       }
     }
     for (; i < i1; ++i) {

@@ -148,7 +148,7 @@ class W(SumCheckPolynomial):
         return _round_poly_from_evals(self.ctx, self.round_evals())
 
     def num_vars(self):
-        return self.add_i.num_vars()
+        return self.w_b.num_vars() + self.w_c.num_vars()    # = add_i's (over all ranks on a sharded context)
 
     def to_evaluations(self):
         h = voidp()
@@ -157,6 +157,19 @@ class W(SumCheckPolynomial):
 
     def native_prover(self):
         return _NativeWProver(self)
+
+
+def prove_w(ctx, w, seed_r, draw=None):
+    """sc_gkr_prove: the whole 2k-round W sumcheck of one layer in one native call (no Python per round).
+    Returns (c_1, evals[n][3], challenges[n])."""
+    from . import _lib
+    n = w.w_b.num_vars() + w.w_c.num_vars()
+    ev = np.zeros(3 * max(n, 1), dtype=np.uint64)
+    ch = np.zeros(max(n, 1), dtype=np.uint64)
+    c1 = u64()
+    cb = _lib.DRAW_FN(draw) if draw is not None else ctypes.cast(None, _lib.DRAW_FN)
+    ctx.check(ctx.lib.sc_gkr_prove(ctx.h, w.add_i.h, w.mul_i.h, w.w_b.h, w.w_c.h, cb, None, seed_r, ctypes.byref(c1), _u64p(ev), _u64p(ch)))
+    return int(c1.value), ev[: 3 * n].reshape(n, 3).copy(), ch[:n].copy()
 
 
 def _gate_arrays(layer):
@@ -209,7 +222,8 @@ def start_round_w(ctx, circuit, evaluation, i, r_i):
     k_next = circuit.num_vars_at(i + 1)
     w_b = DenseMultilinearExtension.from_evaluations_vec(ctx, k_next, np.array(evaluation[i + 1], dtype=np.uint64))
     add_i, mul_i = wiring(ctx, circuit, i, r_i)
-    assert add_i.num_vars() == 2 * w_b.num_vars()                        # :419
+    world = ctx.rank_world()[1]                                          # sharded: add_i / mul_i are this rank's rows of c
+    assert add_i.num_vars() + world.bit_length() - 1 == 2 * w_b.num_vars()   # :419
     return W.new(add_i, mul_i, w_b, w_b)
 
 

@@ -114,3 +114,16 @@ class G(SumCheckPolynomial):
                 and self.f_a_1.num_vars() == 2 * self.var_len):
             return _NativeTriProver(self)
         return None
+
+
+def prove(ctx, g, seed_r, draw=None):
+    """sc_tri_prove: all 3 * var_len rounds of Prover<F, G> for G::new_adj_matrix in one native call.
+    Returns (c_1, evals[n][3], challenges[n])."""
+    from . import _lib
+    n = 3 * g.var_len
+    ev = np.zeros(3 * n, dtype=np.uint64)
+    ch = np.zeros(n, dtype=np.uint64)
+    c1 = u64()
+    cb = _lib.DRAW_FN(draw) if draw is not None else ctypes.cast(None, _lib.DRAW_FN)
+    ctx.check(ctx.lib.sc_tri_prove(ctx.h, g.f_a_1.h, g.var_len, cb, None, seed_r, ctypes.byref(c1), _u64p(ev), _u64p(ch)))
+    return int(c1.value), ev.reshape(n, 3).copy(), ch.copy()
