@@ -42,7 +42,6 @@ __device__ __forceinline__ void st16(ull2* __restrict__ p, ull2 v) {
 // computed exactly on the host (Montgomery words).  KF = 1 uses w[1] = r0.
 struct FoldW {
   u64 w[8];
-  int reverse = 0;   // pass_kernel: walk the tiles from the end of the tables (see sc_ctx::reverse_log)
 };
 
 // Fold KF variables (LE) of a run of IN entries in registers; the first IN >> KF entries
@@ -677,25 +676,17 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     else accumulate_run<F, KS>(f, acc, a, b);
   };
 
-  // walk order: tile t of the walk is tile t of the tables, or (reverse) tile n_tiles - 1 - t: a folding pass that
-  // starts where the previous pass over the same tables ended finds that end still in the Infinity Cache
   const size_t tile_stride = (size_t)gridDim.x * kWaves;
-  const size_t last = n_tiles - 1;
-  const bool rev = fw.reverse != 0;
-  size_t t = (size_t)blockIdx.x * kWaves + wave;
+  size_t tile = (size_t)blockIdx.x * kWaves + wave;
   if constexpr (kPrefetch) {
     ull2 pa[NP], pb[NP];
-    if (t < n_tiles) load_tile(rev ? last - t : t, pa, pb);
-    for (; t < n_tiles; t += tile_stride) {
-      const size_t nx = t + tile_stride;
-      process_tile(rev ? last - t : t, nx < n_tiles ? (rev ? last - nx : nx) : n_tiles, pa, pb);
-    }
+    if (tile < n_tiles) load_tile(tile, pa, pb);
+    for (; tile < n_tiles; tile += tile_stride) process_tile(tile, tile + tile_stride, pa, pb);
   } else {
-    for (; t < n_tiles; t += tile_stride) {
+    for (; tile < n_tiles; tile += tile_stride) {
       ull2 pa[NP], pb[NP];
-      const size_t tile = rev ? last - t : t;
       load_tile(tile, pa, pb);
-      process_tile(tile, n_tiles, pa, pb);
+      process_tile(tile, tile + tile_stride, pa, pb);
     }
   }
 
@@ -1304,25 +1295,15 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int tb = n - 7 - ta;
+  build_eq_weights(f, rv.v + 7, ta, eqA);   // the tile-in-segment weights
   const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
   const size_t n_tiles = (size_t)1 << (n - 7);
   const size_t n_chunks = n_tiles >> chunk_log;
   const int C = 1 << chunk_log;
-  const size_t chunk_first = (size_t)blockIdx.x * kWaves + wave;
-  // the wave's first eight loads go out BEFORE the weights are built (they do not depend on them): on a 2^24-entry
-  // table the ~1 us of build_eq_weights is otherwise 5 % of the launch with the memory pipe idle
-  ull2 pc[8];
-  bool preloaded = false;
-  if (chunk_first < n_chunks && C >= 8) {
-#pragma unroll
-    for (int k = 0; k < 8; ++k) pc[k] = ld16<NT>(Tp + ((chunk_first << chunk_log) + k) * kWave + lane);
-    preloaded = true;
-  }
-  build_eq_weights(f, rv.v + 7, ta, eqA);   // the tile-in-segment weights
   typename F::Acc o0, o1;
   f.acc_zero(o0);
   f.acc_zero(o1);
-  for (size_t chunk = chunk_first; chunk < n_chunks; chunk += (size_t)gridDim.x * kWaves) {
+  for (size_t chunk = (size_t)blockIdx.x * kWaves + wave; chunk < n_chunks; chunk += (size_t)gridDim.x * kWaves) {
     const size_t tile0 = chunk << chunk_log;
     const size_t seg = tile0 >> ta;
     const int in_seg = (int)(tile0 & (((size_t)1 << ta) - 1));
@@ -1333,14 +1314,12 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
     // unroller does not touch loops that contain inline assembly (acc_mac)
     int i = 0;
     for (; i + 8 <= C; i += 8) {
-      if (!preloaded) {
+      ull2 pc[8];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) {
-          const size_t q = (tile0 + i + k) * kWave + lane;
-          pc[k] = ld16<NT>(Tp + q);
-        }
+      for (int k = 0; k < 8; ++k) {
+        const size_t q = (tile0 + i + k) * kWave + lane;
+        pc[k] = ld16<NT>(Tp + q);
       }
-      preloaded = false;
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const u64 w = eqA[in_seg + i + k];
@@ -1350,10 +1329,10 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
     }
     for (; i < C; ++i) {
       const size_t q = (tile0 + i) * kWave + lane;
-      const ull2 p1 = ld16<NT>(Tp + q);
+      const ull2 pc = ld16<NT>(Tp + q);
       const u64 w = eqA[in_seg + i];
-      f.acc_mac(a0, p1.x, w);
-      f.acc_mac(a1, p1.y, w);
+      f.acc_mac(a0, pc.x, w);
+      f.acc_mac(a1, pc.y, w);
     }
     u64 wB = f.one();  // segment weight, wave-uniform: tb factors per chunk of 2*C products
     for (int j = 0; j < tb; ++j) {
@@ -1391,17 +1370,6 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
   const int lane = threadIdx.x & (kWave - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int ta = k - 7;
-  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
-  const int tiles = 1 << ta;
-  const size_t seg_first = (size_t)blockIdx.x * kWaves + wave;
-  // the first eight loads of the wave's first segment go out before the weights are built (see evaluate_kernel)
-  ull2 pc[8];
-  bool preloaded = false;
-  if (seg_first < n_out && tiles >= 8) {
-#pragma unroll
-    for (int q = 0; q < 8; ++q) pc[q] = ld16<NT>(Tp + (seg_first << (k - 1)) + lane + (size_t)q * kWave);
-    preloaded = true;
-  }
   build_eq_weights(f, rv.v + 7, ta, eqA);
   u64 wl = f.one();
 #pragma unroll
@@ -1411,18 +1379,18 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
   }
   const u64 r0 = rv.v[0], one_minus_r0 = f.sub(f.one(), r0);
   __syncthreads();
-  for (size_t seg = seg_first; seg < n_out; seg += (size_t)gridDim.x * kWaves) {
+  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+  const int tiles = 1 << ta;
+  for (size_t seg = (size_t)blockIdx.x * kWaves + wave; seg < n_out; seg += (size_t)gridDim.x * kWaves) {
     const ull2* __restrict__ Sp = Tp + (seg << (k - 1)) + lane;
     typename F::Acc a0, a1;
     f.acc_zero(a0);
     f.acc_zero(a1);
     int i = 0;
     for (; i + 8 <= tiles; i += 8) {
-      if (!preloaded) {
+      ull2 pc[8];
 #pragma unroll
-        for (int q = 0; q < 8; ++q) pc[q] = ld16<NT>(Sp + (size_t)(i + q) * kWave);
-      }
-      preloaded = false;
+      for (int q = 0; q < 8; ++q) pc[q] = ld16<NT>(Sp + (size_t)(i + q) * kWave);
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
         const u64 w = eqA[i + q];
@@ -1431,10 +1399,10 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
       }
     }
     for (; i < tiles; ++i) {
-      const ull2 p1 = Sp[(size_t)i * kWave];
+      const ull2 pc = Sp[(size_t)i * kWave];
       const u64 w = eqA[i];
-      f.acc_mac(a0, p1.x, w);
-      f.acc_mac(a1, p1.y, w);
+      f.acc_mac(a0, pc.x, w);
+      f.acc_mac(a1, pc.y, w);
     }
     u64 v = f.add(f.mul(one_minus_r0, f.acc_get(a0)), f.mul(r0, f.acc_get(a1)));
     v = f.mul(v, wl);
@@ -1449,40 +1417,68 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
 // several).  This is fix_variables of the TOP k index bits (BE order), and the f_A half of
 // G::new: f_A[col] = sum_row eq(r1)[row] * A[row][col] (matrix-multiplication/src/lib.rs:81-83,
 // relabel + fold collapsed into one pass).  Lanes own 16-byte pieces of c: coalesced.
-template <class F, bool NT>
+// Row-walking access pattern (this kernel and gkr_phase1_kernel): a WAVE owns PW consecutive 1 KiB spans of every row
+// of its chunk (lane l: pieces span*64*PW + 64 j + l, j < PW).  Measured on this chip (tools/rowwalk.hip,
+// profiles/r03_rowwalk.txt, two 2^13 x 2^13 tables): one 1 KiB span per wave and row reads at 6.3 TB/s, four
+// contiguous KiB at 6.9; FOUR waves per SIMD are slower than one (5.1-5.7 TB/s: more rows open at once than the
+// DRAM pages like) - so the launch is sized for one wave per SIMD and the memory pipe is fed by the loads in flight
+// per lane (rows in flight x PW), not by occupancy.
+template <class F, bool NT, int PW>
 __global__ void __launch_bounds__(kBlock)
 coldot_kernel(F f, const u64* __restrict__ T, const u64* __restrict__ w, size_t rows, size_t rows_per_chunk,
               size_t M, u64* __restrict__ partial) {
+  constexpr int RIF = (PW >= 4) ? 2 : 4;   // rows in flight per thread (eight 16-byte loads either way)
   const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
   ull2* __restrict__ Pp = reinterpret_cast<ull2*>(partial);
   const size_t mp = M / 2;  // pieces per row
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const size_t i0 = (size_t)blockIdx.y * rows_per_chunk;
   const size_t i1 = (i0 + rows_per_chunk < rows) ? i0 + rows_per_chunk : rows;
-  for (size_t pc = (size_t)blockIdx.x * kBlock + threadIdx.x; pc < mp; pc += (size_t)gridDim.x * kBlock) {
-    typename F::Acc a0, a1;
-    f.acc_zero(a0);
-    f.acc_zero(a1);
+  const size_t n_spans = (mp + (size_t)kWave * PW - 1) / ((size_t)kWave * PW);
+  for (size_t span = (size_t)blockIdx.x * (kBlock / kWave) + wave; span < n_spans; span += (size_t)gridDim.x * (kBlock / kWave)) {
+    const size_t pc0 = span * kWave * PW + lane;
+    typename F::Acc a0[PW], a1[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      f.acc_zero(a0[j]);
+      f.acc_zero(a1[j]);
+    }
+    const ull2 zero = {0, 0};
     size_t i = i0;
-    for (; i + 4 <= i1; i += 4) {  // fixed-count inner loop: see evaluate_kernel.  Four rows in
-      ull2 v[4];                   // flight per thread: eight (rows are M*8 bytes apart) halves the rate
+    for (; i + RIF <= i1; i += RIF) {  // fixed-count inner loop: see evaluate_kernel
+      ull2 v[RIF][PW];
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
-        v[k] = ld16<NT>(Tp + (i + k) * mp + pc);
+      for (int k = 0; k < RIF; ++k)
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
+        for (int j = 0; j < PW; ++j) {
+          const size_t pc = pc0 + (size_t)j * kWave;
+          v[k][j] = (PW == 1 || pc < mp) ? ld16<NT>(Tp + (i + k) * mp + (pc < mp ? pc : 0)) : zero;
+        }
+#pragma unroll
+      for (int k = 0; k < RIF; ++k) {
         const u64 wi = w[i + k];
-        f.acc_mac(a0, v[k].x, wi);
-        f.acc_mac(a1, v[k].y, wi);
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+          f.acc_mac(a0[j], v[k][j].x, wi);
+          f.acc_mac(a1[j], v[k][j].y, wi);
+        }
       }
     }
     for (; i < i1; ++i) {
-      const ull2 v = ld16<NT>(Tp + i * mp + pc);
       const u64 wi = w[i];
-      f.acc_mac(a0, v.x, wi);
-      f.acc_mac(a1, v.y, wi);
+#pragma unroll
+      for (int j = 0; j < PW; ++j) {
+        const size_t pc = pc0 + (size_t)j * kWave;
+        const ull2 v = pc < mp ? ld16<NT>(Tp + i * mp + pc) : zero;
+        f.acc_mac(a0[j], v.x, wi);
+        f.acc_mac(a1[j], v.y, wi);
+      }
     }
-    ull2 o = {f.acc_get(a0), f.acc_get(a1)};
-    Pp[(size_t)blockIdx.y * mp + pc] = o;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const size_t pc = pc0 + (size_t)j * kWave;
+      if (pc < mp) Pp[(size_t)blockIdx.y * mp + pc] = ull2{f.acc_get(a0[j]), f.acc_get(a1[j])};
+    }
   }
 }
 // out[c] = sum_y partial[y][c]
@@ -1636,53 +1632,75 @@ gkr_wiring_scatter_kernel(F f, const u64* __restrict__ eq, const int* __restrict
 
 // P[b], L[b] as above for one chunk of rows (= values of c) per blockIdx.y; index of add/mul = c * M + b.
 // Lanes own 16-byte pieces of b: coalesced.  w[c] = W(c).
-template <class F, bool NT>
+template <class F, bool NT, int PW>
 __global__ void __launch_bounds__(kBlock)
 gkr_phase1_kernel(F f, const u64* __restrict__ add, const u64* __restrict__ mul, const u64* __restrict__ w, size_t rows,
                   size_t rows_per_chunk, size_t M, u64* __restrict__ partialP, u64* __restrict__ partialL) {
+  constexpr int RIF = 2;   // rows in flight per thread: 2 rows x 2 tables x PW 16-byte loads (access pattern: see coldot_kernel)
   const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(add);
   const ull2* __restrict__ Mp = reinterpret_cast<const ull2*>(mul);
   ull2* __restrict__ Pp = reinterpret_cast<ull2*>(partialP);
   ull2* __restrict__ Lp = reinterpret_cast<ull2*>(partialL);
   const size_t mp = M / 2;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   const size_t i0 = (size_t)blockIdx.y * rows_per_chunk;
   const size_t i1 = (i0 + rows_per_chunk < rows) ? i0 + rows_per_chunk : rows;
-  for (size_t pc = (size_t)blockIdx.x * kBlock + threadIdx.x; pc < mp; pc += (size_t)gridDim.x * kBlock) {
-    typename F::Acc p0, p1, l0, l1;
-    f.acc_zero(p0); f.acc_zero(p1); f.acc_zero(l0); f.acc_zero(l1);
-    u64 s0 = 0, s1 = 0;   // sum_c add: plain modular adds
-    size_t i = i0;
-    // four rows (eight 16-byte loads) in flight per thread; wiring tables are mostly zero (one non-zero per gate in 4^k
-    // entries), and a piece whose four words are all zero adds nothing: where a whole wave sees zeros the ~70
-    // instructions of a row are skipped (gkr_sums_kernel does the same)
-    for (; i + 4 <= i1; i += 4) {   // fixed-count inner loop (acc_mac is inline asm: no runtime unrolling)
-      ull2 a[4], m[4];
+  const size_t n_spans = (mp + (size_t)kWave * PW - 1) / ((size_t)kWave * PW);
+  const ull2 zero = {0, 0};
+  for (size_t span = (size_t)blockIdx.x * (kBlock / kWave) + wave; span < n_spans; span += (size_t)gridDim.x * (kBlock / kWave)) {
+    const size_t pc0 = span * kWave * PW + lane;
+    typename F::Acc p0[PW], p1[PW], l0[PW], l1[PW];
+    u64 s0[PW], s1[PW];   // sum_c add: plain modular adds
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        a[k] = ld16<NT>(Ap + (i + k) * mp + pc);
-        m[k] = ld16<NT>(Mp + (i + k) * mp + pc);
+    for (int j = 0; j < PW; ++j) {
+      f.acc_zero(p0[j]); f.acc_zero(p1[j]); f.acc_zero(l0[j]); f.acc_zero(l1[j]);
+      s0[j] = s1[j] = 0;
+    }
+    // wiring tables are mostly zero (one non-zero per gate in 4^k entries), and a piece whose four words are all zero
+    // adds nothing: where a whole wave sees zeros the ~70 instructions of a piece are skipped (gkr_sums_kernel does
+    // the same)
+    auto take = [&](int j, const ull2& a, const ull2& m, u64 wi) {
+      if ((a.x | a.y | m.x | m.y) != 0) {
+        s0[j] = f.add(s0[j], a.x); s1[j] = f.add(s1[j], a.y);
+        f.acc_mac(p0[j], m.x, wi); f.acc_mac(p1[j], m.y, wi);
+        f.acc_mac(l0[j], a.x, wi); f.acc_mac(l1[j], a.y, wi);
       }
+    };
+    size_t i = i0;
+    for (; i + RIF <= i1; i += RIF) {   // fixed-count inner loop (acc_mac is inline asm: no runtime unrolling)
+      ull2 a[RIF][PW], m[RIF][PW];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if ((a[k].x | a[k].y | m[k].x | m[k].y) != 0) {
-          const u64 wi = w[i + k];
-          s0 = f.add(s0, a[k].x); s1 = f.add(s1, a[k].y);
-          f.acc_mac(p0, m[k].x, wi); f.acc_mac(p1, m[k].y, wi);
-          f.acc_mac(l0, a[k].x, wi); f.acc_mac(l1, a[k].y, wi);
+      for (int k = 0; k < RIF; ++k)
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+          const size_t pc = pc0 + (size_t)j * kWave;
+          const bool in = PW == 1 || pc < mp;
+          a[k][j] = in ? ld16<NT>(Ap + (i + k) * mp + (pc < mp ? pc : 0)) : zero;
+          m[k][j] = in ? ld16<NT>(Mp + (i + k) * mp + (pc < mp ? pc : 0)) : zero;
         }
+#pragma unroll
+      for (int k = 0; k < RIF; ++k) {
+        const u64 wi = w[i + k];
+#pragma unroll
+        for (int j = 0; j < PW; ++j) take(j, a[k][j], m[k][j], wi);
       }
     }
     for (; i < i1; ++i) {
-      const ull2 a = ld16<NT>(Ap + i * mp + pc), m = ld16<NT>(Mp + i * mp + pc);
       const u64 wi = w[i];
-      s0 = f.add(s0, a.x); s1 = f.add(s1, a.y);
-      f.acc_mac(p0, m.x, wi); f.acc_mac(p1, m.y, wi);
-      f.acc_mac(l0, a.x, wi); f.acc_mac(l1, a.y, wi);
+#pragma unroll
+      for (int j = 0; j < PW; ++j) {
+        const size_t pc = pc0 + (size_t)j * kWave;
+        if (pc < mp) take(j, ld16<NT>(Ap + i * mp + pc), ld16<NT>(Mp + i * mp + pc), wi);
+      }
     }
-    ull2 op = {f.add(s0, f.acc_get(p0)), f.add(s1, f.acc_get(p1))};
-    ull2 ol = {f.acc_get(l0), f.acc_get(l1)};
-    Pp[(size_t)blockIdx.y * mp + pc] = op;
-    Lp[(size_t)blockIdx.y * mp + pc] = ol;
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const size_t pc = pc0 + (size_t)j * kWave;
+      if (pc < mp) {
+        Pp[(size_t)blockIdx.y * mp + pc] = ull2{f.add(s0[j], f.acc_get(p0[j])), f.add(s1[j], f.acc_get(p1[j]))};
+        Lp[(size_t)blockIdx.y * mp + pc] = ull2{f.acc_get(l0[j]), f.acc_get(l1[j])};
+      }
+    }
   }
 }
 

@@ -127,9 +127,7 @@ struct sc_ctx {
   // 0 = not asked yet)
   int resident_blocks[2][4][4] = {};
   int time_kernels = 0;
-  int eval_blocks = 0, eval_chunk_log = 0, fixlow_blocks = 0, rowwalk_blocks = 0;   // tuning probes (0 = the built-in rule)
-  int reverse_log = 0;                     // largest tables (log2 entries) whose first folding pass walks backwards (0 = off)
-  const u64* last_first_pass_a = nullptr;  // table the last non-folding pass read
+  int rowwalk_blocks = 0;   // tuning probe: blocks of a row-walking launch (0 = one wave per SIMD)
   int nt_load_log = 22;   // tables of >= 2^this entries are loaded nontemporal (measured: 21-25 equal, 27 and off worse)
   int nt_store_log = 25;  // outputs of >= 2^this entries are stored nontemporal
 
@@ -488,9 +486,7 @@ void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const 
   hipStream_t s = ctx->stream;
   // streaming hints are compile-time (kernels.hpp, ld16/st16): 0 = cached, 1 = stream the inputs,
   // 3 = stream inputs and outputs
-  // (a first pass whose tables the folding pass can still find in the Infinity Cache must let its loads allocate)
-  const bool keep = log_in <= ctx->reverse_log;
-  const int nt = ((log_in >= ctx->nt_load_log && !(keep && kf == 0)) ? 1 : 0) | ((kf > 0 && (log_in - kf) >= ctx->nt_store_log) ? 2 : 0);
+  const int nt = (log_in >= ctx->nt_load_log ? 1 : 0) | ((kf > 0 && (log_in - kf) >= ctx->nt_store_log) ? 2 : 0);
 #define SC_PASS(KF, KS)                                                                                            \
   do {                                                                                                             \
     if (nt == 3)                                                                                                   \
@@ -567,11 +563,7 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
                 int log_in, bool across_ranks, bool* from_mailbox) {
   if (kf < 0 || kf > 3 || ks < 1 || ks > 3 || (ks == 3 && kf != 0) || log_in < kf + ks)
     return fail(ctx, SC_ERR_ARG, "launch_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
-  sc::FoldW fw = make_fold_weights(ctx, r, kf);
-  // tables of <= 2^reverse_log entries: the first pass reads them forwards with allocating loads, so its last
-  // 256 MiB are still in the Infinity Cache when the first folding pass starts - which therefore walks backwards
-  fw.reverse = (kf > 0 && A == ctx->last_first_pass_a && log_in <= ctx->reverse_log) ? 1 : 0;
-  if (kf == 0) ctx->last_first_pass_a = A;
+  const sc::FoldW fw = make_fold_weights(ctx, r, kf);
   size_t n_units = (size_t)1 << (log_in - kf - ks);
   int grid = grid_for(ctx, n_units);
   grid = std::min(grid, pass_resident_blocks(ctx, kf, ks));
@@ -1004,37 +996,54 @@ int build_eq_table(sc_ctx* ctx, const u64* r, int nbits, u64** out) {
   return SC_OK;
 }
 
-// How many chunks of rows (blockIdx.y) a row-walking kernel with gx blocks across the columns gets: enough for four
-// blocks per CU - these kernels keep only four to eight 16-byte loads in flight per thread, so the memory pipe is fed
-// by occupancy (2^13 x 2^13 tables on the old rule, "2^16 pieces per launch", ran 256 blocks = one wave per SIMD at
-// 0.57 of peak) - but at least 16 rows per chunk, so that the partial rows stay a small fraction of the table.
-size_t row_chunks(const sc_ctx* ctx, size_t rows, size_t gx) {
-  const size_t want = ((size_t)(ctx->rowwalk_blocks > 0 ? ctx->rowwalk_blocks : 4 * ctx->num_cus) + gx - 1) / gx;
-  size_t chunks = std::min<size_t>(want, std::max<size_t>(rows / 16, 1));
-  return std::max<size_t>(1, std::min<size_t>(chunks, 1024));
+// Launch shape of a row-walking kernel (kernels.hpp, coldot_kernel / gkr_phase1_kernel) over rows x M words: how many
+// contiguous KiB a wave reads per row (PW: 4 where the row is long enough, measured +10-16 % over 1), how many blocks
+// across the columns (gx) and how many chunks of rows (blockIdx.y) - ONE wave per SIMD in total (four waves per SIMD
+// read 10-20 % slower with this access pattern, tools/rowwalk.hip), at least 16 rows per chunk so that the partial
+// rows stay a small fraction of the table.
+struct RowWalk {
+  int pw;
+  size_t gx, chunks, rows_per_chunk;
+};
+RowWalk row_walk_shape(const sc_ctx* ctx, size_t rows, size_t M) {
+  const size_t mp = M / 2;
+  RowWalk s;
+  s.pw = (mp % 256 == 0 && mp >= 1024) ? 4 : (mp % 128 == 0 && mp >= 256) ? 2 : 1;
+  const size_t n_spans = (mp + 64 * (size_t)s.pw - 1) / (64 * (size_t)s.pw);
+  s.gx = std::min<size_t>((n_spans + 3) / 4, 1024);
+  const size_t waves = ctx->rowwalk_blocks > 0 ? 4 * (size_t)ctx->rowwalk_blocks : 4 * (size_t)ctx->num_cus;
+  size_t chunks = std::min<size_t>((waves + n_spans - 1) / n_spans, std::max<size_t>(rows / 16, 1));
+  chunks = std::max<size_t>(1, std::min<size_t>(chunks, 1024));
+  s.rows_per_chunk = (rows + chunks - 1) / chunks;
+  s.rows_per_chunk = (s.rows_per_chunk + 3) / 4 * 4;   // whole batches of rows in flight
+  s.chunks = (rows + s.rows_per_chunk - 1) / s.rows_per_chunk;
+  return s;
 }
 
 // out[c] = sum_i w[i] * in[i*M + c], i < rows: one streaming pass (plus a small reduce when
 // the rows are split over blockIdx.y for parallelism).  M must be even.
 int coldot(sc_ctx* ctx, const u64* in, const u64* w, size_t rows, size_t M, u64* out) {
-  const size_t mp = M / 2;
-  size_t gx = (mp + sc::kBlock - 1) / sc::kBlock;
-  if (gx > 1024) gx = 1024;
-  const size_t chunks0 = row_chunks(ctx, rows, gx);
-  const size_t rows_per_chunk = (rows + chunks0 - 1) / chunks0;
-  const size_t chunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+  const RowWalk rw = row_walk_shape(ctx, rows, M);
+  const size_t gx = rw.gx, chunks = rw.chunks, rows_per_chunk = rw.rows_per_chunk;
   if (rows_per_chunk > sc::GoldilocksMont::kAccMaxTerms)   // one lazy accumulator sums rows_per_chunk products
     return fail(ctx, SC_ERR_UNSUPPORTED, "coldot: %zu rows per chunk exceed the lazy accumulator's capacity", rows_per_chunk);
   u64* partial = out;
   if (chunks > 1) SC_TRY(pool_alloc(ctx, chunks * M, &partial));
   const int nt = (rows * M) >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
   SC_TRY(timer_begin(ctx, SC_KIND_COLDOT, log2_of(rows), 0, log2_of(rows * M), (u64)8 * rows * M + 8 * rows, (u64)8 * M));
-  if (nt)
-    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::coldot_kernel<F, true>), dim3((unsigned)gx, (unsigned)chunks),
-                                                    dim3(sc::kBlock), 0, ctx->stream, f, in, w, rows, rows_per_chunk, M, partial));
-  else
-    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::coldot_kernel<F, false>), dim3((unsigned)gx, (unsigned)chunks),
-                                                    dim3(sc::kBlock), 0, ctx->stream, f, in, w, rows, rows_per_chunk, M, partial));
+#define SC_COLDOT(NT, PW)                                                                                                  \
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::coldot_kernel<F, NT, PW>), dim3((unsigned)gx, (unsigned)chunks),    \
+                                                  dim3(sc::kBlock), 0, ctx->stream, f, in, w, rows, rows_per_chunk, M, partial))
+  if (nt) {
+    if (rw.pw == 4) SC_COLDOT(true, 4);
+    else if (rw.pw == 2) SC_COLDOT(true, 2);
+    else SC_COLDOT(true, 1);
+  } else {
+    if (rw.pw == 4) SC_COLDOT(false, 4);
+    else if (rw.pw == 2) SC_COLDOT(false, 2);
+    else SC_COLDOT(false, 1);
+  }
+#undef SC_COLDOT
   if (chunks > 1) {
     int grid = grid_for(ctx, M);
     SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::sum_rows_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
@@ -1101,9 +1110,7 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
       const size_t nlen = cur_len >> step;
       SC_CHAIN(pool_alloc(ctx, nlen, &nxt));
       const sc::RVec rv = make_rvec(r + done, (size_t)step);
-      // one wave per segment; up to four blocks per CU (fixlow_blocks): 2^12 segments on the 3 x 256 blocks of the
-      // streaming cap are 1.33 per wave - a third of the chip idles through the second round
-      const int grid = (int)std::min<size_t>((nlen + 3) / 4, (size_t)(ctx->fixlow_blocks > 0 ? ctx->fixlow_blocks : 1024));
+      const int grid = (int)std::min<size_t>((nlen + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
       const int nt = cur_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
       SC_CHAIN(timer_begin(ctx, SC_KIND_FIX_LOW, step, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * nlen));
       if (nt)
@@ -1383,12 +1390,9 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
     ctx->dbg_delay_ms = (int)value;
   } else if (k == "dbg_skip_tag") {
     ctx->dbg_skip_tag = value ? 1 : 0;
-  } else if (k == "eval_blocks" || k == "eval_chunk_log" || k == "fixlow_blocks" || k == "rowwalk_blocks") {
+  } else if (k == "rowwalk_blocks") {
     if (value < 0 || value > 4096) return fail(ctx, SC_ERR_ARG, "%s out of range", key);
-    (k == "eval_blocks" ? ctx->eval_blocks : k == "eval_chunk_log" ? ctx->eval_chunk_log : k == "fixlow_blocks" ? ctx->fixlow_blocks : ctx->rowwalk_blocks) = (int)value;
-  } else if (k == "reverse_log") {
-    if (value < 0 || value > 40) return fail(ctx, SC_ERR_ARG, "reverse_log out of range");
-    ctx->reverse_log = (int)value;
+    ctx->rowwalk_blocks = (int)value;
   } else if (k == "nt_load_log") {
     ctx->nt_load_log = (int)value;
   } else if (k == "nt_store_log") {
@@ -1416,7 +1420,6 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   else if (k == "arena_log") *value = ctx->arena_log;
   else if (k == "peer_spin_ms") *value = ctx->peer_spin_ms;
   else if (k == "nt_load_log") *value = ctx->nt_load_log;
-  else if (k == "reverse_log") *value = ctx->reverse_log;
   else if (k == "nt_store_log") *value = ctx->nt_store_log;
   else if (k == "peer_connect_ms") *value = ctx->peer_connect_ms;
   else if (k == "dbg_delay_ms") *value = ctx->dbg_delay_ms;
@@ -1825,15 +1828,13 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
   }
   const int ta = std::min(nv - 7, 10);
   // a wave streams 2^chunk_log consecutive 1 KiB tiles: long contiguous runs per wave read faster
-  // (n = 28: 409 us with 16 tiles, 382 with 128), as long as there are chunks for every wave of a full grid - four
-  // blocks per CU here (eval_blocks): at 2^24 entries the old rule (128-tile chunks, one block per CU) left one wave
-  // per SIMD, nothing to overlap its loads with its products, and the kernel at 0.55 of peak
-  const int eval_cap = ctx->eval_blocks > 0 ? ctx->eval_blocks : 1024;
-  int chunk_log = ctx->eval_chunk_log > 0 ? ctx->eval_chunk_log : std::max(3, nv - 7 - 12);
-  chunk_log = std::min({chunk_log, ta, 7});
+  // (n = 28: 409 us with 16 tiles, 382 with 128), as long as there are chunks for every wave.  (Round 3 swept the grid
+  // and the chunk size at 2^24 entries - 256 to 1024 blocks, 8 to 128 tiles per chunk: 36.4-38.8 us whatever the shape,
+  // profiles/r03_mle24_sweep.txt; at that size the launch is its ~8 us floor plus 22 us of stream.)
+  const int chunk_log = std::min({ta, 7, std::max(3, nv - 17)});
   sc::RVec rv = make_rvec(pt_le, (size_t)nv);
   const size_t n_chunks = ((size_t)1 << (nv - 7)) >> chunk_log;
-  int grid = (int)std::min<size_t>((n_chunks + 3) / 4, (size_t)eval_cap);
+  int grid = (int)std::min<size_t>((n_chunks + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
   if (grid < 1) grid = 1;
   const bool peer = across && ctx->transport == Transport::kPeer;
   const bool mailbox = (ctx->use_mailbox || peer) && !(across && ctx->transport == Transport::kRccl);
@@ -2719,12 +2720,8 @@ int gkr_dense_phase1(sc_gkr_prover* pr, u64* P, u64* L) {
   const size_t M = (size_t)1 << pr->kb;
   const size_t rows = pr->add_len / M;   // this rank's values of c
   const u64* w = pr->w_c + (is_sharded(ctx) ? (size_t)ctx->rank * rows : 0);
-  const size_t mp = M / 2;
-  size_t gx = (mp + sc::kBlock - 1) / sc::kBlock;
-  if (gx > 1024) gx = 1024;
-  const size_t chunks0 = row_chunks(ctx, rows, gx);
-  const size_t rows_per_chunk = (rows + chunks0 - 1) / chunks0;
-  const size_t chunks = (rows + rows_per_chunk - 1) / rows_per_chunk;
+  const RowWalk rw = row_walk_shape(ctx, rows, M);
+  const size_t gx = rw.gx, chunks = rw.chunks, rows_per_chunk = rw.rows_per_chunk;
   if (rows_per_chunk > sc::GoldilocksMont::kAccMaxTerms)
     return fail(ctx, SC_ERR_UNSUPPORTED, "gkr: %zu rows per chunk exceed the lazy accumulator's capacity", rows_per_chunk);
   u64 *pP = P, *pL = L;
@@ -2739,12 +2736,19 @@ int gkr_dense_phase1(sc_gkr_prover* pr, u64* P, u64* L) {
   const int nt = pr->add_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
   int rc = timer_begin(ctx, SC_KIND_GKR, pr->kc, 0, log2_of(pr->add_len), (u64)16 * pr->add_len + 8 * rows, (u64)16 * M);
   if (rc == SC_OK) {
-    if (nt)
-      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_phase1_kernel<F, true>), dim3((unsigned)gx, (unsigned)chunks),
-                                                      dim3(sc::kBlock), 0, ctx->stream, f, pr->add, pr->mul, w, rows, rows_per_chunk, M, pP, pL));
-    else
-      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_phase1_kernel<F, false>), dim3((unsigned)gx, (unsigned)chunks),
-                                                      dim3(sc::kBlock), 0, ctx->stream, f, pr->add, pr->mul, w, rows, rows_per_chunk, M, pP, pL));
+#define SC_PHASE1(NT, PW)                                                                                                   \
+  SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::gkr_phase1_kernel<F, NT, PW>), dim3((unsigned)gx, (unsigned)chunks),  \
+                                                  dim3(sc::kBlock), 0, ctx->stream, f, pr->add, pr->mul, w, rows, rows_per_chunk, M, pP, pL))
+    if (nt) {
+      if (rw.pw == 4) SC_PHASE1(true, 4);
+      else if (rw.pw == 2) SC_PHASE1(true, 2);
+      else SC_PHASE1(true, 1);
+    } else {
+      if (rw.pw == 4) SC_PHASE1(false, 4);
+      else if (rw.pw == 2) SC_PHASE1(false, 2);
+      else SC_PHASE1(false, 1);
+    }
+#undef SC_PHASE1
     if (chunks > 1) {
       const int grid = grid_for(ctx, M);
       SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::sum_rows_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
