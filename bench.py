@@ -48,6 +48,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
+INT8_PEAK_TOPS = 5000.0  # dense int8 matrix-core peak: 2 x the ~2.5 PF dense bf16 figure (MI355X_MICROARCH.md, matrix cores)
 
 
 def lagrange_at(F, e, r):
@@ -899,15 +900,24 @@ def run_triangle(args, pkg, torch, dist, rank, world, local_rank):
     # column-dot and two k-variable folds over the 4^k-entry table
     muladds = lambda kk: 8**kk + (5 * 4**kk - 7) + 2 * (5 * 2**kk - 7) + 3 * 4**kk      # noqa: E731
     alg_bytes = 8 * 4**k * 6
-    note = ("dominant kernel by time is matsq_tiled_kernel (the n^3 multiply-adds of the adjacency square: integer VALU-bound, "
-            "its bytes are n^2 words and say nothing); the roofline object is therefore taken on the dominant STREAMING "
-            "kernel of the proof, the first product-sumcheck pass over the 4^k-entry tables; matsq is reported in `matsq`")
-    roof = roofline_from_log(log, args.steps, "pass", "triangle_k%d" % k, note, kernel_ms, n_launch, elapsed / args.steps * 1e3, alg_bytes)
+    # the dominant launch group of the proof: the matrix square (int8 MFMA on a 0/1 adjacency table: priced against the dense
+    # int8 matrix-core peak), or - once that is a few per cent of the proof - the largest streaming pass (HBM)
+    groups = aggregate_launches(log, args.steps)
+    dom_kind = groups[0]["_key"][0]
+    note = ("dominant launch group by time: %s.  matsq = matsq_bytes_kernel (table -> int8 bytes and transpose) + matsq_mfma_kernel "
+            "(v_mfma_i32_32x32x32_i8, exact counts) + the skipped generic fallback, timed as one group; bytes from the launch log" % dom_kind)
+    roof = roofline_from_log(log, args.steps, dom_kind if dom_kind != "matsq" else groups[min(1, len(groups) - 1)]["_key"][0],
+                             "triangle_k%d" % k, note, kernel_ms, n_launch, elapsed / args.steps * 1e3, alg_bytes)
     ms_rec = [r for r in log if r["kind"] == "matsq"]
     if ms_rec:
         us = sum(r["ms"] for r in ms_rec) / len(ms_rec) * 1e3
-        roof["matsq"] = {"kernel": "sc::matsq_tiled_kernel<GoldilocksMont> on a 2^%d x 2^%d matrix" % (k, k), "avg_launch_us": us,
-                         "field_mul_adds": 8**k, "mul_adds_per_s": 8**k / (us * 1e-6), "bound": "integer VALU (64x64->128 products)"}
+        tops = 2 * 8**k / (us * 1e-6) / 1e12
+        roof["matsq"] = {"kernel": "sc::matsq_bytes_kernel + sc::matsq_mfma_kernel<GoldilocksMont> on a 2^%d x 2^%d 0/1 matrix" % (k, k),
+                         "bound": "mfma", "avg_launch_us": us, "int8_multiply_adds": 8**k, "achieved": tops, "peak": INT8_PEAK_TOPS,
+                         "unit": "TOP/s (int8 multiply-add = 2 ops)", "frac": tops / INT8_PEAK_TOPS}
+        if dom_kind == "matsq":
+            roof.update({"bound": "mfma", "kernel": roof["matsq"]["kernel"], "achieved": tops, "peak": INT8_PEAK_TOPS,
+                         "unit": "TFLOP/s", "frac": tops / INT8_PEAK_TOPS, "avg_launch_us": us, "bytes_per_launch": None, "traffic": None})
     config = {"workload": "triangle_counting::G prover, 2^%d vertices (adjacency MLE of 2^%d entries), Goldilocks" % (k, 2 * k),
               "k": k, "num_vars": 3 * k, "field_mul_adds_per_step": muladds(k), "algorithmic_bytes_per_step": alg_bytes,
               "parity_gate": "; ".join(parity),

@@ -195,3 +195,39 @@ def test_triangle_prover_sharded(world, transport):
             assert got[0] == ref["c_1"], k
             for j in range(3 * k):
                 assert got[1 + j] == [int(x) for x in ref["evals"][j]], (k, j)
+
+
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+def test_matrix_square_paths_vs_oracle(p):
+    """n >= 64: the square of the adjacency MLE's matrix goes to the int8 matrix cores when the table is 0/1 (what
+    G::new_adj_matrix builds) and to the generic field kernel otherwise; both against the oracle's reference-shaped
+    prover.  DIRECTED graphs (asymmetric 0/1 matrices) pin the operand orientation of the MFMA tiles - a symmetric
+    matrix would pass with rows and columns swapped - and a table with field-valued entries pins the fallback."""
+    pkg = load_package()
+    ctx = pkg.Context(pkg.Field(p))
+    F = ctx.field
+    o = oracle(p)
+    gen = random.Random(2027)
+    for k, kind in [(6, "directed"), (7, "directed"), (6, "field"), (6, "almost01")]:
+        n = 1 << k
+        if kind == "directed":
+            words = [F.one if gen.random() < 0.4 else 0 for _ in range(n * n)]
+        elif kind == "field":
+            words = [F.from_int(gen.randrange(p)) for _ in range(n * n)]
+        else:   # 0/1 everywhere but one entry: the flag must send the whole square to the generic kernel
+            words = [F.one if gen.random() < 0.4 else 0 for _ in range(n * n)]
+            words[gen.randrange(n * n)] = F.from_int(2)
+        ev = np.array(words, dtype=np.uint64)
+        t = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2 * k, ev)
+        g = pkg.triangle_counting.G(t, t, t, k)
+        ch = [F.from_int(gen.randrange(p)) for _ in range(3 * k)]
+        ref = o.tri_prove(ev, k, ch)
+        assert ref["status"] == 0
+        eng = g.native_prover()
+        assert eng.c1() == ref["c_1"], (k, kind)
+        for j in range(3 * k):
+            assert eng.round_evals(ch[j - 1] if j else F.one, j) == [int(x) for x in ref["evals"][j]], (k, kind, j)
+        assert g.evaluate(ch) == ref["final_eval"]
+        it = iter(ch)
+        c1, evals, _ = pkg.triangle_counting.prove(ctx, g, 0, draw=lambda _u, _j, _e: int(next(it)))     # sc_tri_prove: the same proof in one call
+        assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])

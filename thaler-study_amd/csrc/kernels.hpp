@@ -1427,7 +1427,7 @@ template <class F, bool NT, int PW>
 __global__ void __launch_bounds__(kBlock)
 coldot_kernel(F f, const u64* __restrict__ T, const u64* __restrict__ w, size_t rows, size_t rows_per_chunk,
               size_t M, u64* __restrict__ partial) {
-  constexpr int RIF = (PW >= 4) ? 2 : 4;   // rows in flight per thread (eight 16-byte loads either way)
+  constexpr int RIF = 4;   // rows in flight per thread (tools/rowwalk.hip: 4 x 4 KiB reads fastest on one table)
   const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
   ull2* __restrict__ Pp = reinterpret_cast<ull2*>(partial);
   const size_t mp = M / 2;  // pieces per row
@@ -1789,8 +1789,10 @@ matsq_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P, size_t 
 // (15 instructions each) rather than at the L1 rate of the naive form.
 template <class F>
 __global__ void __launch_bounds__(kBlock)
-matsq_tiled_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P, size_t z_begin, size_t z_rows) {
+matsq_tiled_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P, size_t z_begin, size_t z_rows,
+                   const unsigned* __restrict__ only_if /* null, or: run only if this word is non-zero */) {
   constexpr int TS = 64, KT = 32;
+  if (only_if && *only_if == 0) return;   // the table was 0/1: matsq_mfma_kernel has done the work
   __shared__ ull2 lds_a[KT * TS / 2];   // A[yy][xx], 16 KiB
   __shared__ u64 lds_b[KT * TS];        // Bt[yy][zz], 16 KiB
   const size_t n = (size_t)1 << k;
@@ -1838,6 +1840,87 @@ matsq_tiled_kernel(F f, const u64* __restrict__ T, int k, u64* __restrict__ P, s
       ull2* dst = reinterpret_cast<ull2*>(P + ((z0 + 4 * ty + j) << k) + x0 + 4 * tx);
       dst[0] = o0;
       dst[1] = o1;
+    }
+  }
+}
+
+// The square of a 0/1 matrix on the matrix cores.  G::new_adj_matrix (triangle-counting/src/lib.rs:32-51) builds the
+// three tables from a Vec<bool>: every entry is 0 or 1, so P[z][x] = sum_y T[z][y] T[y][x] is a COUNT (<= n <= 2^15)
+// and an int8 x int8 -> int32 MFMA computes it exactly - this is a matrix product by nature, not a reshaped stream.
+//  1. matsq_bytes_kernel: the table as bytes, row-major (T8[z][y]) and transposed (T8t[x][y] = T[y][x]) so that both
+//     MFMA operands are 16 contiguous bytes per lane; any entry that is neither 0 nor 1 raises `flag`.
+//  2. matsq_mfma_kernel (if the flag stayed down): one wave per 32 x 32 tile of P, v_mfma_i32_32x32x32_i8 over y in
+//     steps of 32, operands straight from the (L2-resident) byte tables; count -> Montgomery word (count * R^2 * R^-1).
+//  3. matsq_tiled_kernel (if the flag went up; launched behind the other two either way, no host round trip): the
+//     generic field-valued square.
+// The hardware pairs element e of lane (r, h)'s A fragment with element e of lane (r', h)'s B fragment; both are loaded
+// with the same y = y0 + 16 h + e, so whatever k order the instruction uses inside a step the sum is over the same y.
+// C/D layout (cdna_hip_programming.md section 3): col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+typedef int mfma_v4i __attribute__((ext_vector_type(4)));
+typedef int mfma_v16i __attribute__((ext_vector_type(16)));
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+matsq_bytes_kernel(F f, const u64* __restrict__ T, int k, unsigned char* __restrict__ T8, unsigned char* __restrict__ T8t,
+                   unsigned* __restrict__ flag) {
+  constexpr int TS = 64;
+  __shared__ unsigned char tile[TS][TS + 16];   // rows 16-byte aligned (80 bytes)
+  const size_t n = (size_t)1 << k;
+  const int tps = (int)(n / TS);
+  const u64 one = f.one();
+  int bad = 0;
+  for (int tid = blockIdx.x; tid < tps * tps; tid += gridDim.x) {
+    const size_t r0 = (size_t)(tid / tps) * TS, c0 = (size_t)(tid % tps) * TS;
+    __syncthreads();   // the previous tile has been written out
+#pragma unroll
+    for (int i = 0; i < TS * TS / kBlock; ++i) {
+      const int row = (threadIdx.x >> 6) + 4 * i, col = threadIdx.x & 63;
+      const u64 v = T[((r0 + row) << k) | (c0 + col)];
+      bad |= (v != 0 && v != one) ? 1 : 0;
+      tile[row][col] = (v == one) ? 1 : 0;
+    }
+    __syncthreads();
+    const int rr = threadIdx.x >> 2, q = threadIdx.x & 3;   // 64 rows x 4 chunks of 16 bytes
+    *reinterpret_cast<uint4*>(T8 + (r0 + rr) * n + c0 + 16 * q) = *reinterpret_cast<const uint4*>(&tile[rr][16 * q]);
+    unsigned w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      w[j] = (unsigned)tile[16 * q + 4 * j][rr] | ((unsigned)tile[16 * q + 4 * j + 1][rr] << 8) | ((unsigned)tile[16 * q + 4 * j + 2][rr] << 16) |
+             ((unsigned)tile[16 * q + 4 * j + 3][rr] << 24);
+    *reinterpret_cast<uint4*>(T8t + (c0 + rr) * n + r0 + 16 * q) = uint4{w[0], w[1], w[2], w[3]};
+  }
+  if (bad) atomicOr(flag, 1u);
+}
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+matsq_mfma_kernel(F f, const unsigned char* __restrict__ T8, const unsigned char* __restrict__ T8t, int k, u64* __restrict__ P,
+                  size_t z_begin, size_t z_rows, const unsigned* __restrict__ flag) {
+  if (*flag != 0) return;   // not a 0/1 table: the generic kernel behind this launch does the work
+  const size_t n = (size_t)1 << k;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave, r = lane & 31, h = lane >> 5;
+  const size_t tiles_x = n / 32, n_tiles = (z_rows / 32) * tiles_x;
+  const u64 r2 = f.r_squared();
+  for (size_t tid = (size_t)blockIdx.x * (kBlock / kWave) + wave; tid < n_tiles; tid += (size_t)gridDim.x * (kBlock / kWave)) {
+    const size_t z0 = z_begin + (tid / tiles_x) * 32, x0 = (tid % tiles_x) * 32;
+    const unsigned char* ap = T8 + (z0 + r) * n + 16 * h;    // row z0 + r of T:  T[z][y0 + 16 h + e]
+    const unsigned char* bp = T8t + (x0 + r) * n + 16 * h;   // column x0 + r of T: T[y0 + 16 h + e][x]
+    mfma_v16i acc = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    size_t y0 = 0;
+    for (; y0 + 128 <= n; y0 += 128) {   // four steps of loads in flight
+      mfma_v4i a[4], b[4];
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        a[s] = *reinterpret_cast<const mfma_v4i*>(ap + y0 + 32 * s);
+        b[s] = *reinterpret_cast<const mfma_v4i*>(bp + y0 + 32 * s);
+      }
+#pragma unroll
+      for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(a[s], b[s], acc, 0, 0, 0);
+    }
+    for (; y0 < n; y0 += 32)
+      acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(*reinterpret_cast<const mfma_v4i*>(ap + y0), *reinterpret_cast<const mfma_v4i*>(bp + y0), acc, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int row = (reg & 3) + 8 * (reg >> 2) + 4 * h;
+      P[((z0 + row) << k) | (x0 + r)] = f.mul((u64)(unsigned)acc[reg], r2);   // count -> Montgomery word
     }
   }
 }

@@ -3241,10 +3241,30 @@ extern "C" int sc_tri_prover_create(sc_ctx* ctx, const sc_table* adj, size_t var
     rc = timer_begin(ctx, SC_KIND_MATSQ, tp->k, 0, (int)(2 * var_len), (u64)8 * full_len, (u64)8 * z_rows * n);
     if (rc == SC_OK) {
       if (var_len >= 6 && z_rows >= 64) {
-        const size_t tiles = (z_rows / 64) * (n / 64);   // 64 x 64 output tiles of this rank's rows
-        const int grid = (int)std::min<size_t>(tiles, (size_t)4 * ctx->num_cus);
-        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::matsq_tiled_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
-                                                        tp->adj, tp->k, tp->P, z_begin, z_rows));
+        // adjacency tables are 0/1 (G::new_adj_matrix): their square is a count, computed exactly by the int8 matrix
+        // cores.  Bytes + flag, the MFMA kernel, and behind it the generic kernel, which runs only if the flag says
+        // the table held something else - no host round trip decides.
+        u64* bytes = nullptr;   // T8 | T8t | flag
+        rc = pool_alloc(ctx, 2 * (full_len / 8) + 8, &bytes);
+        if (rc == SC_OK) {
+          unsigned char* t8 = reinterpret_cast<unsigned char*>(bytes);
+          unsigned char* t8t = t8 + full_len;
+          unsigned* flag = reinterpret_cast<unsigned*>(bytes + 2 * (full_len / 8));
+          const size_t tiles = (z_rows / 64) * (n / 64);   // 64 x 64 output tiles of this rank's rows
+          const int grid = (int)std::min<size_t>(tiles, (size_t)4 * ctx->num_cus);
+          const size_t tiles32 = (z_rows / 32) * (n / 32);
+          if (hipMemsetAsync(flag, 0, sizeof(unsigned), ctx->stream) != hipSuccess) rc = fail(ctx, SC_ERR_HIP, "matsq: memset failed");
+          SC_DISPATCH_FIELD(ctx, F, f, {
+            hipLaunchKernelGGL((sc::matsq_bytes_kernel<F>), dim3((unsigned)std::min<size_t>((n / 64) * (n / 64), (size_t)8 * ctx->num_cus)),
+                               dim3(sc::kBlock), 0, ctx->stream, f, tp->adj, tp->k, t8, t8t, flag);
+            hipLaunchKernelGGL((sc::matsq_mfma_kernel<F>), dim3((unsigned)std::min<size_t>((tiles32 + 3) / 4, (size_t)8 * ctx->num_cus)),
+                               dim3(sc::kBlock), 0, ctx->stream, f, (const unsigned char*)t8, (const unsigned char*)t8t, tp->k, tp->P, z_begin,
+                               z_rows, (const unsigned*)flag);
+            hipLaunchKernelGGL((sc::matsq_tiled_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, tp->adj, tp->k, tp->P, z_begin,
+                               z_rows, (const unsigned*)flag);
+          });
+          pool_release(ctx, bytes);   // stream-ordered reuse
+        }
       } else {
         SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::matsq_kernel<F>), dim3(grid_for_wide(ctx, z_rows * n)), dim3(sc::kBlock),
                                                         0, ctx->stream, f, tp->adj, tp->k, tp->P, z_begin, z_rows));
