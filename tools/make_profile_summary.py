@@ -41,8 +41,7 @@ with open(os.path.join(P, "%s_%s_kernel_stats.csv" % (tag, workload)), "w") as f
         w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"]])
 
 # ---- per-launch trace: the hot-path kernels in dispatch order
-HOT = ("pass_kernel<", "small_pass3_kernel<", "wgrid_pass_kernel<", "grid_pass3_kernel<", "resident_kernel<", "evaluate_kernel<",
-       "fold_kernel<", "fix_low_kernel<", "fold_be_kernel<", "coldot_kernel<")
+HOT = ("pass_kernel<", "wgrid_pass_kernel<", "evaluate_kernel<", "fold_kernel<", "fix_low_kernel<", "fold_be_kernel<", "coldot_kernel<")
 
 
 def is_hot(name):
@@ -51,11 +50,6 @@ def is_hot(name):
 
 def describe(name):
     """(kind, kf, ks) of a hot kernel from its demangled name"""
-    m = re.search(r"small_pass3_kernel<sc::\w+, (\d)>", name)
-    if m:
-        return "tail_pass", int(m.group(1)), 3
-    if "grid_pass3_kernel<" in name:
-        return "tail_pass", -1, 3        # kf is a run-time argument: taken from bench.py's schedule
     if "wgrid_pass_kernel<" in name:
         return "grid_pass", -1, -1       # kf, ks from bench.py's schedule
     m = re.search(r"pass_kernel<sc::\w+, (\d), (\d)(?:, \d)?>", name)
@@ -64,14 +58,14 @@ def describe(name):
     m = re.search(r"fold_kernel<sc::\w+, (\d)", name)
     if m:
         return "fold", int(m.group(1)), 0
-    for k in ("resident", "evaluate", "fix_low", "fold_be", "coldot"):
+    for k in ("evaluate", "fix_low", "fold_be", "coldot"):
         if k + "_kernel<" in name:
             return k, 0, 0
     return "other", 0, 0
 
 
 if workload == "prover":   # a proof is passes only (the evaluate launches behind it are bench.py's parity gate)
-    HOT = ("pass_kernel<", "small_pass3_kernel<", "wgrid_pass_kernel<", "grid_pass3_kernel<", "resident_kernel<")
+    HOT = ("pass_kernel<", "wgrid_pass_kernel<")
 trace = [r for r in csv.DictReader(open(one(d_stats, "*_kernel_trace.csv"))) if is_hot(r["Kernel_Name"])]
 
 
@@ -110,8 +104,6 @@ assert len(fetch) == len(last) == len(write), (len(fetch), len(last), len(write)
 def bench_name(kind, kf, ks, log_in):
     if kind == "pass":
         return "sc::pass_kernel<GoldilocksMont,%d,%d> on 2^%d-entry tables" % (kf, ks, log_in)
-    if kind == "tail_pass":
-        return "sc::grid_pass3_kernel<GoldilocksMont> (kf=%d, ks=3; small_pass3_kernel with mid_pass=0) on 2^%d-entry tables" % (kf, log_in)
     if kind == "grid_pass":
         return "sc::wgrid_pass_kernel<GoldilocksMont,ks> (kf=%d, ks=%d) on 2^%d-entry tables" % (kf, ks, log_in)
     if kind == "evaluate":
@@ -144,7 +136,7 @@ schedule = (bench or {}).get("config", {}).get("schedule") or []
 for i, r in enumerate(last):
     kind, kf, ks = describe(r["Kernel_Name"])
     if kf < 0 or ks < 0:                      # run-time (kf, ks): the i-th launch of a proof in bench.py's launch log
-        assert i < len(schedule) and schedule[i][0] in ("grid_pass", "tail_pass"), (i, schedule)
+        assert i < len(schedule) and schedule[i][0] == "grid_pass", (i, schedule)
         kf, ks = schedule[i][1], schedule[i][2]
     t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     grid = int(r["Grid_Size_X"]) // 256
