@@ -1310,22 +1310,38 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
     typename F::Acc a0, a1;
     f.acc_zero(a0);
     f.acc_zero(a1);
-    // eight loads in flight per lane; written as a fixed-count inner loop because the runtime
-    // unroller does not touch loops that contain inline assembly (acc_mac)
+    // Batches of eight 16-byte loads per lane, DOUBLE-BUFFERED: the next batch is requested before the products of the
+    // current one.  On a 2^24-entry table the launch has one wave per SIMD, and a wave that waits for its loads (~0.7 us)
+    // and then multiplies (240 instructions issued alone, ~0.9 us) in turn reads at 5.2 TB/s whatever the grid shape
+    // (profiles/r03_mle24_sweep.txt); with the next batch in flight during the products the two overlap.  Written as
+    // fixed-count loops because the runtime unroller does not touch loops that contain inline assembly (acc_mac).
+    auto load8 = [&](ull2 (&p8)[8], size_t tile) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p8[k] = ld16<NT>(Tp + (tile + k) * kWave + lane);
+    };
+    auto mac8 = [&](const ull2 (&p8)[8], int w0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u64 w = eqA[w0 + k];
+        f.acc_mac(a0, p8[k].x, w);
+        f.acc_mac(a1, p8[k].y, w);
+      }
+    };
     int i = 0;
+    if (C >= 16) {
+      ull2 pa[8], pb[8];
+      load8(pa, tile0);
+      for (; i + 16 <= C; i += 16) {
+        load8(pb, tile0 + i + 8);
+        mac8(pa, in_seg + i);
+        if (i + 32 <= C) load8(pa, tile0 + i + 16);
+        mac8(pb, in_seg + i + 8);
+      }
+    }
     for (; i + 8 <= C; i += 8) {
       ull2 pc[8];
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const size_t q = (tile0 + i + k) * kWave + lane;
-        pc[k] = ld16<NT>(Tp + q);
-      }
-#pragma unroll
-      for (int k = 0; k < 8; ++k) {
-        const u64 w = eqA[in_seg + i + k];
-        f.acc_mac(a0, pc[k].x, w);
-        f.acc_mac(a1, pc[k].y, w);
-      }
+      load8(pc, tile0 + i);
+      mac8(pc, in_seg + i);
     }
     for (; i < C; ++i) {
       const size_t q = (tile0 + i) * kWave + lane;
@@ -1386,17 +1402,34 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
     typename F::Acc a0, a1;
     f.acc_zero(a0);
     f.acc_zero(a1);
-    int i = 0;
-    for (; i + 8 <= tiles; i += 8) {
-      ull2 pc[8];
+    // double-buffered batches of eight loads (see evaluate_kernel)
+    auto load8 = [&](ull2 (&p8)[8], int tile) {
 #pragma unroll
-      for (int q = 0; q < 8; ++q) pc[q] = ld16<NT>(Sp + (size_t)(i + q) * kWave);
+      for (int q = 0; q < 8; ++q) p8[q] = ld16<NT>(Sp + (size_t)(tile + q) * kWave);
+    };
+    auto mac8 = [&](const ull2 (&p8)[8], int w0) {
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const u64 w = eqA[i + q];
-        f.acc_mac(a0, pc[q].x, w);
-        f.acc_mac(a1, pc[q].y, w);
+        const u64 w = eqA[w0 + q];
+        f.acc_mac(a0, p8[q].x, w);
+        f.acc_mac(a1, p8[q].y, w);
       }
+    };
+    int i = 0;
+    if (tiles >= 16) {
+      ull2 pa[8], pb[8];
+      load8(pa, 0);
+      for (; i + 16 <= tiles; i += 16) {
+        load8(pb, i + 8);
+        mac8(pa, i);
+        if (i + 32 <= tiles) load8(pa, i + 16);
+        mac8(pb, i + 8);
+      }
+    }
+    for (; i + 8 <= tiles; i += 8) {
+      ull2 pc[8];
+      load8(pc, i);
+      mac8(pc, i);
     }
     for (; i < tiles; ++i) {
       const ull2 pc = Sp[(size_t)i * kWave];
@@ -1481,13 +1514,25 @@ coldot_kernel(F f, const u64* __restrict__ T, const u64* __restrict__ w, size_t 
     }
   }
 }
-// out[c] = sum_y partial[y][c]
+// out[c] = sum_y partial[y][c], for one or two arrays of partial rows (blockIdx.y selects; the second is the L of a GKR
+// phase).  Eight rows in flight per thread: the first version walked the rows one dependent load at a time with 2^13
+// threads - 20 us per array for 64 x 2^13 words, a tenth of the streaming pass it follows.
 template <class F>
 __global__ void __launch_bounds__(kBlock)
-sum_rows_kernel(F f, const u64* __restrict__ partial, size_t chunks, size_t M, u64* __restrict__ out) {
+sum_rows_kernel(F f, const u64* __restrict__ partial0, const u64* __restrict__ partial1, size_t chunks, size_t M,
+                u64* __restrict__ out0, u64* __restrict__ out1) {
+  const u64* __restrict__ partial = blockIdx.y ? partial1 : partial0;
+  u64* __restrict__ out = blockIdx.y ? out1 : out0;
   for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < M; c += (size_t)gridDim.x * kBlock) {
     u64 t = 0;
-    for (size_t y = 0; y < chunks; ++y) t = f.add(t, partial[y * M + c]);
+    size_t y = 0;
+    for (; y + 8 <= chunks; y += 8) {
+      u64 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = partial[(y + q) * M + c];
+      t = f.add(t, f.add(f.add(f.add(v[0], v[1]), f.add(v[2], v[3])), f.add(f.add(v[4], v[5]), f.add(v[6], v[7]))));
+    }
+    for (; y < chunks; ++y) t = f.add(t, partial[y * M + c]);
     out[c] = t;
   }
 }

@@ -1045,9 +1045,9 @@ int coldot(sc_ctx* ctx, const u64* in, const u64* w, size_t rows, size_t M, u64*
   }
 #undef SC_COLDOT
   if (chunks > 1) {
-    int grid = grid_for(ctx, M);
-    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::sum_rows_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
-                                                    (const u64*)partial, chunks, M, out));
+    int grid = grid_for_wide(ctx, M);
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::sum_rows_kernel<F>), dim3(grid, 1), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                    (const u64*)partial, (const u64*)partial, chunks, M, out, out));
     pool_release(ctx, partial);
   }
   SC_HIP(ctx, hipGetLastError());
@@ -2750,11 +2750,9 @@ int gkr_dense_phase1(sc_gkr_prover* pr, u64* P, u64* L) {
     }
 #undef SC_PHASE1
     if (chunks > 1) {
-      const int grid = grid_for(ctx, M);
-      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::sum_rows_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
-                                                      (const u64*)pP, chunks, M, P));
-      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::sum_rows_kernel<F>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f,
-                                                      (const u64*)pL, chunks, M, L));
+      const int grid = grid_for_wide(ctx, M);
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::sum_rows_kernel<F>), dim3(grid, 2), dim3(sc::kBlock), 0, ctx->stream, f,
+                                                      (const u64*)pP, (const u64*)pL, chunks, M, P, L));
     }
     if (hipGetLastError() != hipSuccess) {
       poison(ctx);
