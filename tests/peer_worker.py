@@ -1,5 +1,5 @@
 """One rank of the multi-process peer-transport tests (launched by torch.distributed.run; every rank on GPU 0).
-SC_PEER_WORKER_MODE = parity | faults.  Not collected by pytest.
+SC_PEER_WORKER_MODE = parity | faults | widened.  Not collected by pytest.
 
 The library's bound on an in-kernel wait for a peer (peer_spin_ms, default 2 s) is the skew it tolerates between the
 ranks' launches of the same pass; the ranks of a real run call in lockstep.  Here every rank does seconds of oracle
@@ -83,6 +83,88 @@ def parity(pkg, dist, pyref, Oracle, rank, world):
         del a, b, g
         ctx.close()
     print("PEER-OK rank %d" % rank, flush=True)
+
+
+def widened(pkg, dist, pyref, Oracle, rank, world):
+    """BASELINE config 5's pieces over the peer transport between PROCESSES: sharded G::new (+ proof), the sharded GKR W
+    prover with sharded wiring, the sharded triangle prover - vector all-reduces and gathers that go through the arenas
+    in chunks (arena_log = 8 here: 256 words per rank and chunk), bit-exact against the oracle on every rank"""
+    import random
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_gpu_gkr import make_circuit, random_circuit
+    D = pkg.distributed
+    p = pyref.GOLDILOCKS
+    o = Oracle(p)
+    F = pkg.Field(p)
+    g_ = world.bit_length() - 1
+    ctx = pkg.Context(F, device=0)
+    ctx.set_option("arena_log", 8)
+    D.attach_peer(ctx, rank, world)
+    # ---- sharded G::new at n = 8 (2^16-entry matrices; the f_a all-reduce moves 2 x 2^8 limbs) + the proof on it
+    n = 8
+    pt = np.array([o.challenge(pyref.SEED_PT, j) for j in range(2 * n)], dtype=np.uint64)
+    fa, fb = o.g_new(n, o.generate(11, 2 * n), o.generate(12, 2 * n), pt)
+    ch = np.array([o.challenge(pyref.SEED_R, j + 1) for j in range(n)], dtype=np.uint64)
+    ref = o.prove(fa, fb, ch)
+    start, length = D.shard_range(2 * n, rank, world)
+    nl = length.bit_length() - 1
+    At = pkg.DenseMultilinearExtension.generate(ctx, 11, nl, start=start)
+    Bt = pkg.DenseMultilinearExtension.generate(ctx, 12, nl, start=start)
+    dist.barrier()
+    g = pkg.matrix_multiplication.G.new_from_tables(ctx, n, At, Bt, [int(x) for x in pt])
+    s0, l0 = D.shard_range(n, rank, world)
+    assert np.array_equal(g.f_a.to_evaluations(), fa[s0:s0 + l0]) and np.array_equal(g.f_b.to_evaluations(), fb[s0:s0 + l0])
+    dist.barrier()
+    c1, evals, _ = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+    assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+    del g, At, Bt
+    # ---- GKR layers: sharded wiring, dense W prover on the shards (P / L all-reduce, add_r / mul_r gather), generic sums
+    gp = pkg.gkr_protocol
+    rng = random.Random(4242)
+    for ks in ([5, 4], [6, 7], [4, 9]):
+        layers = random_circuit(rng, ks)
+        circuit = make_circuit(pkg, layers, 1 << ks[-1])
+        inputs = [F.from_int(rng.randrange(p)) for _ in range(1 << ks[-1])]
+        evaluation = circuit.evaluate(F, inputs)
+        k_i, k_next = ks
+        r_i = [F.from_int(rng.randrange(p)) for _ in range(k_i)]
+        oadd, omul = o.wiring_fixed(layers[0], k_next, r_i)
+        ow = np.array(evaluation[1], dtype=np.uint64)
+        chw = [F.from_int(rng.randrange(p)) for _ in range(2 * k_next)]
+        refw = o.w_prove(oadd, omul, ow, ow, chw)
+        assert refw["status"] == 0
+        dist.barrier()
+        w = gp.start_round_w(ctx, circuit, evaluation, 0, r_i)
+        n_loc = oadd.size // world
+        assert np.array_equal(w.add_i.to_evaluations(), oadd[rank * n_loc:(rank + 1) * n_loc])
+        dist.barrier()
+        assert w.round_evals() == [int(x) for x in refw["evals"][0]]
+        dist.barrier()
+        eng = w.native_prover()
+        assert eng.c1() == refw["c_1"], ks
+        for j in range(2 * k_next):
+            assert eng.round_evals(chw[j - 1] if j else F.one, j) == [int(x) for x in refw["evals"][j]], (ks, j)
+        assert w.evaluate(chw) == refw["final_eval"]
+        del eng, w
+    # ---- triangle counting, 64 vertices: adjacency rows sharded, the matrix square split across the ranks and gathered
+    k = 6
+    nv = 1 << k
+    words = np.array([F.one if rng.random() < 0.4 else 0 for _ in range(nv * nv)], dtype=np.uint64)
+    cht = [F.from_int(rng.randrange(p)) for _ in range(3 * k)]
+    reft = o.tri_prove(words, k, cht)
+    assert reft["status"] == 0
+    rows = nv // world
+    t = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2 * k - g_, words[rank * rows * nv:(rank + 1) * rows * nv])
+    tg = pkg.triangle_counting.G(t, t, t, k)
+    dist.barrier()
+    eng = pkg.triangle_counting._NativeTriProver(tg)
+    assert eng.c1() == reft["c_1"]
+    for j in range(3 * k):
+        assert eng.round_evals(cht[j - 1] if j else F.one, j) == [int(x) for x in reft["evals"][j]], j
+    del eng, tg, t
+    dist.barrier()
+    ctx.close()
+    print("WIDENED-OK rank %d" % rank, flush=True)
 
 
 def faults(pkg, dist, pyref, Oracle, rank, world):
@@ -211,7 +293,7 @@ def main():
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     pkg = ge.load_package()
     mode = os.environ.get("SC_PEER_WORKER_MODE", "parity")
-    (parity if mode == "parity" else faults)(pkg, dist, pyref, Oracle, rank, world)
+    {"parity": parity, "faults": faults, "widened": widened}[mode](pkg, dist, pyref, Oracle, rank, world)
     dist.barrier()
     dist.destroy_process_group()
 

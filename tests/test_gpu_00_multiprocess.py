@@ -142,3 +142,13 @@ def test_peer_exchange_fault_injection(nproc):
     out = _workers(nproc, "faults", 30050 + (os.getpid() % 40) + nproc)
     assert out.returncode == 0, (_quiet(out.stdout, 1500), _quiet(out.stderr))
     assert out.stdout.count("FAULTS-OK") == nproc, out.stdout[-3000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_config5_pieces_over_peer_processes(nproc):
+    """sharded G::new, the sharded GKR W prover (sharded wiring, generic sums) and the sharded triangle prover between
+    PROCESSES over the peer transport, with an arena so small that every vector all-reduce and gather goes in chunks"""
+    out = _workers(nproc, "widened", 30150 + (os.getpid() % 40) + nproc)
+    assert out.returncode == 0, (_quiet(out.stdout, 1500), _quiet(out.stderr))
+    assert out.stdout.count("WIDENED-OK") == nproc, out.stdout[-3000:]
