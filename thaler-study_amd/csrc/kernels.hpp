@@ -11,6 +11,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "field.hpp"
 
 namespace sc {
@@ -789,7 +791,7 @@ fold_wide_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, GridW gw,
 }
 
 // the block's sums: thread c < 3^KS returns cell c
-template <class F, int KS>
+template <class F, int KS, bool PF>
 __device__ __forceinline__ u64 wgrid_body(const F& f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
                                           u64* __restrict__ B2, const GridW& gw, int kf, size_t n_out) {
   constexpr int kWaves = kBlock / kWave;
@@ -842,43 +844,114 @@ __device__ __forceinline__ u64 wgrid_body(const F& f, const u64* __restrict__ A,
 #pragma unroll
   for (int k = 0; k < 4; ++k) f.acc_zero(acc[k]);
 
-  const size_t n_iter = (n_out + kWgEntries - 1) / kWgEntries;
-  for (size_t it = (size_t)blockIdx.x * kWaves + wave; it < n_iter; it += (size_t)gridDim.x * kWaves) {
-    const size_t i = it * kWgEntries + ent;
-    u64 v = 0;   // entries past the end of a short table are zeros: they add nothing to any cell
-    if (i < n_out) {
-      switch (kf) {   // compile-time fan-in: all loads of an entry are in flight together
-        case 0: v = src[i]; break;
-        case 1: v = grid_fold1<F, 1>(f, src, dst, gw, i); break;
-        case 2: v = grid_fold1<F, 2>(f, src, dst, gw, i); break;
-        case 3: v = grid_fold1<F, 3>(f, src, dst, gw, i); break;
-        case 4: v = grid_fold1<F, 4>(f, src, dst, gw, i); break;
-        default: v = grid_fold1<F, 5>(f, src, dst, gw, i); break;
+  if constexpr (PF) {
+    const size_t n_iter = (n_out + kWgEntries - 1) / kWgEntries;
+    const size_t it0 = (size_t)blockIdx.x * kWaves + wave, it_stride = (size_t)gridDim.x * kWaves;
+    // kf = 0 and kf = 2 are the fan-ins that occur on tables large enough for a wave to take several iterations (first
+    // passes of small proofs; the pass behind a (., 2) pass_kernel launch).  For those the NEXT iteration's global loads
+    // are requested before this iteration's fold, so that their ~0.8 us latency runs under the ~300 instructions and
+    // nine LDS round trips of an iteration instead of in front of them.  A separate instantiation (PF; the host picks it
+    // for kf = 0 / 2 on tables with more iterations than waves): next to the 64 load registers of the kf = 5 fold the
+    // prefetch registers cost a wave per SIMD (139-165 VGPRs instead of 99-120).
+    ull2 nx0 = {0, 0}, nx1 = {0, 0};
+    auto request = [&](size_t i) {
+      if (kf == 0) {
+        nx0.x = src[i];
+      } else {
+        const ull2* __restrict__ pt = reinterpret_cast<const ull2*>(src + i * 4);
+        nx0 = pt[0];
+        nx1 = pt[1];
       }
-    }
-    ef[slot] = v;
-    wave_lds_sync();
-#pragma clang loop unroll(full)
-    for (int j = 0; j < KS; ++j) {
-      const int st = kPow3[KS - 1 - j];
-#pragma clang loop unroll(full)
-      for (int q = 0; q < 3; ++q) {
-        if (2 * ((gpi * kPow3[j]) << (KS - 1 - j)) > kWave * q) {   // does any lane have a q-th step at this level?
-          const unsigned d = step[j][q];
-          if (d != 0) {
-            lds_u64* const x = (lds_u64*)(size_t)(d & 0x7FFFFFFFu);
-            x[2 * st] = f.sub(x[st], x[0]);
+    };
+    bool have = it0 < n_iter && it0 * kWgEntries + ent < n_out;
+    if (have) request(it0 * kWgEntries + ent);
+    for (size_t it = it0; it < n_iter; it += it_stride) {
+      const size_t i = it * kWgEntries + ent;
+      u64 v = 0;   // entries past the end of a short table are zeros: they add nothing to any cell
+      {
+        const ull2 x0 = nx0, x1 = nx1;
+        const bool mine = have;
+        const size_t ni = (it + it_stride) * kWgEntries + ent;
+        have = it + it_stride < n_iter && ni < n_out;
+        if (have) request(ni);
+        if (mine) {
+          if (kf == 0) {
+            v = x0.x;
+          } else {
+            typename F::Acc3 s;
+            f.acc3_zero(s);
+            f.acc3_mac(s, x0.x, gw.w[0]);
+            f.acc3_mac(s, x0.y, gw.w[1]);
+            f.acc3_mac(s, x1.x, gw.w[2]);
+            f.acc3_mac(s, x1.y, gw.w[3]);
+            v = f.acc3_get(s);
+            dst[i] = v;
           }
         }
       }
+      ef[slot] = v;
       wave_lds_sync();
-    }
+#pragma clang loop unroll(full)
+      for (int j = 0; j < KS; ++j) {
+        const int st = kPow3[KS - 1 - j];
+#pragma clang loop unroll(full)
+        for (int q = 0; q < 3; ++q) {
+          if (2 * ((gpi * kPow3[j]) << (KS - 1 - j)) > kWave * q) {   // does any lane have a q-th step at this level?
+            const unsigned d = step[j][q];
+            if (d != 0) {
+              lds_u64* const x = (lds_u64*)(size_t)(d & 0x7FFFFFFFu);
+              x[2 * st] = f.sub(x[st], x[0]);
+            }
+          }
+        }
+        wave_lds_sync();
+      }
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const int p = lane + kWave * k;
-      if (p < pairs) f.acc_mac(acc[k], ef[p], ef[kGridChunk + p]);
+      for (int k = 0; k < 4; ++k) {
+        const int p = lane + kWave * k;
+        if (p < pairs) f.acc_mac(acc[k], ef[p], ef[kGridChunk + p]);
+      }
+      wave_lds_sync();    // the next iteration overwrites the arrays
     }
-    wave_lds_sync();    // the next iteration overwrites the arrays
+  } else {
+    const size_t n_iter = (n_out + kWgEntries - 1) / kWgEntries;
+    for (size_t it = (size_t)blockIdx.x * kWaves + wave; it < n_iter; it += (size_t)gridDim.x * kWaves) {
+      const size_t i = it * kWgEntries + ent;
+      u64 v = 0;   // entries past the end of a short table are zeros: they add nothing to any cell
+      if (i < n_out) {
+        switch (kf) {   // compile-time fan-in: all loads of an entry are in flight together
+          case 0: v = src[i]; break;
+          case 1: v = grid_fold1<F, 1>(f, src, dst, gw, i); break;
+          case 2: v = grid_fold1<F, 2>(f, src, dst, gw, i); break;
+          case 3: v = grid_fold1<F, 3>(f, src, dst, gw, i); break;
+          case 4: v = grid_fold1<F, 4>(f, src, dst, gw, i); break;
+          default: v = grid_fold1<F, 5>(f, src, dst, gw, i); break;
+        }
+      }
+      ef[slot] = v;
+      wave_lds_sync();
+#pragma clang loop unroll(full)
+      for (int j = 0; j < KS; ++j) {
+        const int st = kPow3[KS - 1 - j];
+#pragma clang loop unroll(full)
+        for (int q = 0; q < 3; ++q) {
+          if (2 * ((gpi * kPow3[j]) << (KS - 1 - j)) > kWave * q) {   // does any lane have a q-th step at this level?
+            const unsigned d = step[j][q];
+            if (d != 0) {
+              lds_u64* const x = (lds_u64*)(size_t)(d & 0x7FFFFFFFu);
+              x[2 * st] = f.sub(x[st], x[0]);
+            }
+          }
+        }
+        wave_lds_sync();
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int p = lane + kWave * k;
+        if (p < pairs) f.acc_mac(acc[k], ef[p], ef[kGridChunk + p]);
+      }
+      wave_lds_sync();    // the next iteration overwrites the arrays
+    }
   }
 
 #pragma unroll
@@ -977,7 +1050,7 @@ __device__ __forceinline__ void exchange_wide(const WgOut& o, u64 total) {
   }
 }
 
-template <class F, int KS>
+template <class F, int KS, bool PF>
 __global__ void __launch_bounds__(kBlock)
 wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
                   GridW gw, int kf, size_t n_out, WgOut out) {
@@ -985,7 +1058,7 @@ wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
   constexpr int cells = kPow3[KS];
   __shared__ int lds_flag;
   const int tid = threadIdx.x;
-  u64 total = wgrid_body<F, KS>(f, A, B, A2, B2, gw, kf, n_out);
+  u64 total = wgrid_body<F, KS, PF>(f, A, B, A2, B2, gw, kf, n_out);
   if (gridDim.x > 1) {
     // level 1: the blocks of a group of 32
     const int n_blocks = gridDim.x, group = blockIdx.x / kWgGroupBlocks, n_groups = (n_blocks + kWgGroupBlocks - 1) / kWgGroupBlocks;

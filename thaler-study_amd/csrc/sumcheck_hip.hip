@@ -617,8 +617,8 @@ int launch_grid_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u6
   const size_t n_out = (size_t)1 << (log_in - kf);
   if (ctx->wgrid_blocks == 0) {
     int per_cu = 0;
-    const void* fn = ctx->gold ? reinterpret_cast<const void*>(&sc::wgrid_pass_kernel<sc::GoldilocksMont, 5>)
-                               : reinterpret_cast<const void*>(&sc::wgrid_pass_kernel<sc::MontGeneric, 5>);
+    const void* fn = ctx->gold ? reinterpret_cast<const void*>(&sc::wgrid_pass_kernel<sc::GoldilocksMont, 5, false>)
+                               : reinterpret_cast<const void*>(&sc::wgrid_pass_kernel<sc::MontGeneric, 5, false>);
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, sc::kBlock, 0) != hipSuccess || per_cu < 1) {
       (void)hipGetLastError();
       per_cu = 2;
@@ -642,7 +642,13 @@ int launch_grid_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u6
   wo.limbs_dev = rccl ? ctx->d_sums : nullptr;
   if (peer) fill_peer(ctx, wo.px, challenge_digest(r, kf, ks, log_in));
   SC_TRY(timer_begin(ctx, SC_KIND_GRID_PASS, kf, ks, log_in, (u64)16 << log_in, kf > 0 ? (u64)16 << (log_in - kf) : 0));
-#define SC_WG(KS) hipLaunchKernelGGL((sc::wgrid_pass_kernel<F, KS>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, A, B, A2, B2, gw, kf, n_out, wo)
+  // the prefetching instantiation: fan-ins 0 and 2 on tables that give a wave more than one iteration (kernels.hpp)
+  const bool pf = (kf == 0 || kf == 2) && n_iter > (size_t)grid * kWaves;
+#define SC_WG(KS)                                                                                                                       \
+  do {                                                                                                                                  \
+    if (pf) hipLaunchKernelGGL((sc::wgrid_pass_kernel<F, KS, true>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, A, B, A2, B2, gw, kf, n_out, wo); \
+    else hipLaunchKernelGGL((sc::wgrid_pass_kernel<F, KS, false>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream, f, A, B, A2, B2, gw, kf, n_out, wo);   \
+  } while (0)
   SC_DISPATCH_FIELD(ctx, F, f, {
     switch (ks) {
       case 1: SC_WG(1); break;
