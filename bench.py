@@ -47,6 +47,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the pool's driver on
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+ABANDONED = []   # contexts whose stream may be stuck in a collective that never completes: never destroyed; the process
+                 # leaves through os._exit once rank 0's line is out
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 INT8_PEAK_TOPS = 5000.0  # dense int8 matrix-core peak: 2 x the ~2.5 PF dense bf16 figure (MI355X_MICROARCH.md, matrix cores)
 
@@ -169,10 +171,26 @@ def attach_plane(plane, pkg, ctx, rank, world, dist):
         ok = ok and box[0] is not None
         if not agree(ok):             # nobody enters ncclCommInitRank unless everybody does (it blocks until all ranks arrive)
             return bail()
-        try:
-            ctx.comm_init_rccl(box[0], rank, world)
-        except Exception as e:  # pragma: no cover - e.g. two ranks on one device: RCCL refuses duplicate GPUs
-            ok, err = False, str(e)
+        # ncclCommInitRank blocks until every rank has arrived and has been seen to hang on broken fabrics: it runs in a
+        # thread this rank can walk away from (the run then ends through os._exit, see ABANDONED)
+        import threading
+        box2 = {}
+
+        def init():
+            try:
+                ctx.comm_init_rccl(box[0], rank, world)
+                box2["ok"] = True
+            except Exception as e:  # pragma: no cover - e.g. two ranks on one device: RCCL refuses duplicate GPUs
+                box2["err"] = str(e)
+
+        th = threading.Thread(target=init, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("SC_BENCH_RCCL_INIT_TIMEOUT", "180")))
+        if th.is_alive():
+            ok, err = False, "ncclCommInitRank did not return within its time limit"
+            ABANDONED.append(ctx)
+        elif "err" in box2:
+            ok, err = False, box2["err"]
     else:
         ar, ag = D.torch_collectives()
         ctx.comm_init_host(rank, world, ar, ag)
@@ -264,7 +282,8 @@ def time_plane(args, pkg, torch, dist, rank, world, local_rank, plane, n):
         else:
             ok, why = attach_plane(plane, pkg, ctx, rank, world, dist)
             if not ok:
-                ctx.close()
+                if ctx not in ABANDONED:
+                    ctx.close()
                 return {"ok": False, "plane": plane, "error": why[:300]}
     comm_nranks = ctx.get_option("comm_nranks")
     start, length = D.shard_range(n, rank, world)
@@ -326,7 +345,20 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
 
     runs, failed = [], {}
     for plane in planes_to_time(world):
-        r = time_plane(args, pkg, torch, dist, rank, world, local_rank, plane, n)
+        try:
+            r = time_plane(args, pkg, torch, dist, rank, world, local_rank, plane, n)
+        except pkg.SumcheckHipError as e:
+            # a plane that came up but failed while proving (a collective that never completed, a peer that fell out of
+            # step): the other plane's measurement must survive it.  Parity failures are SystemExit and do propagate.
+            r = {"ok": False, "plane": plane, "error": "failed while proving: %s" % str(e)[:240]}
+            ABANDONED.append(plane)
+        if dist is not None:          # a plane counts only if it worked on every rank
+            flag = torch.tensor([1 if r["ok"] else 0], dtype=torch.int64)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and r["ok"]:
+                r.pop("tables", None)
+                ABANDONED.append(r.pop("ctx"))
+                r = {"ok": False, "plane": plane, "error": "failed on another rank"}
         if not r["ok"]:
             failed[plane] = r["error"]
             if rank == 0:
@@ -992,6 +1024,15 @@ def main():
     result = run(args, pkg, torch, dist, rank, world, local_rank)
     if rank == 0:
         print(json.dumps(result), flush=True)
+    abandoned = bool(ABANDONED)
+    if dist is not None:          # ... on ANY rank: then nobody waits in a final barrier for a rank that has to leave
+        flag = torch.tensor([1 if abandoned else 0], dtype=torch.int64)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        abandoned = int(flag.item()) == 1
+    if abandoned:                 # something may never return (a stuck collective): leave without destroying it
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
