@@ -178,6 +178,8 @@ def attach_plane(plane, pkg, ctx, rank, world, dist):
 
         def init():
             try:
+                if os.environ.get("SC_BENCH_TEST_RCCL_HANG") == "1":      # test hook: an init that never returns
+                    time.sleep(3600)
                 ctx.comm_init_rccl(box[0], rank, world)
                 box2["ok"] = True
             except Exception as e:  # pragma: no cover - e.g. two ranks on one device: RCCL refuses duplicate GPUs

@@ -72,6 +72,18 @@ def test_bench_two_ranks_on_one_device():
 
 
 @pytest.mark.gpu
+def test_bench_survives_a_collective_library_that_hangs():
+    """an ncclCommInitRank that never returns (injected) must not take the peer plane's measurement with it: the line
+    comes out with the RCCL plane marked unusable, exit code 0, no process left behind"""
+    port = 29550 + (os.getpid() % 90)
+    out = _bench(["--gpus", "2", "--num-vars", "18", "--steps", "3", "--warmup", "1", "--cpu-num-vars", "0"],
+                 {"SC_BENCH_TEST_RCCL_HANG": "1", "SC_BENCH_RCCL_INIT_TIMEOUT": "3"}, port=port, timeout=300)
+    d = _one_line(out)
+    tr = d["config"]["transports"]
+    assert tr["peer"]["ms_per_step"] > 0 and tr["rccl"]["ms_per_step"] is None and "time limit" in tr["rccl"]["error"]
+
+
+@pytest.mark.gpu
 def test_bench_plain_invocation_starts_its_own_ranks():
     """`python bench.py --gpus 2` with no launcher and no WORLD_SIZE: bench.py starts the two rank processes itself (a
     child launcher, before this process touches the GPU) and relays rank 0's line and the exit code"""
