@@ -627,3 +627,100 @@ pub fn vsbw_multilinear_from_evaluations<T: MontConfig<1>>(evals: &[F64<T>], r: 
 pub fn cti_multilinear_from_evaluations<T: MontConfig<1>>(evals: &[F64<T>], r: &[F64<T>]) -> F64<T> {
     evaluate_be::<T>(evals, r)
 }
+
+// =====================================================================================
+// One process per GPU: the data planes of a sharded context, and whole proofs in one call
+// =====================================================================================
+
+impl<T: MontConfig<1>> Context<T> {
+    /// `sc_ctx_set_option` (tunables of include/sumcheck_hip.h, e.g. "peer_spin_ms", "grid_sharded")
+    pub fn set_option(&self, key: &str, value: i64) {
+        let k = std::ffi::CString::new(key).expect("option name");
+        let rc = unsafe { sys::sc_ctx_set_option(self.raw(), k.as_ptr(), value) };
+        self.check(rc, "sc_ctx_set_option");
+    }
+    /// Peer transport, step 1: this rank's 64-byte IPC handle.  All-gather the handles of all ranks by any means
+    /// (they are plain bytes), then call `comm_peer_connect` with them in rank order.
+    pub fn comm_peer_export(&self, rank: i32, world: i32) -> [u8; 64] {
+        let mut h = [0u8; 64];
+        let rc = unsafe { sys::sc_ctx_comm_peer_export(self.raw(), rank, world, h.as_mut_ptr()) };
+        self.check(rc, "sc_ctx_comm_peer_export");
+        h
+    }
+    /// Peer transport, step 2: map the peers, say hello, self-test.  `Err` (the library's message) if this node's
+    /// peer memory does not behave as the kernels need - the caller then joins RCCL instead, on every rank.
+    pub fn comm_peer_connect(&self, handles: &[[u8; 64]]) -> Result<(), String> {
+        let flat: Vec<u8> = handles.iter().flat_map(|h| h.iter().copied()).collect();
+        let rc = unsafe { sys::sc_ctx_comm_peer_connect(self.raw(), flat.as_ptr()) };
+        if rc == sys::SC_OK {
+            Ok(())
+        } else {
+            Err(unsafe { CStr::from_ptr(sys::sc_last_error(self.raw())) }.to_string_lossy().into_owned())
+        }
+    }
+    /// RCCL: rank 0 makes the id (`Context::rccl_unique_id`), the application broadcasts it, every rank joins.
+    pub fn rccl_unique_id() -> [u8; 128] {
+        let mut id = [0u8; 128];
+        let rc = unsafe { sys::sc_comm_unique_id(id.as_mut_ptr()) };
+        assert_eq!(rc, sys::SC_OK, "sc_comm_unique_id");
+        id
+    }
+    pub fn comm_init_rccl(&self, id: &[u8; 128], rank: i32, world: i32) {
+        let rc = unsafe { sys::sc_ctx_comm_init_rccl(self.raw(), id.as_ptr(), rank, world) };
+        self.check(rc, "sc_ctx_comm_init_rccl");
+    }
+    /// (rank, world) of this context's communicator
+    pub fn rank_world(&self) -> (i32, i32) {
+        let (mut r, mut w) = (0i32, 1i32);
+        let rc = unsafe { sys::sc_ctx_comm_rank(self.raw(), &mut r, &mut w) };
+        self.check(rc, "sc_ctx_comm_rank");
+        (r, w)
+    }
+}
+
+/// C trampoline for the `draw` callbacks of the whole-proof entry points: `user` points at a
+/// `&mut dyn FnMut(usize, [u64; 3]) -> u64` (round, the round's (H(0), H(1), H(2)) -> the next challenge word).
+unsafe extern "C" fn draw_trampoline(user: *mut std::ffi::c_void, round: usize, evals: *const u64) -> u64 {
+    let f = &mut *(user as *mut &mut dyn FnMut(usize, [u64; 3]) -> u64);
+    f(round, [*evals, *evals.add(1), *evals.add(2)])
+}
+
+/// (c_1, round polynomials as (H(0), H(1), H(2)) triples, challenges) of a whole proof
+pub type Transcript<T> = (F64<T>, Vec<[F64<T>; 3]>, Vec<F64<T>>);
+
+fn transcript_from<T: MontConfig<1>>(c1: u64, evals: &[u64], ch: &[u64]) -> Transcript<T> {
+    let ev = evals.chunks(3).map(|e| [from_word::<T>(e[0]), from_word::<T>(e[1]), from_word::<T>(e[2])]).collect();
+    (from_word::<T>(c1), ev, ch.iter().map(|&w| from_word::<T>(w)).collect())
+}
+
+impl<T: MontConfig<1>> GpuW<T> {
+    /// `sc_gkr_prove`: the whole 2k-round sumcheck of one GKR layer in one call; `draw(round, evals)` returns the
+    /// verifier's (or Fiat-Shamir's) next challenge as a Montgomery word.
+    pub fn prove_with(&self, draw: &mut dyn FnMut(usize, [u64; 3]) -> u64) -> Transcript<T> {
+        let n = self.num_vars();
+        let (mut c1, mut ev, mut ch) = (0u64, vec![0u64; 3 * n], vec![0u64; n]);
+        let mut cb: &mut dyn FnMut(usize, [u64; 3]) -> u64 = draw;
+        let rc = unsafe {
+            sys::sc_gkr_prove(self.add_i.ctx.raw(), self.add_i.h, self.mul_i.h, self.w_b.h, self.w_c.h, Some(draw_trampoline),
+                              &mut cb as *mut _ as *mut std::ffi::c_void, 0, &mut c1, ev.as_mut_ptr(), ch.as_mut_ptr())
+        };
+        self.add_i.ctx.check(rc, "sc_gkr_prove");
+        transcript_from::<T>(c1, &ev, &ch)
+    }
+}
+
+impl<T: MontConfig<1>> GpuTriangleG<T> {
+    /// `sc_tri_prove`: all 3 * var_len rounds of `Prover<F, G>` for `G::new_adj_matrix` in one call.
+    pub fn prove_with(&self, draw: &mut dyn FnMut(usize, [u64; 3]) -> u64) -> Transcript<T> {
+        let n = 3 * self.var_len;
+        let (mut c1, mut ev, mut ch) = (0u64, vec![0u64; 3 * n], vec![0u64; n]);
+        let mut cb: &mut dyn FnMut(usize, [u64; 3]) -> u64 = draw;
+        let rc = unsafe {
+            sys::sc_tri_prove(self.f_a_1.ctx.raw(), self.f_a_1.h, self.var_len, Some(draw_trampoline),
+                              &mut cb as *mut _ as *mut std::ffi::c_void, 0, &mut c1, ev.as_mut_ptr(), ch.as_mut_ptr())
+        };
+        self.f_a_1.ctx.check(rc, "sc_tri_prove");
+        transcript_from::<T>(c1, &ev, &ch)
+    }
+}
+

@@ -157,3 +157,22 @@ def test_shard_plan_and_limbs():
     for _ in range(8):
         total += D.split_limbs([p - 1] * len(vals))
     assert D.recombine_limbs(total, p) == [(8 * (p - 1)) % p] * len(vals)
+
+
+def test_bench_self_launch_relays_exit_code_without_gpu():
+    """`python bench.py --gpus 2` with no WORLD_SIZE starts its rank processes itself (a child launcher; the parent never
+    imports torch or touches a GPU) and relays their exit code: here, without a GPU, every rank refuses to run (the HIP
+    path has no CPU fallback), so the parent must exit non-zero and print no JSON line"""
+    import subprocess
+    import sys
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--num-vars", "12", "--steps", "1", "--warmup", "0",
+                          "--cpu-num-vars", "0"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    from conftest import has_gpu
+    if has_gpu():
+        return      # on a GPU box the run is real: covered by tests/test_gpu_00_multiprocess.py
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert "needs a GPU" in out.stderr
