@@ -127,7 +127,6 @@ struct sc_ctx {
   // 0 = not asked yet)
   int resident_blocks[2][4][4] = {};
   int time_kernels = 0;
-  int rowwalk_blocks = 0;   // tuning probe: blocks of a row-walking launch (0 = one wave per SIMD)
   int nt_load_log = 22;   // tables of >= 2^this entries are loaded nontemporal (measured: 21-25 equal, 27 and off worse)
   int nt_store_log = 25;  // outputs of >= 2^this entries are stored nontemporal
 
@@ -1017,7 +1016,7 @@ RowWalk row_walk_shape(const sc_ctx* ctx, size_t rows, size_t M) {
   s.pw = (mp % 256 == 0 && mp >= 1024) ? 4 : (mp % 128 == 0 && mp >= 256) ? 2 : 1;
   const size_t n_spans = (mp + 64 * (size_t)s.pw - 1) / (64 * (size_t)s.pw);
   s.gx = std::min<size_t>((n_spans + 3) / 4, 1024);
-  const size_t waves = ctx->rowwalk_blocks > 0 ? 4 * (size_t)ctx->rowwalk_blocks : 4 * (size_t)ctx->num_cus;
+  const size_t waves = 4 * (size_t)ctx->num_cus;   // one per SIMD
   size_t chunks = std::min<size_t>((waves + n_spans - 1) / n_spans, std::max<size_t>(rows / 16, 1));
   chunks = std::max<size_t>(1, std::min<size_t>(chunks, 1024));
   s.rows_per_chunk = (rows + chunks - 1) / chunks;
@@ -1396,9 +1395,6 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
     ctx->dbg_delay_ms = (int)value;
   } else if (k == "dbg_skip_tag") {
     ctx->dbg_skip_tag = value ? 1 : 0;
-  } else if (k == "rowwalk_blocks") {
-    if (value < 0 || value > 4096) return fail(ctx, SC_ERR_ARG, "%s out of range", key);
-    ctx->rowwalk_blocks = (int)value;
   } else if (k == "nt_load_log") {
     ctx->nt_load_log = (int)value;
   } else if (k == "nt_store_log") {
