@@ -2542,6 +2542,7 @@ int w_round_sums(sc_ctx* ctx, const WView& w, u64 e[3]) {
 }
 
 int evaluate_replicated(sc_ctx* ctx, const u64* d, size_t len, const u64* pt, u64* out);
+int fetch_word(sc_ctx* ctx, const u64* d, u64* out);
 
 }  // namespace
 
@@ -2705,11 +2706,7 @@ namespace {
 
 // value of a whole (unsharded) device table at an LE point, on this rank alone
 int evaluate_replicated(sc_ctx* ctx, const u64* d, size_t len, const u64* pt, u64* out) {
-  if (len == 1) {
-    SC_HIP(ctx, hipMemcpyAsync(out, d, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
-    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    return SC_OK;
-  }
+  if (len == 1) return fetch_word(ctx, d, out);
   HostField hf(ctx->fp);
   bool mb = false;
   SC_TRY(evaluate_local(ctx, d, len, pt, hf.one(), false, &mb));
@@ -3178,7 +3175,8 @@ struct sc_tri_prover {
 
 namespace {
 
-// Fold the challenges the sub-prover has not applied yet plus `r_last`; hand back its tables.
+// Fold the challenges the sub-prover has not applied yet plus `r_last`; hand back the table(s) asked for (a null
+// a_out / b_out: that table is not needed, its folds are not launched).
 int prover_finish(sc_prover* pr, u64 r_last, u64** a_out, u64** b_out, size_t* len_out) {
   sc_ctx* ctx = pr->ctx;
   std::vector<u64> rs(pr->pending);   // the sub-prover's own state is left untouched
@@ -3186,15 +3184,34 @@ int prover_finish(sc_prover* pr, u64 r_last, u64** a_out, u64** b_out, size_t* l
   const size_t len = (size_t)1 << pr->cur_log;
   u64 *na = nullptr, *nb = nullptr;
   size_t la = 0, lb = 0;
-  SC_TRY(fold_chain(ctx, pr->cur_a, len, rs.data(), rs.size(), SC_ORDER_LE, &na, &la));
-  int rc = fold_chain(ctx, pr->cur_b, len, rs.data(), rs.size(), SC_ORDER_LE, &nb, &lb);
-  if (rc != SC_OK) {
-    pool_release(ctx, na);
-    return rc;
+  if (a_out) SC_TRY(fold_chain(ctx, pr->cur_a, len, rs.data(), rs.size(), SC_ORDER_LE, &na, &la));
+  if (b_out) {
+    const int rc = fold_chain(ctx, pr->cur_b, len, rs.data(), rs.size(), SC_ORDER_LE, &nb, &lb);
+    if (rc != SC_OK) {
+      pool_release(ctx, na);
+      return rc;
+    }
   }
-  *a_out = na;
-  *b_out = nb;
-  *len_out = la;
+  if (a_out) *a_out = na;
+  if (b_out) *b_out = nb;
+  *len_out = a_out ? la : lb;
+  return SC_OK;
+}
+
+// one word of device memory to the host: through the pinned mailbox (a one-wave kernel + a spin on its sequence word,
+// ~5 us) rather than hipMemcpyAsync + hipStreamSynchronize (~40 us of host time around an 8-byte copy)
+int fetch_word(sc_ctx* ctx, const u64* d, u64* out) {
+  if (ctx->use_mailbox) {
+    const u64 seq = ctx->mailbox_seq + 1;
+    hipLaunchKernelGGL(sc::mailbox_copy_kernel, dim3(1), dim3(sc::kWave), 0, ctx->stream, d, 1, ctx->d_mailbox, seq);
+    SC_HIP(ctx, hipGetLastError());
+    ctx->mailbox_seq = seq;
+    SC_TRY(wait_mailbox(ctx, seq));
+    *out = ctx->h_mailbox[0];
+    return SC_OK;
+  }
+  SC_HIP(ctx, hipMemcpyAsync(out, d, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream));
+  SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
   return SC_OK;
 }
 
@@ -3322,10 +3339,9 @@ extern "C" int sc_tri_prover_round(sc_tri_prover* tp, uint64_t r_prev, size_t j,
   if (j == k) {
     // x fully fixed at r_x = r[0..k): P(r_x, .) is not needed any more, f3(r_x, .) is
     // every buffer lands in a member of tp at once, so an error return leaks nothing (destroy frees them)
-    u64 *pa = nullptr, *pb = nullptr;
+    u64* pb = nullptr;
     size_t len = 0;
-    SC_TRY_POP(prover_finish(tp->sub, r_prev, &pa, &pb, &len));
-    pool_release(ctx, pa);
+    SC_TRY_POP(prover_finish(tp->sub, r_prev, nullptr, &pb, &len));   // P(r_x, .) is not needed
     pool_release(ctx, tp->f3r);
     tp->f3r = pb;  // f3(r_x, z), 2^k entries
     size_t l1 = 0;
@@ -3336,18 +3352,12 @@ extern "C" int sc_tri_prover_round(sc_tri_prover* tp, uint64_t r_prev, size_t j,
     SC_TRY_POP(coldot(ctx, tp->adj, tp->f3r, n, n, tp->Q));  // Q[y] = sum_z f2[(z<<k)|y] f3r[z]
     SC_TRY_POP(tri_start_phase(tp, tp->f1y, tp->Q, n));
   } else if (j == 2 * k) {
-    u64 *pa = nullptr, *pb = nullptr;
+    u64* pa = nullptr;
     size_t len = 0;
-    SC_TRY_POP(prover_finish(tp->sub, r_prev, &pa, &pb, &len));
-    pool_release(ctx, pb);
-    hipError_t ce = hipMemcpyAsync(&tp->scale, pa, sizeof(u64), hipMemcpyDeviceToHost, ctx->stream);  // f1(r_x, r_y)
-    if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
+    SC_TRY_POP(prover_finish(tp->sub, r_prev, &pa, nullptr, &len));   // Q(r_y) is not needed
+    const int fr = fetch_word(ctx, pa, &tp->scale);                    // f1(r_x, r_y)
     pool_release(ctx, pa);
-    if (ce != hipSuccess) {
-      poison(ctx);
-      tp->r.pop_back();
-      return fail(ctx, SC_ERR_HIP, "triangle prover: %s", hipGetErrorString(ce));
-    }
+    SC_TRY_POP(fr);
     size_t l2 = 0;
     pool_release(ctx, tp->f2r);
     tp->f2r = nullptr;
