@@ -47,5 +47,7 @@ for n in ns:
         per = len(log) // 4
         avg = [sum(log[j + q * per]["ms"] for q in range(4)) / 4 for j in range(per)]
         desc = " ".join("%s%d,%d:%.1f" % ("g" if log[j]["kind"] == "grid_pass" else "", log[j]["kf"], log[j]["ks"], avg[j] * 1e3) for j in range(per))
-        print("n=%2d %-40s proof %s ms | %s" % (n, sets[i] or "(default)", " ".join("%.4f" % m for m in meds[i]), desc), flush=True)
+        lib = pkg.load()
+        where = "a@%#x b@%#x" % (int(lib.sc_table_device_ptr(tabs[i][0].h) or 0), int(lib.sc_table_device_ptr(tabs[i][1].h) or 0))
+        print("n=%2d %-40s proof %s ms | %s | %s" % (n, sets[i] or "(default)", " ".join("%.4f" % m for m in meds[i]), desc, where), flush=True)
     del gs, tabs
