@@ -145,22 +145,6 @@ struct sc_ctx {
   // device-buffer pool (free blocks by capacity in words; live blocks by pointer)
   std::multimap<size_t, u64*> pool_free;
   std::map<u64*, size_t> pool_live;
-  // Placement selection for the outputs of the first folding pass of a large proof (prover_pass): that pass runs at
-  // ~6.05 or at ~5.45 TB/s depending on how its output buffers lie relative to its input tables in physical memory
-  // (experiments/r03_fold_pass_two_modes.md: a pairwise property of (inputs, outputs), stable over time, invisible
-  // from user space).  The pool therefore holds up to placement_candidates pairs of output buffers of that size; the
-  // first proofs over a given pair of tables time the pass (one event pair) with each of them and later proofs use
-  // the fastest.  1 = off.
-  int placement_candidates = 4;
-  struct PlaceEntry {
-    const u64 *a = nullptr, *b = nullptr;   // the input tables (keys)
-    int log_in = 0, tries = 0, best = 0;
-    float ms[8] = {};
-  };
-  std::vector<PlaceEntry> place_cache;                              // a handful of recent table pairs
-  size_t place_next = 0;
-  std::map<size_t, std::vector<std::pair<u64*, u64*>>> place_sets;   // output size in words -> candidate pairs
-  hipEvent_t pl_ev[2] = {};
 
   // sharding
   Transport transport = Transport::kNone;
@@ -298,8 +282,6 @@ int pool_alloc(sc_ctx* ctx, size_t words, u64** out) {
     // release cached blocks and retry once
     for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
     ctx->pool_free.clear();
-    ctx->place_sets.clear();     // the placement candidates were among them: start the selection over
-    for (auto& pe : ctx->place_cache) pe.tries = pe.best = 0;
     e = hipMalloc(&p, words * sizeof(u64));
     if (e != hipSuccess)
       return fail(ctx, SC_ERR_OOM, "hipMalloc(%zu bytes): %s", words * sizeof(u64), hipGetErrorString(e));
@@ -315,29 +297,6 @@ void pool_release(sc_ctx* ctx, u64* p) {
   if (it == ctx->pool_live.end()) return;
   ctx->pool_free.emplace(it->second, p);
   ctx->pool_live.erase(it);
-}
-
-// take one particular cached block out of the pool (placement candidates); false if somebody else holds it
-bool pool_take(sc_ctx* ctx, u64* p, size_t min_words) {
-  for (auto it = ctx->pool_free.lower_bound(min_words); it != ctx->pool_free.end(); ++it) {
-    if (it->second == p) {
-      ctx->pool_live[p] = it->first;
-      ctx->pool_free.erase(it);
-      return true;
-    }
-  }
-  return false;
-}
-// a block that is certainly a NEW allocation (another placement), registered with the pool like any other
-int pool_alloc_fresh(sc_ctx* ctx, size_t words, u64** out) {
-  u64* p = nullptr;
-  if (hipMalloc(&p, words * sizeof(u64)) != hipSuccess) {
-    (void)hipGetLastError();
-    return SC_ERR_OOM;   // the caller falls back to the ordinary pool: not an error of the context
-  }
-  ctx->pool_live[p] = words;
-  *out = p;
-  return SC_OK;
 }
 
 int new_table(sc_ctx* ctx, size_t len, sc_table** out) {
@@ -1354,8 +1313,6 @@ extern "C" int sc_ctx_create(const sc_field* f, int device, sc_ctx** out) {
     SC_CREATE_HIP(hipEventCreate(&ctx->kt_ev[i][0]));
     SC_CREATE_HIP(hipEventCreate(&ctx->kt_ev[i][1]));
   }
-  SC_CREATE_HIP(hipEventCreate(&ctx->pl_ev[0]));
-  SC_CREATE_HIP(hipEventCreate(&ctx->pl_ev[1]));
 #undef SC_CREATE_HIP
   *out = ctx;
   return SC_OK;
@@ -1382,8 +1339,6 @@ extern "C" int sc_ctx_destroy(sc_ctx* ctx) {
   for (int i = 0; i < sc_ctx::kTimerRing; ++i)
     for (int k = 0; k < 2; ++k)
       if (ctx->kt_ev[i][k]) (void)hipEventDestroy(ctx->kt_ev[i][k]);
-  for (int k = 0; k < 2; ++k)
-    if (ctx->pl_ev[k]) (void)hipEventDestroy(ctx->pl_ev[k]);
   if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
   delete ctx;
   return SC_OK;
@@ -1440,9 +1395,6 @@ extern "C" int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value) {
     ctx->dbg_delay_ms = (int)value;
   } else if (k == "dbg_skip_tag") {
     ctx->dbg_skip_tag = value ? 1 : 0;
-  } else if (k == "placement_candidates") {
-    if (value < 1 || value > 8) return fail(ctx, SC_ERR_ARG, "placement_candidates must be 1..8");
-    ctx->placement_candidates = (int)value;
   } else if (k == "nt_load_log") {
     ctx->nt_load_log = (int)value;
   } else if (k == "nt_store_log") {
@@ -1470,7 +1422,6 @@ extern "C" int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* va
   else if (k == "arena_log") *value = ctx->arena_log;
   else if (k == "peer_spin_ms") *value = ctx->peer_spin_ms;
   else if (k == "nt_load_log") *value = ctx->nt_load_log;
-  else if (k == "placement_candidates") *value = ctx->placement_candidates;
   else if (k == "nt_store_log") *value = ctx->nt_store_log;
   else if (k == "peer_connect_ms") *value = ctx->peer_connect_ms;
   else if (k == "dbg_delay_ms") *value = ctx->dbg_delay_ms;
@@ -2321,64 +2272,13 @@ int prover_pass(sc_prover* pr, size_t j) {
     return fail(ctx, SC_ERR_STATE, "prover: table has %d variables, pass needs %d", pr->cur_log, kf + ks);
 
   u64 *na = nullptr, *nb = nullptr;
-  sc_ctx::PlaceEntry* pe = nullptr;   // non-null: this pass is being timed for the placement selection
-  int cand = -1;
   if (kf > 0) {
     size_t out_len = (size_t)1 << (pr->cur_log - kf);
-    // the first folding pass of a large proof (inputs = the caller's tables, outputs >= 128 MiB each): pick the
-    // output pair among the candidates (sc_ctx::placement_candidates)
-    if (ctx->placement_candidates > 1 && !by_grid && pr->cur_a == pr->a0 && out_len >= ((size_t)1 << 24)) {
-      for (auto& e : ctx->place_cache)
-        if (e.a == pr->a0 && e.b == pr->b0 && e.log_in == pr->cur_log) pe = &e;
-      if (!pe) {
-        if (ctx->place_cache.size() < 8) {
-          ctx->place_cache.emplace_back();
-          pe = &ctx->place_cache.back();
-        } else {
-          pe = &ctx->place_cache[ctx->place_next++ % 8];
-          *pe = sc_ctx::PlaceEntry();
-        }
-        pe->a = pr->a0;
-        pe->b = pr->b0;
-        pe->log_in = pr->cur_log;
-      }
-      const int K = ctx->placement_candidates;
-      cand = pe->tries < K ? pe->tries : pe->best;
-      auto& set = ctx->place_sets[out_len];
-      bool ok = true;
-      while (ok && (int)set.size() <= cand) {   // grow the candidate set with fresh allocations
-        u64 *ca = nullptr, *cb = nullptr;
-        if (set.empty()) {
-          ok = pool_alloc(ctx, out_len, &ca) == SC_OK && pool_alloc(ctx, out_len, &cb) == SC_OK;   // candidate 0: whatever the pool has
-        } else {
-          ok = pool_alloc_fresh(ctx, out_len, &ca) == SC_OK && pool_alloc_fresh(ctx, out_len, &cb) == SC_OK;
-        }
-        if (!ok) {
-          pool_release(ctx, ca);
-          pool_release(ctx, cb);
-          break;
-        }
-        set.emplace_back(ca, cb);
-        pool_release(ctx, ca);   // candidates rest in the pool like any cached block
-        pool_release(ctx, cb);
-      }
-      if (ok && pool_take(ctx, set[cand].first, out_len)) {
-        if (pool_take(ctx, set[cand].second, out_len)) {
-          na = set[cand].first;
-          nb = set[cand].second;
-        } else {
-          pool_release(ctx, set[cand].first);
-        }
-      }
-      if (!na || pe->tries >= K) pe = nullptr;   // only exploration passes are timed; a busy candidate: the ordinary path
-    }
-    if (!na) {
-      SC_TRY(pool_alloc(ctx, out_len, &na));
-      int rc = pool_alloc(ctx, out_len, &nb);
-      if (rc != SC_OK) {
-        pool_release(ctx, na);
-        return rc;
-      }
+    SC_TRY(pool_alloc(ctx, out_len, &na));
+    int rc = pool_alloc(ctx, out_len, &nb);
+    if (rc != SC_OK) {
+      pool_release(ctx, na);
+      return rc;
     }
   }
   bool mb = false;
@@ -2387,20 +2287,8 @@ int prover_pass(sc_prover* pr, size_t j) {
     rc = launch_grid_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, pr->pending.data(), pr->cur_log, pr->sharded);
     if (rc == SC_OK) rc = collect_grid(ctx, ks, pr->sharded, pr->S);
   } else {
-    if (pe) (void)hipEventRecord(ctx->pl_ev[0], ctx->stream);
     rc = launch_pass(ctx, kf, ks, pr->cur_a, pr->cur_b, na, nb, pr->pending.data(), pr->cur_log, pr->sharded, &mb);
-    if (pe) (void)hipEventRecord(ctx->pl_ev[1], ctx->stream);
     if (rc == SC_OK) rc = collect_sums(ctx, ks == 1 ? 3 : ks == 2 ? 9 : 27, pr->sharded, mb, pr->S);
-    if (pe && rc == SC_OK) {
-      float ms = 0.f;
-      if (hipEventSynchronize(ctx->pl_ev[1]) == hipSuccess && hipEventElapsedTime(&ms, ctx->pl_ev[0], ctx->pl_ev[1]) == hipSuccess && ms > 0.f) {
-        pe->ms[cand] = ms;
-        if (pe->tries == 0 || ms < pe->ms[pe->best]) pe->best = cand;
-        pe->tries += 1;
-      } else {
-        (void)hipGetLastError();
-      }
-    }
   }
   if (rc != SC_OK) {
     pool_release(ctx, na);
