@@ -80,7 +80,10 @@ def test_bench_widened_workloads(workload, size, cpu_size, kernel):
     assert d["n_gpus"] == 1 and d["steps"] == 4 and d["value"] > 0 and d["dtype"] == "u64"
     assert "bit-exact vs CPU oracle" in d["config"]["parity_gate"] and "workload" in d["config"]
     r = d["roofline"]
-    assert r["bound"] == "hbm" and 0 < r["frac"] <= 1.0 and kernel in r["kernel"]
+    # (the triangle workload's dominant launch group is either a streaming pass or, on small graphs, the int8 MFMA square)
+    assert r["bound"] in (("hbm", "mfma") if workload == "triangle" else ("hbm",)) and 0 < r["frac"] <= 1.0 and kernel in r["kernel"]
+    if workload == "triangle":
+        assert r["matsq"]["bound"] == "mfma" and r["matsq"]["achieved"] > 0
     assert abs(sum(k["bytes_per_launch"] * k["launches_per_step"] for k in r["kernels"]) - r["step"]["bytes_moved"]) < 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
