@@ -236,6 +236,26 @@ int sc_prover_create(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_prove
 int sc_prover_c1(const sc_prover* pr, uint64_t* out);
 /* Prover::num_vars (:114-116) */
 int sc_prover_num_vars(const sc_prover* pr, size_t* out);
+/* The schedule of a proof WITHOUT a device: the launches sc_prove would issue for a proof of num_vars variables on a
+ * communicator of `world` ranks over `transport` (0 none, 1 RCCL, 2 host callbacks, 3 peer), computed by the same
+ * planner the engine runs at every pass (pure host logic: callable - and tested - on a machine without a GPU).
+ * Steps come in launch order; `kf` challenges are folded and `ks` rounds served by each; `log_in` = log2 entries per
+ * table on a rank; `sharded` = its sums are exchanged across the ranks.  SC_PLAN_GATHER is the all-gather of both
+ * tables (no rounds).  Returns SC_ERR_STATE for option combinations the engine would refuse. */
+#define SC_PLAN_PASS 0       /* pass_kernel<kf,ks> */
+#define SC_PLAN_GRID_PASS 1  /* wgrid_pass_kernel: up to five rounds */
+#define SC_PLAN_RANK_PASS 2  /* rank_pass_kernel (peer transport): the rounds of the rank bits */
+#define SC_PLAN_GATHER 3     /* all-gather of the shards; the proof goes on replicated */
+typedef struct sc_plan_options {   /* the context options the schedule depends on (sc_ctx_set_option names) */
+  int32_t vars_per_pass, first_pass_vars, grid_pass, grid_log, grid_max_vars, grid_sharded, tail_log, use_mailbox;
+} sc_plan_options;
+typedef struct sc_plan_step {
+  int32_t action, kf, ks, log_in, sharded;
+} sc_plan_step;
+void sc_plan_options_default(sc_plan_options* o);
+int sc_plan_proof(const sc_plan_options* opt, size_t num_vars, int world, int transport, sc_plan_step* out, size_t cap,
+                  size_t* n_out);
+
 /* Prover::round(r_prev, j) (:105-112).  Rounds must be called in order j = 0,1,...;
  * r_prev is ignored for j == 0 like in the reference.  out_e = (H(0),H(1),H(2)) of the
  * round polynomial; sc_interpolate_quadratic turns it into the coefficients that

@@ -42,6 +42,29 @@ pub struct sc_ctx {
 pub struct sc_table {
     _private: [u8; 0],
 }
+/// The context options the schedule depends on (`sc_plan_proof`).
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct sc_plan_options {
+    pub vars_per_pass: i32,
+    pub first_pass_vars: i32,
+    pub grid_pass: i32,
+    pub grid_log: i32,
+    pub grid_max_vars: i32,
+    pub grid_sharded: i32,
+    pub tail_log: i32,
+    pub use_mailbox: i32,
+}
+/// One launch of a planned proof: `action` is one of the `SC_PLAN_*` values of the header.
+#[repr(C)]
+#[derive(Clone, Copy, Debug, Default)]
+pub struct sc_plan_step {
+    pub action: i32,
+    pub kf: i32,
+    pub ks: i32,
+    pub log_in: i32,
+    pub sharded: i32,
+}
 #[repr(C)]
 pub struct sc_prover {
     _private: [u8; 0],
@@ -164,6 +187,16 @@ extern "C" {
         out: *mut u64,
     ) -> c_int;
 
+    pub fn sc_plan_options_default(o: *mut sc_plan_options);
+    pub fn sc_plan_proof(
+        opt: *const sc_plan_options,
+        num_vars: usize,
+        world: c_int,
+        transport: c_int,
+        out: *mut sc_plan_step,
+        cap: usize,
+        n_out: *mut usize,
+    ) -> c_int;
     pub fn sc_prover_create(
         ctx: *mut sc_ctx,
         a: *const sc_table,

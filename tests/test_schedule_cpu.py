@@ -1,0 +1,95 @@
+"""The prover's schedule as pure host logic (sc_plan_proof = the planner the engine runs at every pass): invariants over
+every (num_vars, world, transport, options) the library accepts - checked WITHOUT a GPU.  The GPU suite checks that
+the launches of real proofs are exactly these plans (tests/test_gpu_schedule.py)."""
+import itertools
+
+import pytest
+
+from conftest import load_package
+
+
+@pytest.fixture(scope="module")
+def plan():
+    return load_package().schedule.plan_proof
+
+
+OPTION_SETS = [
+    {}, {"grid_pass": 0}, {"vars_per_pass": 1}, {"first_pass_vars": 1}, {"first_pass_vars": 2}, {"first_pass_vars": 3},
+    {"grid_max_vars": 1}, {"grid_max_vars": 3}, {"grid_log": 3}, {"grid_log": 26}, {"grid_sharded": 0}, {"grid_sharded": 0, "tail_log": 4},
+    {"grid_sharded": 0, "tail_log": 0, "grid_pass": 0}, {"use_mailbox": 0}, {"grid_max_vars": 4, "grid_log": 12, "first_pass_vars": 2},
+]
+
+
+def check(steps, n, world, transport, opts):
+    g = world.bit_length() - 1
+    served = sum(s["ks"] for s in steps)
+    assert served == n, (served, n)
+    cur_log, kf, sharded = n - g, 0, transport != "none"
+    gmax = opts.get("grid_max_vars", 5)
+    for s in steps:
+        assert s["log_in"] == cur_log and s["sharded"] == (sharded if s["action"] != "gather" else True), (s, cur_log, sharded)
+        if s["action"] == "gather":
+            assert sharded and world > 1 or transport != "none"
+            cur_log += g
+            sharded = False
+            continue
+        assert s["kf"] == kf, (s, kf)
+        if s["action"] == "rank_pass":
+            assert transport == "peer" and sharded and cur_log == kf and s["ks"] == g and 1 <= g <= 3 and kf <= 5
+            cur_log, sharded = g, False
+        elif s["action"] == "pass":
+            assert kf <= 3 and 1 <= s["ks"] <= 3 and (s["ks"] < 3 or kf == 0) and cur_log >= kf + s["ks"]
+            assert s["ks"] <= max(opts.get("vars_per_pass", 2), 1) or (kf == 0 and s["ks"] == 3)
+            cur_log -= kf
+        else:
+            assert s["action"] == "grid_pass" and kf <= 5 and 1 <= s["ks"] <= gmax and cur_log >= kf + s["ks"]
+            assert cur_log - kf <= opts.get("grid_log", 20) and opts.get("grid_pass", 1) == 1 and opts.get("use_mailbox", 1) == 1
+            assert not sharded or opts.get("grid_sharded", 1) == 1
+            cur_log -= kf
+        kf = s["ks"]
+    # whatever is left after the last launch are the variables its cached grid serves
+    assert cur_log >= 0
+
+
+@pytest.mark.parametrize("opts", OPTION_SETS, ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()) or "default")
+def test_plan_invariants(plan, opts):
+    for world, transport in [(1, "none"), (1, "peer"), (1, "rccl"), (2, "peer"), (2, "rccl"), (4, "host"), (8, "peer"), (8, "rccl"), (8, "host")]:
+        g = world.bit_length() - 1
+        for n in range(max(g, 1), 41):
+            steps = plan(n, world, transport, **opts)     # none of these combinations may be refused
+            check(steps, n, world, transport, opts)
+
+
+def test_known_schedules(plan):
+    def sig(steps):
+        return [(s["action"], s["kf"], s["ks"], s["log_in"]) for s in steps]
+
+    # the headline: n = 28 on one GPU (bench.py config.schedule of every run)
+    assert sig(plan(28)) == [("pass", 0, 3, 28), ("pass", 3, 2, 28), ("pass", 2, 2, 25), ("pass", 2, 2, 23), ("grid_pass", 2, 5, 21),
+                             ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14), ("grid_pass", 5, 4, 9)]
+    # BASELINE config 4: n = 28 over 8 ranks, peer transport - seven launches, seven exchanges, no gather
+    s8 = plan(28, 8, "peer")
+    assert sig(s8) == [("pass", 0, 3, 25), ("pass", 3, 2, 25), ("grid_pass", 2, 5, 22), ("grid_pass", 5, 5, 20), ("grid_pass", 5, 5, 15),
+                       ("grid_pass", 5, 5, 10), ("rank_pass", 5, 3, 5)]
+    assert all(s["sharded"] for s in s8)
+    # the same over RCCL: the shard is gathered when it is down to its pending challenges, the rank bits are one more pass
+    r8 = plan(28, 8, "rccl")
+    assert sig(r8)[:6] == sig(s8)[:6] and sig(r8)[6:] == [("gather", 0, 0, 5), ("grid_pass", 5, 3, 8)]
+    # two rounds per pass with a gather at 2^16-entry shards (grid_sharded 0): round 1's sharded schedule
+    t8 = plan(28, 8, "rccl", grid_sharded=0)
+    assert [s["action"] for s in t8].count("gather") == 1 and t8[[s["action"] for s in t8].index("gather")]["log_in"] == 16
+    # small proofs are grid passes alone, five rounds per launch
+    assert sig(plan(12)) == [("grid_pass", 0, 4, 12), ("grid_pass", 4, 4, 12), ("grid_pass", 4, 4, 8)]
+    assert len(plan(20)) == 4 and len(plan(5)) == 1
+
+
+def test_plan_argument_checks(plan):
+    pkg = load_package()
+    for bad in [dict(num_vars=2, world=8, transport="peer"), dict(num_vars=10, world=3, transport="peer"),
+                dict(num_vars=10, world=2, transport="none"), dict(num_vars=10, world=1, transport="none", grid_max_vars=6),
+                dict(num_vars=10, world=1, transport="none", vars_per_pass=3)]:
+        with pytest.raises(pkg.SumcheckHipError) as ei:
+            plan(**bad)
+        assert ei.value.code == 1
+    with pytest.raises(KeyError):
+        plan(10, no_such_option=1)

@@ -7,4 +7,4 @@ from . import _lib  # noqa: F401
 from ._lib import ORDER_BE, ORDER_LE, SumcheckHipError, build, load  # noqa: F401
 from .field import GOLDILOCKS, Field  # noqa: F401
 from .dense_mle import Context, DenseMultilinearExtension  # noqa: F401
-from . import sum_check_protocol, matrix_multiplication, multilinear_extensions, distributed, gkr_protocol, triangle_counting, fiat_shamir, synthetic  # noqa: F401
+from . import sum_check_protocol, matrix_multiplication, multilinear_extensions, distributed, gkr_protocol, triangle_counting, fiat_shamir, synthetic, schedule  # noqa: F401

@@ -26,6 +26,19 @@ class ScField(ctypes.Structure):
     _fields_ = [("p", u64), ("p_inv_neg", u64), ("r_mod_p", u64), ("r2_mod_p", u64)]
 
 
+class ScPlanOptions(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ("vars_per_pass", "first_pass_vars", "grid_pass", "grid_log", "grid_max_vars", "grid_sharded",
+                                             "tail_log", "use_mailbox")]
+
+
+class ScPlanStep(ctypes.Structure):
+    _fields_ = [(k, ctypes.c_int32) for k in ("action", "kf", "ks", "log_in", "sharded")]
+
+
+PLAN_ACTIONS = {0: "pass", 1: "grid_pass", 2: "rank_pass", 3: "gather"}
+TRANSPORTS = {"none": 0, "rccl": 1, "host": 2, "peer": 3}
+
+
 class ScLaunchRecord(ctypes.Structure):
     _fields_ = [("kind", ctypes.c_int32), ("kf", ctypes.c_int32), ("ks", ctypes.c_int32), ("log_in", ctypes.c_int32),
                 ("bytes_read", u64), ("bytes_written", u64), ("ms", ctypes.c_double)]
@@ -75,6 +88,9 @@ SIGNATURES = {
     "sc_prod2_round_sums": (ctypes.c_int, [voidp, voidp, voidp, u64p]),
     "sc_prod2_fold_and_sums": (ctypes.c_int, [voidp, voidp, voidp, u64p, ctypes.POINTER(voidp), ctypes.POINTER(voidp), u64p]),
     "sc_prod2_evaluate": (ctypes.c_int, [voidp, voidp, voidp, u64p, size_t, u64p]),
+    "sc_plan_options_default": (None, [ctypes.POINTER(ScPlanOptions)]),
+    "sc_plan_proof": (ctypes.c_int, [ctypes.POINTER(ScPlanOptions), size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ScPlanStep), size_t,
+                                     ctypes.POINTER(size_t)]),
     "sc_prover_create": (ctypes.c_int, [voidp, voidp, voidp, ctypes.POINTER(voidp)]),
     "sc_prover_c1": (ctypes.c_int, [voidp, u64p]),
     "sc_prover_num_vars": (ctypes.c_int, [voidp, ctypes.POINTER(size_t)]),

@@ -2154,17 +2154,30 @@ struct sc_prover {
 
 namespace {
 
+// ---- the schedule: PURE host logic (no device, no context), shared by the engine and by sc_plan_proof ---------------
+
 // measured (two vs three rounds from the first pass, ms): n = 16 0.109 / 0.116, 18 0.128 / 0.125, 20 0.167 / 0.152,
 // 22 0.204 / 0.198, 24 0.307 / 0.294, 26 0.75 / 0.68, 28 2.36 / 2.13
 constexpr int kFirstPass3Log = 18;
 
+// the options the schedule depends on + the communicator's shape
+struct PlanOpts {
+  int vars_per_pass, first_pass_vars, grid_pass, grid_log, grid_max_vars, grid_sharded, tail_log, use_mailbox;
+  int transport;   // sc_plan_options.h numbering = Transport: 0 none, 1 RCCL, 2 host callbacks, 3 peer
+  int log_world;
+};
+PlanOpts plan_opts_of(const sc_ctx* ctx) {
+  return PlanOpts{ctx->vars_per_pass, ctx->first_pass_vars, ctx->grid_pass, ctx->grid_log, ctx->grid_max_vars, ctx->grid_sharded,
+                  ctx->tail_log, ctx->use_mailbox, (int)ctx->transport, ctx->log_world};
+}
+
 // rounds a pass_kernel launch at round j serves (the schedule of DESIGN.md section 4)
-int pass_rounds(const sc_ctx* ctx, size_t num_vars, size_t j, int kf, int cur_log) {
+int pass_rounds(const PlanOpts& o, size_t num_vars, size_t j, int kf, int cur_log) {
   const size_t remaining = num_vars - j;  // variables left including round j's
-  int ks = (ctx->vars_per_pass == 2 && remaining >= 2) ? 2 : 1;
+  int ks = (o.vars_per_pass == 2 && remaining >= 2) ? 2 : 1;
   if (j == 0 && kf == 0) {
-    const int first = ctx->first_pass_vars ? ctx->first_pass_vars : (cur_log >= kFirstPass3Log ? 3 : 2);
-    if (ctx->vars_per_pass == 2 && remaining >= 3 && first == 3) ks = 3;
+    const int first = o.first_pass_vars ? o.first_pass_vars : (cur_log >= kFirstPass3Log ? 3 : 2);
+    if (o.vars_per_pass == 2 && remaining >= 3 && first == 3) ks = 3;
     if (first < ks) ks = first;
   }
   return ks;
@@ -2172,19 +2185,62 @@ int pass_rounds(const sc_ctx* ctx, size_t num_vars, size_t j, int kf, int cur_lo
 
 // Rounds a grid pass (kernels.hpp, wgrid_pass_kernel) serves when `vars` variables are left, i.e. the folded table
 // has 2^vars entries: as few passes as grid_max_vars allows, the rounds shared evenly among them.
-int grid_passes_needed(const sc_ctx* ctx, int vars) { return (vars + ctx->grid_max_vars - 1) / ctx->grid_max_vars; }
-int grid_rounds(const sc_ctx* ctx, int vars) {
-  const int need = grid_passes_needed(ctx, vars);
+int grid_passes_needed(const PlanOpts& o, int vars) { return (vars + o.grid_max_vars - 1) / o.grid_max_vars; }
+int grid_rounds(const PlanOpts& o, int vars) {
+  const int need = grid_passes_needed(o, vars);
   return std::max(1, std::min((vars + need - 1) / need, vars));
 }
 // does the pass at round j go to wgrid_pass_kernel?  The folded table (on a sharded prover: the folded shard) must be
 // small enough and keep at least one variable.  (The one-round-per-pass mode and an explicit first_pass_vars are
 // requests for those schedules.)
-bool takes_grid_pass(const sc_ctx* ctx, bool sharded, int cur_log, int kf, size_t j) {
-  if (!ctx->grid_pass || !ctx->use_mailbox || ctx->vars_per_pass != 2) return false;
-  if (sharded && !ctx->grid_sharded) return false;
-  if (j == 0 && kf == 0 && ctx->first_pass_vars != 0) return false;
-  return cur_log - kf >= 1 && cur_log - kf <= ctx->grid_log;
+bool takes_grid_pass(const PlanOpts& o, bool sharded, int cur_log, int kf, size_t j) {
+  if (!o.grid_pass || !o.use_mailbox || o.vars_per_pass != 2) return false;
+  if (sharded && !o.grid_sharded) return false;
+  if (j == 0 && kf == 0 && o.first_pass_vars != 0) return false;
+  return cur_log - kf >= 1 && cur_log - kf <= o.grid_log;
+}
+
+// What the prover does at round j when its cache does not cover the round: the state is (kf pending challenges, local
+// tables of 2^cur_log entries, still sharded or not).
+//   Sharded: pairs (2b, 2b+1) stay shard-local while the local table still has the kf+ks variables this pass
+//   touches.  A shard that can go on with five-round passes (exchange inside the kernel / one collective per pass)
+//   is gathered only when it is down to its pending challenges: 2^kf <= 32 entries.  Otherwise (grid_sharded 0)
+//   it is gathered at tail_log: below that the latency of a collective per two-round pass costs more than finishing
+//   redundantly on every rank.  On the peer transport, when nothing but the pending challenges is left, the rounds of
+//   the rank bits are ONE small launch: fold, exchange the single entries (the gather), cells.
+struct PassPlan {
+  enum Kind { kPass = SC_PLAN_PASS, kGridPass = SC_PLAN_GRID_PASS, kRankPass = SC_PLAN_RANK_PASS } kind;
+  bool gather_first;   // all-gather both tables (cur_log += log_world, unsharded from here on) before the launch
+  int ks;              // rounds the launch serves
+  const char* error;   // non-null: the state cannot be continued (a caller bug or an option combination without a kernel)
+};
+PassPlan plan_pass(const PlanOpts& o, size_t num_vars, size_t j, int kf, int cur_log, bool sharded) {
+  PassPlan p{PassPlan::kPass, false, 0, nullptr};
+  if (kf > sc::kGridMaxVars) {
+    p.error = "more unfolded challenges than a pass can fold";
+    return p;
+  }
+  int ks = pass_rounds(o, num_vars, j, kf, cur_log);
+  const bool shard_grid = sharded && takes_grid_pass(o, true, cur_log, kf, j);
+  if (sharded && !shard_grid && o.transport == (int)Transport::kPeer && cur_log == kf && o.log_world >= 1 && o.log_world <= 3 &&
+      num_vars - j == (size_t)o.log_world && takes_grid_pass(o, true, cur_log + 1, kf, j)) {
+    p.kind = PassPlan::kRankPass;
+    p.ks = o.log_world;
+    return p;
+  }
+  if (sharded && !shard_grid && (cur_log < kf + ks || cur_log <= o.tail_log)) {
+    p.gather_first = true;
+    cur_log += o.log_world;
+    sharded = false;
+  }
+  // the smallest tables: up to five rounds per pass (after a gather the table is whole: decided on that)
+  const bool by_grid = takes_grid_pass(o, sharded, cur_log, kf, j);
+  if (by_grid) ks = grid_rounds(o, cur_log - kf);   // sharded: planned on the shard's own variables
+  if (kf > 3 && !by_grid) p.error = "unfolded challenges and no grid pass to fold them";
+  else if (cur_log < kf + ks) p.error = "the table has fewer variables than the pass needs";
+  p.kind = by_grid ? PassPlan::kGridPass : PassPlan::kPass;
+  p.ks = ks;
+  return p;
 }
 
 // all-gather both tables of a sharded prover into pool buffers (any transport)
@@ -2215,20 +2271,10 @@ int gather_pair(sc_ctx* ctx, const u64* a, const u64* b, size_t len, u64** fa, u
 int prover_pass(sc_prover* pr, size_t j) {
   sc_ctx* ctx = pr->ctx;
   const int kf = (int)pr->pending.size();
-  int ks = pass_rounds(ctx, pr->num_vars, j, kf, pr->cur_log);
-  if (kf > sc::kGridMaxVars) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges", kf);
-
-  // Sharded: pairs (2b, 2b+1) stay shard-local while the local table still has the kf+ks variables this pass
-  // touches.  A shard that can go on with five-round passes (exchange inside the kernel / one collective per pass)
-  // is gathered only when it is down to its pending challenges: 2^kf <= 32 entries.  Otherwise (grid_sharded 0)
-  // it is gathered at tail_log: below that the latency of a collective per two-round pass costs more than finishing
-  // redundantly on every rank.
-  const bool shard_grid = pr->sharded && takes_grid_pass(ctx, true, pr->cur_log, kf, j);
-  // ... and on the peer transport, when nothing but the pending challenges is left, the rounds of the rank bits are
-  // one small launch: fold, exchange the single entries (the gather), cells - instead of a gather launch and a pass
-  // on the gathered table
-  if (pr->sharded && !shard_grid && ctx->transport == Transport::kPeer && pr->cur_log == kf && ctx->log_world >= 1 &&
-      ctx->log_world <= 3 && pr->num_vars - j == (size_t)ctx->log_world && takes_grid_pass(ctx, true, pr->cur_log + 1, kf, j)) {
+  const PassPlan plan = plan_pass(plan_opts_of(ctx), pr->num_vars, j, kf, pr->cur_log, pr->sharded);
+  if (plan.error) return fail(ctx, SC_ERR_STATE, "prover (round %zu, %d pending, 2^%d entries): %s", j, kf, pr->cur_log, plan.error);
+  const int ks = plan.ks;
+  if (plan.kind == PassPlan::kRankPass) {
     u64 *na = nullptr, *nb = nullptr;
     SC_TRY(pool_alloc(ctx, (size_t)ctx->world, &na));
     int rc = pool_alloc(ctx, (size_t)ctx->world, &nb);
@@ -2252,7 +2298,7 @@ int prover_pass(sc_prover* pr, size_t j) {
     pr->g_known = -1;
     return SC_OK;
   }
-  if (pr->sharded && !shard_grid && (pr->cur_log < kf + ks || pr->cur_log <= ctx->tail_log)) {
+  if (plan.gather_first) {
     u64 *fa = nullptr, *fb = nullptr;
     SC_TRY(gather_pair(ctx, pr->cur_a, pr->cur_b, (size_t)1 << pr->cur_log, &fa, &fb));
     pool_release(ctx, pr->own_a);
@@ -2264,12 +2310,7 @@ int prover_pass(sc_prover* pr, size_t j) {
     pr->cur_log += ctx->log_world;
     pr->sharded = false;
   }
-  // the smallest tables: up to five rounds per pass (after a gather the table is whole: decide here)
-  const bool by_grid = takes_grid_pass(ctx, pr->sharded, pr->cur_log, kf, j);
-  if (by_grid) ks = grid_rounds(ctx, pr->cur_log - kf);   // sharded: planned on the shard's own variables
-  if (kf > 3 && !by_grid) return fail(ctx, SC_ERR_STATE, "prover: %d unfolded challenges and no grid pass to fold them", kf);
-  if (pr->cur_log < kf + ks)
-    return fail(ctx, SC_ERR_STATE, "prover: table has %d variables, pass needs %d", pr->cur_log, kf + ks);
+  const bool by_grid = plan.kind == PassPlan::kGridPass;
 
   u64 *na = nullptr, *nb = nullptr;
   if (kf > 0) {
@@ -2400,6 +2441,62 @@ static int prover_create_impl(sc_ctx* ctx, const sc_table* a, const sc_table* b,
   prover_answer(pr, 0, e);
   pr->c1 = hf.add(e[0], e[1]);
   *out = pr;
+  return SC_OK;
+}
+
+extern "C" void sc_plan_options_default(sc_plan_options* o) {
+  if (!o) return;
+  const sc_ctx d{};   // the defaults are the context's member initialisers (no device is touched)
+  o->vars_per_pass = d.vars_per_pass;
+  o->first_pass_vars = d.first_pass_vars;
+  o->grid_pass = d.grid_pass;
+  o->grid_log = d.grid_log;
+  o->grid_max_vars = d.grid_max_vars;
+  o->grid_sharded = d.grid_sharded;
+  o->tail_log = d.tail_log;
+  o->use_mailbox = d.use_mailbox;
+}
+
+// The launches of a whole proof, by the planner the engine itself runs (plan_pass): a dry run of sc_prove's state machine.
+extern "C" int sc_plan_proof(const sc_plan_options* opt, size_t num_vars, int world, int transport, sc_plan_step* out, size_t cap,
+                             size_t* n_out) {
+  if (!opt || !n_out || (cap && !out)) return SC_ERR_ARG;
+  if (world < 1 || !is_pow2((size_t)world) || transport < 0 || transport > 3 || (world > 1 && transport == 0)) return SC_ERR_ARG;
+  if (opt->vars_per_pass < 1 || opt->vars_per_pass > 2 || opt->first_pass_vars < 0 || opt->first_pass_vars > 3 || opt->grid_log < 0 ||
+      opt->grid_log > 26 || opt->grid_max_vars < 1 || opt->grid_max_vars > sc::kGridMaxVars || opt->tail_log < 0)
+    return SC_ERR_ARG;
+  const int g = log2_of((size_t)world);
+  if (num_vars < (size_t)g || num_vars > 62) return SC_ERR_ARG;
+  const PlanOpts o{opt->vars_per_pass, opt->first_pass_vars, opt->grid_pass, opt->grid_log, opt->grid_max_vars, opt->grid_sharded,
+                   opt->tail_log, opt->use_mailbox, transport, g};
+  // the prover's state: local table size, pending challenges, still sharded?
+  int cur_log = (int)num_vars - g, kf = 0;
+  bool sharded = transport != 0;
+  size_t n = 0, j = 0;
+  auto emit = [&](int action, int kf_, int ks_, int log_in, bool sh) {
+    if (n < cap) out[n] = sc_plan_step{action, kf_, ks_, log_in, sh ? 1 : 0};
+    ++n;
+  };
+  while (j < num_vars) {
+    const PassPlan p = plan_pass(o, num_vars, j, kf, cur_log, sharded);
+    if (p.error) return SC_ERR_STATE;
+    if (p.kind == PassPlan::kRankPass) {
+      emit(SC_PLAN_RANK_PASS, kf, p.ks, cur_log, true);
+      cur_log = g;
+      sharded = false;
+    } else {
+      if (p.gather_first) {
+        emit(SC_PLAN_GATHER, 0, 0, cur_log, true);
+        cur_log += g;
+        sharded = false;
+      }
+      emit(p.kind, kf, p.ks, cur_log, sharded);
+      cur_log -= kf;
+    }
+    kf = p.ks;   // the rounds the launch serves are answered from its cache; their challenges are pending at the next one
+    j += (size_t)p.ks;
+  }
+  *n_out = n;
   return SC_OK;
 }
 
