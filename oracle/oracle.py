@@ -186,7 +186,7 @@ class Oracle:
         return s
 
     def gridk_sums(self, a, b, k):
-        """3^k-cell grid in the {0,1,inf} basis, first variable on the slowest axis (k = 1, 2, 3)"""
+        """3^k-cell grid in the {0,1,inf} basis, first variable on the slowest axis (k = 1 .. 5)"""
         s = np.empty(3 ** k, dtype=np.uint64)
         self.lib.sco_g_gridk_sums(self.fp, _ptr(a), _ptr(b), self._nv(a), k, _ptr(s))
         return s

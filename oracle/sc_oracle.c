@@ -536,7 +536,7 @@ void sco_g_gridk_sums(const sco_field* f, const u64* a, const u64* b, size_t nv,
   size_t blocks = (size_t)1 << (nv - (size_t)k);
   for (size_t q = 0; q < blocks; ++q) {
     for (int cell = 0; cell < cells; ++cell) {
-      int c[3], rem = cell;
+      int c[8], rem = cell;   /* k <= 5 in practice (243 cells) */
       for (int d = k - 1; d >= 0; --d) {
         c[d] = rem % 3;
         rem /= 3;

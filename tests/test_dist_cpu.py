@@ -1,9 +1,11 @@
 """World-size-2 (and 4) gloo tests on CPU for the N > 1 path: the shard plan, the 32-bit
 limb all-reduce, the tail gather and the torch.distributed adapter that
-`Context.comm_init_host` uses.  The GPU kernels cannot run here, so the oracle stands in
-for them inside a Python model of the engine's schedule; the model and the engine are
-compared against the same full-table oracle transcript (the engine in
-tests/test_gpu_sharded.py)."""
+`Context.comm_init_host` uses.  The GPU kernels cannot run here, so the oracle stands in for
+them - but the SCHEDULE is the engine's own: sc_plan_proof (pure host code of the product library,
+the planner prover_pass calls at every pass) says which launches and gathers a sharded proof
+consists of, the model executes them over gloo collectives, and the result is compared against
+the full-table oracle transcript (the engine itself: tests/test_gpu_sharded.py,
+tests/test_gpu_schedule.py)."""
 import os
 import sys
 
@@ -16,35 +18,38 @@ from conftest import ROOT, load_package
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
-def model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allgather, pyref):
-    """Python model of sc_prover_* in sharded mode (thaler-study_amd/csrc/sumcheck_hip.hip,
-    prover_pass / prover_answer), with oracle calls in place of kernels."""
+def model_sharded_prove(o, D, plan_proof, p, n, rank, world, opts, allreduce, allgather, pyref):
+    """The sharded prover with the oracle in place of the kernels, driven by the ENGINE'S OWN PLANNER: the launches come
+    from sc_plan_proof (the function prover_pass calls at every pass, thaler-study_amd/csrc/sumcheck_hip.hip: plan_pass),
+    this model only executes them - fold the pending challenges, accumulate the 3^ks-cell grid, sum its limbs across
+    the ranks, gather when the plan says so - and answers the rounds from the grid like prover_answer."""
     start, length = D.shard_range(n, rank, world)
     a = o.generate_range(pyref.SEED_A, start, length)
     b = o.generate_range(pyref.SEED_B, start, length)
     ch = [o.challenge(pyref.SEED_R, j + 1) for j in range(n)]
-    g = world.bit_length() - 1
+    steps = list(plan_proof(n, world, "host", **opts))
     sharded, pending, cache = True, [], None
     evals = []
-    n_allreduce = 0
+    n_allreduce = n_gather = 0
     L = o.lib
     add, sub, mul = (lambda x, y: L.sco_add(o.fp, x, y)), (lambda x, y: L.sco_sub(o.fp, x, y)), \
         (lambda x, y: L.sco_mul(o.fp, x, y))
-    # vpp: 1 = one round per pass, 2 = two, 3 = two with three-round first and tail passes
     for j in range(n):
         if j:
             pending.append(ch[j - 1])
         covered = cache is not None and 0 <= j - cache[1] < cache[0] and len(pending) == j - cache[1]
         if not covered:
-            kf = len(pending)
-            ks = 2 if (vpp >= 2 and n - j >= 2) else 1
-            cur_log = int(a.size).bit_length() - 1
-            if vpp == 3 and n - j >= 3 and (j == 0 or (kf > 0 and cur_log <= 19)):
-                ks = 3    # three-round first pass / three-round tail passes on small inputs
-            if sharded and (cur_log < kf + ks or cur_log <= tail_log):
+            step = steps.pop(0)
+            if step["action"] == "gather":
+                assert sharded and step["log_in"] == int(a.size).bit_length() - 1
                 a = allgather(a)
                 b = allgather(b)
                 sharded = False
+                n_gather += 1
+                step = steps.pop(0)
+            assert step["action"] in ("pass", "grid_pass"), step      # (rank passes exist on the peer transport only)
+            kf, ks = step["kf"], step["ks"]
+            assert kf == len(pending) and step["log_in"] == int(a.size).bit_length() - 1 and step["sharded"] == sharded, (step, len(pending), a.size)
             if kf:
                 a = o.fix_variables(a, pending)
                 b = o.fix_variables(b, pending)
@@ -80,7 +85,8 @@ def model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allga
             h.append(t)
         t = add(h[1], h[2])
         evals.append([h[0], h[1], sub(add(t, t), h[0])])   # H(2) = 2H(1) - H(0) + 2H(inf)
-    return evals, ch, n_allreduce
+    assert not steps, steps          # every planned launch was needed, none was missing
+    return evals, ch, n_allreduce, n_gather
 
 
 def _worker(rank, world, port, cases, q):
@@ -101,12 +107,12 @@ def _worker(rank, world, port, cases, q):
         payload = D.broadcast_bytes(bytes(range(128)) if rank == 0 else None)
         assert payload == bytes(range(128))
         out = []
-        for (p, n, tail_log, vpp) in cases:
+        for (p, n, opts) in cases:
             o = Oracle(p)
-            evals, ch, nar = model_sharded_prove(o, D, p, n, rank, world, tail_log, vpp, allreduce, allgather, pyref)
+            evals, ch, nar, ng = model_sharded_prove(o, D, pkg.schedule.plan_proof, p, n, rank, world, opts, allreduce, allgather, pyref)
             full = o.prove(o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n), np.array(ch, dtype=np.uint64))
             ok = full["status"] == 0 and evals == [[int(x) for x in row] for row in full["evals"]]
-            out.append((p, n, tail_log, vpp, ok, nar))
+            out.append((p, n, opts, ok, nar, ng))
         dist.barrier()
         dist.destroy_process_group()
         q.put((rank, out))
@@ -118,9 +124,12 @@ def _worker(rank, world, port, cases, q):
 @pytest.mark.parametrize("world", [2, 4])
 def test_gloo_sharded_schedule(world):
     GOLD = 2**64 - 2**32 + 1
-    cases = [(GOLD, 10, 0, 2), (GOLD, 10, 0, 1), (GOLD, 11, 4, 2), (389, 9, 0, 2), (GOLD, 3, 0, 2),
-             (GOLD, world.bit_length() - 1, 0, 2), (5, 8, 2, 1), (GOLD, 10, 0, 3), (GOLD, 11, 4, 3),
-             (389, 9, 0, 3), (GOLD, 3, 0, 3), (GOLD, 4, 0, 3)]
+    two = {"grid_pass": 0, "first_pass_vars": 2, "tail_log": 0}      # round 1's schedule: two rounds per pass, exchange per pass
+    cases = [(GOLD, 10, two), (GOLD, 10, {"vars_per_pass": 1, "tail_log": 0}), (GOLD, 11, dict(two, tail_log=4)), (389, 9, two),
+             (GOLD, 3, two), (GOLD, world.bit_length() - 1, two), (5, 8, {"vars_per_pass": 1, "tail_log": 2}),
+             # the default schedule: five-round passes on the shards, gathered when only the pending challenges are left
+             (GOLD, 10, {}), (GOLD, 14, {}), (389, 13, {}), (GOLD, 3, {}), (GOLD, 4, {}), (GOLD, 12, {"grid_max_vars": 3}),
+             (GOLD, 12, {"grid_sharded": 0, "tail_log": 5}), (GOLD, 13, {"first_pass_vars": 3})]
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = 29600 + world + (os.getpid() % 200)
@@ -132,10 +141,11 @@ def test_gloo_sharded_schedule(world):
         pr.join(timeout=60)
     for rank, out in results:
         assert not isinstance(out, str), out
-        for (p, n, tail_log, vpp, ok, nar) in out:
-            assert ok, (rank, p, n, tail_log, vpp)
-        # with tail_log 0 and n = 10 the run used several limb all-reduces
-        assert out[0][5] >= 3
+        for (p, n, opts, ok, nar, ng) in out:
+            assert ok, (rank, p, n, opts)
+            assert ng == 1 or n < world.bit_length(), (n, opts, ng)     # exactly one gather per sharded proof on a host transport
+        # with tail_log 0 and n = 10 the two-round schedule used several limb all-reduces
+        assert out[0][4] >= 3
 
 
 def test_shard_plan_and_limbs():
