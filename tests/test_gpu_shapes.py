@@ -2,7 +2,8 @@
   * config 4: n = 28 sharded over 8 ranks - 8 virtual ranks (threads, host transport) with 2^25-entry
     shards, equal to the 1-rank transcript bit for bit, verifier identities, sharded evaluate;
   * config 5: G::new (matrix-multiplication/src/lib.rs:77-92) at n = 8, 10, 12 vs the oracle and at
-    n = 14 (2^28-entry matrices) through size-independent properties."""
+    n = 14 (2^28-entry matrices) through size-independent properties;
+  * the largest instances the 288 GB hold: n = 32 and 33 (entry indices beyond 2^32)."""
 import numpy as np
 import pytest
 
@@ -119,3 +120,31 @@ def test_mle_config2_properties_n28():
     tr = t.relabel(0, 14, 14)
     swapped = pt[14:] + pt[:14]
     assert tr.evaluate(swapped) == v_le
+
+
+@pytest.mark.parametrize("n", [32, 33])
+def test_largest_instances(n):
+    """the maximum sizes one MI355X holds (2^33-entry tables are 2 x 64 GiB of the 288 GB; entry indices pass 2^32):
+    a full proof under the verifier's identities, BE = LE at the reversed point, fix-then-evaluate, and single entries
+    read back through boolean points on both sides of the 2^32 boundary"""
+    pkg = load_package()
+    F = pkg.Field(GOLD)
+    o = oracle(GOLD)
+    ctx = pkg.Context(F)
+    a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
+    b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, n)
+    g = pkg.matrix_multiplication.G(a, b)
+    c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+    final = g.evaluate([int(x) for x in ch])
+    assert verifier_identities(F, c1, evals, ch, final) is None
+    pt = [int(o.challenge(pyref.SEED_PT, j)) for j in range(n)]
+    v = a.evaluate(pt)
+    assert a.evaluate(pt[::-1], pkg.ORDER_BE) == v
+    for k in (1, 3, n - 1):
+        assert a.fix_variables(pt[:k]).evaluate(pt[k:]) == v, k
+    hi = (1 << n) - 1
+    for idx in (0, hi, (1 << 32) - 1, (1 << 32) + 5 if n > 32 else hi - 7, (1 << (n - 1)) + 3):
+        bits = [F.one if (idx >> d) & 1 else F.zero for d in range(n)]
+        assert a.evaluate(bits) == int(o.generate_range(pyref.SEED_A, idx, 1)[0]), idx
+    del a, b, g
+    ctx.close()
