@@ -374,7 +374,7 @@ __device__ __forceinline__ void exchange_and_publish(const PassOut& o, u64* xl) 
 }
 
 // Tail of every pass: res[0] of thread s < NS holds the block's residue of sum s.
-template <class F, int NS>
+template <class F, int NS, int BS = kBlock>
 __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my_res, int* lds_flag) {
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   __shared__ u64 xl[2 * NS + 2];   // this rank's limbs on their way to the peers (sharded passes only)
@@ -412,7 +412,7 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
   if constexpr (NS >= 9) {
     // thread = (row, slice): every load of a thread in flight at once (a round of dependent loads costs ~0.6 us from
     // L2; a wave per pair of rows walked 27 rows of 512 partials in four such iterations of two rounds, ~7 us)
-    constexpr int K = (kBlock / NS < 16) ? kBlock / NS : 16, U = 32;
+    constexpr int K = (BS / NS < 16) ? BS / NS : 16, U = 32;
     __shared__ u64 fin[K * NS];
     const int row = threadIdx.x % NS, slice = threadIdx.x / NS;
     if (slice < K) {
@@ -519,7 +519,7 @@ __device__ __forceinline__ u64 reduce_cells(const F& f, const typename F::Acc (&
 // every launch of the 27-cell pass, ~3.5 us of a 9-cell one: nothing at 2^28 entries, 10 % of a pass on a 2^25-entry
 // shard).  Here the accumulators of eight cells at a time go to LDS, thread (cell, part) adds eight of them as
 // integers, 32 lanes finish with five shuffle rounds and ONE lane per cell reduces to a residue: ~170 instructions
-// per chunk of eight cells.  scratch: 8 * kBlock accumulators; out: NS words.
+// per chunk of BS / 32 cells.  scratch: (BS / 32) * BS accumulators (BS = threads of the block); out: NS words.
 template <class A>
 __device__ __forceinline__ A shfl_down_acc(const A& a, int off) {
   static_assert(sizeof(A) % 4 == 0, "accumulator words");
@@ -530,10 +530,10 @@ __device__ __forceinline__ A shfl_down_acc(const A& a, int off) {
   for (int w = 0; w < (int)(sizeof(A) / 4); ++w) dst[w] = (unsigned)__shfl_down((int)src[w], off, kWave);
   return r;
 }
-template <class F, int NS>
+template <class F, int NS, int BS = kBlock>
 __device__ __forceinline__ u64 reduce_cells_lds(const F& f, const typename F::Acc (&acc)[NS], typename F::Acc* scratch, u64* out) {
   typedef typename F::Acc Acc;
-  constexpr int CH = 8;
+  constexpr int CH = BS / 32;   // cells per chunk: 32 threads sum one cell
   const int tid = threadIdx.x, cell = tid >> 5, part = tid & 31;
 #pragma unroll
   for (int c0 = 0; c0 < NS; c0 += CH) {
@@ -542,12 +542,12 @@ __device__ __forceinline__ u64 reduce_cells_lds(const F& f, const typename F::Ac
     if (c0 > 0) __syncthreads();   // the previous chunk's accumulators have been read
 #pragma unroll
     for (int s = 0; s < CH; ++s)
-      if (s < n) scratch[s * kBlock + tid] = acc[(c0 + s < NS) ? c0 + s : 0];
+      if (s < n) scratch[s * BS + tid] = acc[(c0 + s < NS) ? c0 + s : 0];
     __syncthreads();
     if (cell < n) {
-      Acc t = scratch[cell * kBlock + part];
+      Acc t = scratch[cell * BS + part];
 #pragma unroll
-      for (int k = 1; k < kBlock / 32; ++k) f.acc_add(t, scratch[cell * kBlock + part + 32 * k]);
+      for (int k = 1; k < BS / 32; ++k) f.acc_add(t, scratch[cell * BS + part + 32 * k]);
 #pragma unroll
       for (int off = 16; off >= 1; off >>= 1) {
         const Acc o = shfl_down_acc(t, off);
@@ -560,21 +560,30 @@ __device__ __forceinline__ u64 reduce_cells_lds(const F& f, const typename F::Ac
   return tid < NS ? out[tid] : 0;
 }
 
+// Threads per block of pass_kernel<., KF, KS, .>.  The arithmetic-heavy instantiations hold two or three waves per SIMD
+// (their registers allow no more) and get ALL of a CU's waves into ONE block, so that the waves of a SIMD can share
+// their work through LDS (see the tile loop); the light ones keep 256 threads and several blocks per CU.
+__host__ __device__ constexpr int pass_block_threads(int kf, int ks) {
+  return (ks == 3 || (kf == 3 && ks == 2)) ? 512 : (kf == 2 && ks == 2) ? 768 : kBlock;
+}
+
 // NT: bit 0 = nontemporal loads, bit 1 = nontemporal stores (see ld16 / st16)
 template <class F, int KF, int KS, int NT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(pass_block_threads(KF, KS))
 pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
             u64* __restrict__ B2, FoldW fw, size_t n_units, PassOut out) {
   constexpr bool kNtLoad = (NT & 1) != 0, kNtStore = (NT & 2) != 0;
   constexpr int IN = 1 << (KF + KS), OUT = 1 << KS, NS = (KS == 1) ? 3 : (KS == 2) ? 9 : 27;
   constexpr int NP = IN / 2, NPO = OUT / 2;  // 16-byte pieces per lane, in and out
-  constexpr int kWaves = kBlock / kWave;
-  // the tile transposes; after the loop the same bytes hold eight cells' accumulators of every thread (reduce_cells_lds)
+  constexpr int BS = pass_block_threads(KF, KS), kWaves = BS / kWave;
+  static_assert(BS == kBlock || NS >= 9, "reduce_cells (the KS = 1 passes) is written for 256 threads");
+  // the tile transposes; after the loop the same bytes hold a chunk of every thread's accumulators (reduce_cells_lds)
   constexpr int kTransposeSlots = (NP > 1 || NPO > 1) ? kWaves * kWave * NP : 1;
-  constexpr int kReduceSlots = (NS >= 9) ? (int)(8 * kBlock * sizeof(typename F::Acc) / sizeof(ull2)) : 1;
+  constexpr int kReduceSlots = (NS >= 9) ? (int)((NS < BS / 32 ? NS : BS / 32) * BS * sizeof(typename F::Acc) / sizeof(ull2)) : 1;
   __shared__ ull2 lds_t[kTransposeSlots > kReduceSlots ? kTransposeSlots : kReduceSlots];
   __shared__ u64 lds[kWaves * NS];
   __shared__ int lds_flag;
+  __shared__ unsigned lds_next;   // the block's tile counter
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
   ull2* const my_lds = lds_t + ((NP > 1 || NPO > 1) ? wave * kWave * NP : 0);
 
@@ -633,8 +642,9 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   };
   // The 27-cell grid runs at two waves per SIMD and is ALU-heavy: it cannot count on other
   // waves to cover its loads, so it fetches the wave's next tile before it starts on the
-  // arithmetic of the current one.  (The three-variable fold would need 128 more registers
-  // for the same trick and falls to one wave per SIMD.)
+  // arithmetic of the current one.  (The three-variable fold has no registers for a second tile; asking for one table
+  // of the next tile at a time, while the other table is folded out of LDS, was measured and gave nothing: that pass is
+  // not waiting for its own loads.)
   constexpr bool kPrefetch = (KS == 3);
   auto process_tile = [&](size_t tile, size_t next, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
     u64 a[IN], b[IN];
@@ -678,28 +688,46 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     else accumulate_run<F, KS>(f, acc, a, b);
   };
 
-  const size_t tile_stride = (size_t)gridDim.x * kWaves;
-  size_t tile = (size_t)blockIdx.x * kWaves + wave;
+  // Tiles are not dealt out in advance.  The waves that share a SIMD are issued oldest-first: with a fixed share each,
+  // the older wave runs at the pace of its arithmetic, the younger one gets the memory bandwidth that is left and
+  // then finishes its share ALONE, at half the SIMD's issue rate (per-block stamps of an n = 28 first pass with
+  // two 256-thread blocks per CU: blocks 0..255 left the loop after 459 us, blocks 256..511 - the second block of
+  // every CU - after 707 us; profiles/r03_pass_block_stamps.txt).  So a block's waves draw their tiles from a
+  // counter in LDS (block b takes the tiles c * gridDim + b, c = 0, 1, ...): whoever is faster takes more, and the
+  // waves of a SIMD finish together.  An LDS atomic is ~100 cycles and not in the way of the global loads (a
+  // global counter per CU was tried: its returns queue behind the tile loads and cost more than the balance gave).
+  if (threadIdx.x == 0) lds_next = 0;
+  __syncthreads();
+  auto next_tile = [&]() -> size_t {
+    unsigned c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
+  };
   if constexpr (kPrefetch) {
     ull2 pa[NP], pb[NP];
+    size_t tile = next_tile();
     if (tile < n_tiles) load_tile(tile, pa, pb);
-    for (; tile < n_tiles; tile += tile_stride) process_tile(tile, tile + tile_stride, pa, pb);
+    while (tile < n_tiles) {
+      const size_t next = next_tile();
+      process_tile(tile, next, pa, pb);
+      tile = next;
+    }
   } else {
-    for (; tile < n_tiles; tile += tile_stride) {
+    for (size_t tile = next_tile(); tile < n_tiles; tile = next_tile()) {
       ull2 pa[NP], pb[NP];
       load_tile(tile, pa, pb);
-      process_tile(tile, tile + tile_stride, pa, pb);
+      process_tile(tile, 0, pa, pb);
     }
   }
 
   u64 mine;
   if constexpr (NS >= 9) {
     __syncthreads();   // every wave is done with its transposes
-    mine = reduce_cells_lds<F, NS>(f, acc, reinterpret_cast<typename F::Acc*>(lds_t), lds);
+    mine = reduce_cells_lds<F, NS, BS>(f, acc, reinterpret_cast<typename F::Acc*>(lds_t), lds);
   } else {
     mine = reduce_cells<F, NS>(f, acc, lds);
   }
-  finish_pass<F, NS>(f, out, mine, &lds_flag);
+  finish_pass<F, NS, BS>(f, out, mine, &lds_flag);
 }
 
 // ------------------------------------------------------------------------------------

@@ -460,7 +460,7 @@ int pass_resident_blocks_t(sc_ctx* ctx, int kf, int ks) {
   }
 #undef SC_FN
   int per_cu = 0;
-  if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, sc::kBlock, 0) != hipSuccess || per_cu < 1) {
+  if (!fn || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, sc::pass_block_threads(kf, ks), 0) != hipSuccess || per_cu < 1) {
     (void)hipGetLastError();
     return ctx->max_blocks;
   }
@@ -481,7 +481,7 @@ int pass_resident_blocks(sc_ctx* ctx, int kf, int ks) {
 template <class F>
 void launch_pass_t(sc_ctx* ctx, const F& f, int kf, int ks, const u64* A, const u64* B, u64* A2,
                    u64* B2, const sc::FoldW& fw, size_t n_units, int grid, int log_in, const sc::PassOut& out) {
-  dim3 g(grid), b(sc::kBlock);
+  dim3 g(grid), b(sc::pass_block_threads(kf, ks));
   hipStream_t s = ctx->stream;
   // streaming hints are compile-time (kernels.hpp, ld16/st16): 0 = cached, 1 = stream the inputs,
   // 3 = stream inputs and outputs
@@ -564,7 +564,8 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
     return fail(ctx, SC_ERR_ARG, "launch_pass: kf=%d ks=%d log_in=%d", kf, ks, log_in);
   const sc::FoldW fw = make_fold_weights(ctx, r, kf);
   size_t n_units = (size_t)1 << (log_in - kf - ks);
-  int grid = grid_for(ctx, n_units);
+  const size_t bs = (size_t)sc::pass_block_threads(kf, ks);
+  int grid = (int)std::min<size_t>(std::max<size_t>((n_units + bs - 1) / bs, 1), (size_t)ctx->max_blocks);
   grid = std::min(grid, pass_resident_blocks(ctx, kf, ks));
   const bool peer = across_ranks && ctx->transport == Transport::kPeer;
   const bool mailbox = (ctx->use_mailbox || peer) && !(across_ranks && ctx->transport == Transport::kRccl);
