@@ -410,12 +410,15 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
   if (!*lds_flag) return;
   const int n_blocks = gridDim.x;
   if constexpr (NS >= 9) {
-    // thread = (row, slice): every load of a thread in flight at once (a round of dependent loads costs ~0.6 us from
-    // L2; a wave per pair of rows walked 27 rows of 512 partials in four such iterations of two rounds, ~7 us)
-    constexpr int K = (BS / NS < 16) ? BS / NS : 16, U = 32;
+    // thread = (cell, slice), the sixteen slices of a cell in adjacent lanes: a load instruction of a wave reads four
+    // 128-byte lines (cell-major partials: slices = consecutive blocks), not 64 scattered words - with the cells in
+    // adjacent lanes the same loads took 4.6 us for 256 x 27 partials (profiles/r03_pass_block_stamps.txt), two thirds
+    // of the last block's work.  Every load of a thread is in flight at once; the slices are summed through LDS.
+    constexpr int K = 16, U = 16;
+    static_assert(BS >= K * NS, "sixteen slices per cell");
     __shared__ u64 fin[K * NS];
-    const int row = threadIdx.x % NS, slice = threadIdx.x / NS;
-    if (slice < K) {
+    const int row = threadIdx.x / K, slice = threadIdx.x % K;
+    if (row < NS) {
       const u64* src = o.partials + (size_t)row * o.n_rows;
       u64 part = 0;
       for (int b0 = slice; b0 < n_blocks; b0 += K * U) {
@@ -426,7 +429,11 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
           x[u] = (b < n_blocks) ? __hip_atomic_load(src + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
         }
 #pragma unroll
-        for (int u = 0; u < U; ++u) part = f.add(part, x[u]);
+        for (int u = 0; u < U / 2; ++u) x[u] = f.add(x[u], x[u + U / 2]);
+#pragma unroll
+        for (int u = 0; u < U / 4; ++u) x[u] = f.add(x[u], x[u + U / 4]);
+#pragma unroll
+        for (int u = 0; u < U / 4; ++u) part = f.add(part, x[u]);
       }
       fin[slice * NS + row] = part;
     }

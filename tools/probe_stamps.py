@@ -16,7 +16,7 @@ os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 
 
 def report(tag, dur_us, save=None):
-    buf = np.zeros(4 * 4097, dtype=np.uint64)
+    buf = np.zeros(4 * 4096 + 16, dtype=np.uint64)
     assert lib.sc_dbg_stamps(buf.ctypes.data, buf.size) == 0
     lib.sc_dbg_stamps_clear()
     blocks = buf[:4 * 4096].reshape(4096, 4)
@@ -32,6 +32,9 @@ def report(tag, dur_us, save=None):
     print("   stream loop done : %s" % q(us(t1)))
     print("   block reduced    : %s" % q(us(t2)))
     print("   published        : %.1f   (last block reduced -> published %.1f us)" % (us(fin), us(fin) - us(t2).max()))
+    x = buf[4 * 4096 + 1:4 * 4096 + 5].astype(np.int64)
+    if x.all():
+        print("   last block       : ticket %.1f  fence done %.1f  partials summed %.1f  values stored %.1f  seq stored %.1f" % (us(x[0]), us(x[1]), us(x[2]), us(x[3]), us(fin)))
     xcc = (hw >> np.uint64(32)).astype(np.int64) & 0xF
     hwid = hw.astype(np.int64) & 0xFFFFFFFF
     cu = (hwid >> 8) & 0xF; sh = (hwid >> 12) & 1; se = (hwid >> 13) & 0x7
