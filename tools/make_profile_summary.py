@@ -127,7 +127,7 @@ for r in stats:
     lines.append("| `%s` | %s | %.1f | %.3f | %s |" % (short(r["Name"]), r["Calls"], float(r["AverageNs"]) / 1e3, float(r["TotalDurationNs"]) / 1e6, r["Percentage"]))
 lines.append("\n## One step, launch by launch (last step of the trace)\n")
 lines.append("HBM bytes = FETCH_SIZE x 2 x 1024 (gfx950 reports half of a wide coalesced read, MI355X_MICROARCH.md section HBM) + WRITE_SIZE x 1024.\n")
-lines.append("| # | kernel | input entries/table | grid | kernel us | bytes the launch must move | PMC HBM bytes | TB/s of bytes moved | frac of 8 TB/s |")
+lines.append("| # | kernel | input entries/table | blocks x threads | kernel us | bytes the launch must move | PMC HBM bytes | TB/s of bytes moved | frac of 8 TB/s |")
 lines.append("|---|---|---|---|---|---|---|---|---|")
 size = n
 tot_t = tot_b = tot_p = 0.0
@@ -139,7 +139,8 @@ for i, r in enumerate(last):
         assert i < len(schedule) and schedule[i][0] == "grid_pass", (i, schedule)
         kf, ks = schedule[i][1], schedule[i][2]
     t = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-    grid = int(r["Grid_Size_X"]) // 256
+    wg = int(r.get("Workgroup_Size_X", 256) or 256)
+    grid = "%d x %d" % (int(r["Grid_Size_X"]) // wg, wg)
     if workload == "prover":
         log_in = size
         need = 16 * 2 ** size + (16 * 2 ** (size - kf) if kf else 0)
@@ -151,7 +152,7 @@ for i, r in enumerate(last):
     pmc = fetch[i] * 2 * 1024 + write[i] * 1024
     name = bench_name(kind, kf, ks, log_in)
     per_kernel.setdefault(name, []).append(pmc)
-    lines.append("| %d | `%s` | 2^%d | %d | %.1f | %.4g | %.4g | %.2f | %.3f |" % (i, name, log_in, grid, t, need, pmc, need / t / 1e6, need / t / 1e6 / 8))
+    lines.append("| %d | `%s` | 2^%d | %s | %.1f | %.4g | %.4g | %.2f | %.3f |" % (i, name, log_in, grid, t, need, pmc, need / t / 1e6, need / t / 1e6 / 8))
     tot_t += t
     tot_b += need
     tot_p += pmc
