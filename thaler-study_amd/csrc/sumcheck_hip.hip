@@ -555,6 +555,9 @@ inline void commit_peer(sc_ctx* ctx) {
   ctx->xchg_next = 0;
 }
 
+sc::PassOut next_pass_out(sc_ctx* ctx, bool across_ranks = false, unsigned digest = 0, bool* from_mailbox = nullptr);
+int commit_pass_out(sc_ctx* ctx, const sc::PassOut& out, int grid);
+
 // Launch one pass over tables of 2^log_in entries.  The 2*NS split limbs end up in the
 // host mailbox (*from_mailbox = true; wait with collect_sums) or in ctx->d_sums when they
 // still have to be all-reduced on the device (RCCL transport).
@@ -567,27 +570,13 @@ int launch_pass(sc_ctx* ctx, int kf, int ks, const u64* A, const u64* B, u64* A2
   const size_t bs = (size_t)sc::pass_block_threads(kf, ks);
   int grid = (int)std::min<size_t>(std::max<size_t>((n_units + bs - 1) / bs, 1), (size_t)ctx->max_blocks);
   grid = std::min(grid, pass_resident_blocks(ctx, kf, ks));
-  const bool peer = across_ranks && ctx->transport == Transport::kPeer;
-  const bool mailbox = (ctx->use_mailbox || peer) && !(across_ranks && ctx->transport == Transport::kRccl);
-  sc::PassOut out;
-  out.partials = ctx->d_partials;
-  out.n_rows = (int)ctx->partial_rows;
-  out.ticket = ctx->d_ticket;
-  out.ticket_base = ctx->ticket_base;
-  out.sums_dev = ctx->d_sums;
-  out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
-  out.seq = mailbox ? ctx->mailbox_seq + 1 : 0;
-  if (peer) fill_peer(ctx, out.px, challenge_digest(r, kf, ks, log_in));
+  const sc::PassOut out = next_pass_out(ctx, across_ranks, challenge_digest(r, kf, ks, log_in), from_mailbox);
   SC_TRY(timer_begin(ctx, SC_KIND_PASS, kf, ks, log_in, (u64)16 << log_in, kf > 0 ? (u64)16 << (log_in - kf) : 0));
   SC_DISPATCH_FIELD(ctx, F, f, launch_pass_t<F>(ctx, f, kf, ks, A, B, A2, B2, fw, n_units, grid, log_in, out));
-  SC_HIP(ctx, hipGetLastError());
   // the launch is in the stream: only now do the ticket base, the mailbox sequence and the exchange tag move (a
   // failed launch must leave them where the device-side counter and the peers still are)
-  if (peer) commit_peer(ctx);
-  if (mailbox) ctx->mailbox_seq += 1;
-  if (grid > 1) ctx->ticket_base += (unsigned)grid;
+  SC_TRY(commit_pass_out(ctx, out, grid));
   SC_TRY(timer_end(ctx));
-  *from_mailbox = mailbox;
   return SC_OK;
 }
 
@@ -734,7 +723,7 @@ int rank_pass(sc_ctx* ctx, int kf, const u64* A, const u64* B, u64* A2, u64* B2,
 // kernel on the peer transport (digest = what the ranks must agree on), by a collective on the stream for RCCL (the
 // limbs stay in d_sums), by the host for a host transport.  *from_mailbox tells collect_sums where the limbs are.
 // Nothing is committed here: call commit_pass_out() once the launch is known to be in the stream.
-sc::PassOut next_pass_out(sc_ctx* ctx, bool across_ranks = false, unsigned digest = 0, bool* from_mailbox = nullptr) {
+sc::PassOut next_pass_out(sc_ctx* ctx, bool across_ranks, unsigned digest, bool* from_mailbox) {
   const bool peer = across_ranks && ctx->transport == Transport::kPeer;
   const bool mailbox = (ctx->use_mailbox || peer) && !(across_ranks && ctx->transport == Transport::kRccl);
   sc::PassOut out;
