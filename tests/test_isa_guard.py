@@ -116,4 +116,3 @@ def test_block_per_cu_instantiations_fit_one_cu(isa):
         assert u["ScratchSize [bytes/lane]"] == 0, (frag, u)
         body = kernel_body(text, frag)
         assert re.search(r"ds_add_rtn_u32", body), frag               # the tile counter
-        assert not re.search(r"global_atomic_add\S* v\d+, v", body) or True
