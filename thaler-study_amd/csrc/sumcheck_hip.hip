@@ -792,15 +792,7 @@ int collect_sums(sc_ctx* ctx, int ns, bool across_ranks, bool from_mailbox, u64*
     if (across_ranks && ctx->transport == Transport::kPeer) SC_TRY(check_exchange(ctx, "sums"));
   } else if (across_ranks && ctx->transport == Transport::kPeer) {
     // limbs left in d_sums by a small kernel: one wave exchanges them with the peers and publishes
-    sc::PassOut po;
-    po.partials = ctx->d_partials;
-    po.n_rows = (int)ctx->partial_rows;
-    po.ticket = ctx->d_ticket;
-    po.ticket_base = ctx->ticket_base;
-    po.sums_dev = ctx->d_sums;
-    po.mailbox = ctx->d_mailbox;
-    po.seq = ctx->mailbox_seq + 1;
-    fill_peer(ctx, po.px, 0x5c5c5c5cu + (unsigned)ns);
+    const sc::PassOut po = next_pass_out(ctx, true, 0x5c5c5c5cu + (unsigned)ns);
     const u64* limbs = ctx->d_sums;
     switch (ns) {
       case 1: hipLaunchKernelGGL((sc::peer_exchange_kernel<1>), dim3(1), dim3(sc::kWave), 0, ctx->stream, limbs, po); break;
@@ -859,15 +851,7 @@ int peer_gather(sc_ctx* ctx, const u64* a, const u64* b, size_t len, u64* dst_a,
   const size_t cap = (size_t)ctx->world << ctx->arena_log;      // words per table of an arena
   for (size_t off = 0; off < len; off += chunk_cap) {
     const size_t n = std::min(chunk_cap, len - off);
-    sc::PassOut out;
-    out.partials = ctx->d_partials;
-    out.n_rows = (int)ctx->partial_rows;
-    out.ticket = ctx->d_ticket;
-    out.ticket_base = ctx->ticket_base;
-    out.sums_dev = ctx->d_sums;
-    out.mailbox = ctx->d_mailbox;
-    out.seq = ctx->mailbox_seq + 1;
-    fill_peer(ctx, out.px, 0);
+    const sc::PassOut out = next_pass_out(ctx, true, 0);
     const size_t arena_off = kInboxRegionWords + kPeerHeaderWords + (size_t)(ctx->gather_count & 1u) * 2 * cap;
     sc::PeerG pg;
     for (int q = 0; q < ctx->world; ++q) pg.arena[q] = ctx->peer_base[q] + arena_off;
@@ -1828,17 +1812,7 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
   const size_t n_chunks = ((size_t)1 << (nv - 7)) >> chunk_log;
   int grid = (int)std::min<size_t>((n_chunks + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
   if (grid < 1) grid = 1;
-  const bool peer = across && ctx->transport == Transport::kPeer;
-  const bool mailbox = (ctx->use_mailbox || peer) && !(across && ctx->transport == Transport::kRccl);
-  sc::PassOut out;
-  out.partials = ctx->d_partials;
-  out.n_rows = (int)ctx->partial_rows;
-  out.ticket = ctx->d_ticket;
-  out.ticket_base = ctx->ticket_base;
-  out.sums_dev = ctx->d_sums;
-  out.mailbox = mailbox ? ctx->d_mailbox : nullptr;
-  out.seq = mailbox ? ctx->mailbox_seq + 1 : 0;
-  if (peer) fill_peer(ctx, out.px, challenge_digest(pt_le, std::min(nv, 3), 0, nv));
+  const sc::PassOut out = next_pass_out(ctx, across, challenge_digest(pt_le, std::min(nv, 3), 0, nv), from_mailbox);
   const int nt = nv >= ctx->nt_load_log ? 1 : 0;
   SC_TRY(timer_begin(ctx, SC_KIND_EVALUATE, nv, 0, nv, (u64)8 << nv, 0));
   if (nt)
@@ -1849,7 +1823,6 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
                                                     f, d, nv, rv, ta, chunk_log, w_extra, out));
   SC_TRY(commit_pass_out(ctx, out, grid));
   SC_TRY(timer_end(ctx));
-  *from_mailbox = mailbox;
   return SC_OK;
 }
 
