@@ -163,7 +163,7 @@ __device__ __forceinline__ u64 shfl_u64(u64 v, int src) {
 
 // Block-wide modular sum of NS per-thread residues; result valid in threads [0, NS).
 template <class F, int NS>
-__device__ __forceinline__ void block_reduce(const F& f, u64 (&res)[NS], u64* lds /*[4][NS]*/) {
+__device__ __forceinline__ void block_reduce(const F& f, u64 (&res)[NS], u64* lds /*[waves of the block][NS]*/) {
 #pragma unroll
   for (int off = kWave / 2; off >= 1; off >>= 1) {
 #pragma unroll
@@ -177,8 +177,8 @@ __device__ __forceinline__ void block_reduce(const F& f, u64 (&res)[NS], u64* ld
   __syncthreads();
   if (threadIdx.x < NS) {
     u64 t = lds[threadIdx.x];
-#pragma unroll
-    for (int w = 1; w < kBlock / kWave; ++w) t = f.add(t, lds[w * NS + threadIdx.x]);
+    const int n_waves = (int)blockDim.x / kWave;
+    for (int w = 1; w < n_waves; ++w) t = f.add(t, lds[w * NS + threadIdx.x]);
     res[0] = t;  // thread s holds sum s in res[0]
   }
 }
@@ -1283,18 +1283,30 @@ rank_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64*
 // LE fold of KF in {1,2,3} variables in one pass: coalesced 16-byte loads, wave-private LDS
 // transposition (a lane needs 2^(KF+1) consecutive entries), one coalesced 16-byte store
 // per lane.  n_units = number of output pieces (pairs of output entries).
+constexpr int kFoldBlock = 1024;   // fold_kernel: four-wave blocks for small tables, all sixteen waves of a CU beyond (host)
+constexpr int kFoldGrab = 4;       // consecutive tiles per draw from the block's counter
+constexpr size_t fold_kernel_lds_bytes(int kf, int threads) { return (size_t)(threads / kWave) * kWave * (size_t)(1 << kf) * sizeof(ull2); }
 template <class F, int KF, bool NT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kFoldBlock)
 fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, FoldW fw, size_t n_units) {
   constexpr int IN = 2 << KF, NP = IN / 2;
-  constexpr int kWaves = kBlock / kWave;
-  __shared__ ull2 lds_t[kWaves * kWave * NP];
+  extern __shared__ ull2 fold_lds[];   // [waves of the block][kWave * NP]: sized by the launch (fold_kernel_lds_bytes)
+  __shared__ unsigned lds_next;
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  ull2* const my_lds = lds_t + wave * kWave * NP;
+  ull2* const my_lds = fold_lds + wave * kWave * NP;
   const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
   ull2* __restrict__ T2p = reinterpret_cast<ull2*>(T2);
   const size_t n_tiles = (n_units + kWave - 1) / kWave, in_pieces = n_units * NP;
-  for (size_t tile = (size_t)blockIdx.x * kWaves + wave; tile < n_tiles; tile += (size_t)gridDim.x * kWaves) {
+  if (threadIdx.x == 0) lds_next = 0;
+  __syncthreads();
+  // the waves of a block draw runs of kFoldGrab tiles from a counter in LDS (evaluate_kernel; block b owns the runs c * grid + b)
+  auto next_run = [&]() -> size_t {
+    unsigned c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return ((size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x) * kFoldGrab;
+  };
+  for (size_t run = next_run(); run < n_tiles; run = next_run())
+  for (size_t tile = run; tile < run + kFoldGrab && tile < n_tiles; ++tile) {
     ull2 pv[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {
@@ -1380,7 +1392,7 @@ __device__ __forceinline__ void build_eq_weights(const F& f, const u64* r, int t
     eqH[half][i] = w;   // entries with bits above nb repeat lower ones and are never read
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < (1 << ta); i += kBlock) eqA[i] = f.mul(eqH[0][i & ((1 << lo_bits) - 1)], eqH[1][i >> lo_bits]);
+  for (int i = threadIdx.x; i < (1 << ta); i += blockDim.x) eqA[i] = f.mul(eqH[0][i & ((1 << lo_bits) - 1)], eqH[1][i >> lo_bits]);
   __syncthreads();
 }
 
@@ -1393,17 +1405,32 @@ __device__ __forceinline__ void build_eq_weights(const F& f, const u64* r, int t
 // eqB; the bit-0 and lane weights are applied once per thread at the end.  This is the
 // streaming form of vsbw_multilinear_from_evaluations' "eq table, then dot product"
 // (multilinear-extensions/src/lib.rs:6-24) without materialising the 2^n eq table.
+// Launched with kBlock threads while every wave gets at most one chunk, with stream_block<F>::evaluate threads = all twelve
+// waves a CU holds of it (three per SIMD) beyond that: the waves of a block then draw their chunks from a counter in LDS.  With three
+// 256-thread blocks per CU and a fixed share per wave the three wave slots of a SIMD left the loop of a 2^28-entry
+// table after 202 / 270 / 336 us - a SIMD issues its oldest wave first (pass_kernel, "Tiles are not dealt out in advance").
+template <class F> struct stream_block {            // threads of the one-block-per-CU launches of the two streaming readers
+  static constexpr int evaluate = 768, fix_low = 1024;
+};
+template <> struct stream_block<MontGeneric> {      // the generic-modulus arithmetic needs more registers per wave
+  static constexpr int evaluate = 512, fix_low = 512;
+};
 template <class F, bool NT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(stream_block<F>::evaluate)
 evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chunk_log, u64 w_extra, PassOut out) {
-  constexpr int kWaves = kBlock / kWave;
   __shared__ u64 eqA[1024];  // ta <= 10
-  __shared__ u64 lds[kWaves];
+  __shared__ u64 lds[stream_block<F>::evaluate / kWave];
   __shared__ int lds_flag;
+  __shared__ unsigned lds_next;
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int tb = n - 7 - ta;
-  build_eq_weights(f, rv.v + 7, ta, eqA);   // the tile-in-segment weights
+  if (threadIdx.x == 0) lds_next = 0;
+  build_eq_weights(f, rv.v + 7, ta, eqA);   // the tile-in-segment weights (ends with a barrier)
+  auto next_chunk = [&]() -> size_t {
+    unsigned c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
+  };
   const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
   const size_t n_tiles = (size_t)1 << (n - 7);
   const size_t n_chunks = n_tiles >> chunk_log;
@@ -1411,7 +1438,7 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
   typename F::Acc o0, o1;
   f.acc_zero(o0);
   f.acc_zero(o1);
-  for (size_t chunk = (size_t)blockIdx.x * kWaves + wave; chunk < n_chunks; chunk += (size_t)gridDim.x * kWaves) {
+  for (size_t chunk = next_chunk(); chunk < n_chunks; chunk = next_chunk()) {
     const size_t tile0 = chunk << chunk_log;
     const size_t seg = tile0 >> ta;
     const int in_seg = (int)(tile0 & (((size_t)1 << ta) - 1));
@@ -1487,14 +1514,19 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
 // reads the table 1.14 times and writes an eighth of it; this reads it once.
 // (DenseMultilinearExtension::fix_variables with many variables; the f_B half of G::new.)
 template <class F, bool NT>
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(stream_block<F>::fix_low)
 fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVec rv, size_t n_out) {
-  constexpr int kWaves = kBlock / kWave;
   __shared__ u64 eqA[1024];  // k - 7 <= 10
+  __shared__ unsigned lds_next;   // the block's segment counter (see evaluate_kernel)
   const int lane = threadIdx.x & (kWave - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
   const int ta = k - 7;
+  if (threadIdx.x == 0) lds_next = 0;
   build_eq_weights(f, rv.v + 7, ta, eqA);
+  auto next_seg = [&]() -> size_t {
+    unsigned c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
+  };
   u64 wl = f.one();
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
@@ -1505,7 +1537,7 @@ fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVe
   __syncthreads();
   const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
   const int tiles = 1 << ta;
-  for (size_t seg = (size_t)blockIdx.x * kWaves + wave; seg < n_out; seg += (size_t)gridDim.x * kWaves) {
+  for (size_t seg = next_seg(); seg < n_out; seg = next_seg()) {
     const ull2* __restrict__ Sp = Tp + (seg << (k - 1)) + lane;
     typename F::Acc a0, a1;
     f.acc_zero(a0);

@@ -1089,14 +1089,20 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
       const size_t nlen = cur_len >> step;
       SC_CHAIN(pool_alloc(ctx, nlen, &nxt));
       const sc::RVec rv = make_rvec(r + done, (size_t)step);
-      const int grid = (int)std::min<size_t>((nlen + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
+      // one segment per wave: four-wave blocks while there is at most one segment per wave of one block per CU, beyond that
+      // one block per CU with all sixteen waves, which draw their segments from a counter in LDS (kernels.hpp, evaluate_kernel)
+      int grid = (int)std::min<size_t>((nlen + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024)), threads = sc::kBlock;
+      if (nlen > (size_t)4 * ctx->num_cus) {
+        threads = ctx->gold ? sc::stream_block<sc::GoldilocksMont>::fix_low : sc::stream_block<sc::MontGeneric>::fix_low;
+        grid = std::min(ctx->num_cus, ctx->max_blocks);
+      }
       const int nt = cur_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
       SC_CHAIN(timer_begin(ctx, SC_KIND_FIX_LOW, step, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * nlen));
       if (nt)
-        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F, true>), dim3(grid), dim3(sc::kBlock), 0,
+        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F, true>), dim3(grid), dim3(threads), 0,
                                                         ctx->stream, f, cur, nxt, step, rv, nlen));
       else
-        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F, false>), dim3(grid), dim3(sc::kBlock), 0,
+        SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fix_low_kernel<F, false>), dim3(grid), dim3(threads), 0,
                                                         ctx->stream, f, cur, nxt, step, rv, nlen));
       SC_CHAIN(timer_end(ctx));
       cur_len = nlen;
@@ -1121,15 +1127,25 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
       SC_CHAIN(timer_begin(ctx, SC_KIND_FOLD, step, 0, log2_of(cur_len), (u64)8 * cur_len, (u64)8 * nlen));
       if (nlen >= 2) {
         size_t n_units = nlen / 2;
-        int grid = grid_for(ctx, n_units);
+        int grid = grid_for(ctx, n_units), threads = sc::kBlock;
+        if (n_units > (size_t)ctx->max_blocks * sc::kBlock * sc::kFoldGrab) {   // several runs per wave: one block per CU with all sixteen waves (kernels.hpp)
+          threads = sc::kFoldBlock;
+          grid = std::min(ctx->num_cus, ctx->max_blocks);
+        }
         const int nt = cur_len >= ((size_t)1 << ctx->nt_load_log) ? 1 : 0;
 #define SC_FOLD(KF)                                                                                                  \
   do {                                                                                                               \
+    if (sc::fold_kernel_lds_bytes(KF, threads) > 65536)   /* more dynamic LDS than a launch gets by default */        \
+      SC_DISPATCH_FIELD(ctx, F, f, {                                                                                 \
+        (void)f;                                                                                                     \
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(nt ? &sc::fold_kernel<F, KF, true> : &sc::fold_kernel<F, KF, false>), \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)sc::fold_kernel_lds_bytes(KF, threads)); \
+      });                                                                                                            \
     if (nt)                                                                                                          \
-      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_kernel<F, KF, true>), dim3(grid), dim3(sc::kBlock), 0, \
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_kernel<F, KF, true>), dim3(grid), dim3(threads), sc::fold_kernel_lds_bytes(KF, threads), \
                                                       ctx->stream, f, cur, nxt, fw, n_units));                       \
     else                                                                                                             \
-      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_kernel<F, KF, false>), dim3(grid), dim3(sc::kBlock), 0, \
+      SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::fold_kernel<F, KF, false>), dim3(grid), dim3(threads), sc::fold_kernel_lds_bytes(KF, threads), \
                                                       ctx->stream, f, cur, nxt, fw, n_units));                       \
   } while (0)
         if (step == 3) SC_FOLD(3);
@@ -1807,19 +1823,26 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
   // (n = 28: 409 us with 16 tiles, 382 with 128), as long as there are chunks for every wave.  (Round 3 swept the grid
   // and the chunk size at 2^24 entries - 256 to 1024 blocks, 8 to 128 tiles per chunk: 36.4-38.8 us whatever the shape,
   // profiles/r03_mle24_sweep.txt; at that size the launch is its ~8 us floor plus 22 us of stream.)
-  const int chunk_log = std::min({ta, 7, std::max(3, nv - 17)});
+  int chunk_log = std::min({ta, 7, std::max(3, nv - 17)});
   sc::RVec rv = make_rvec(pt_le, (size_t)nv);
-  const size_t n_chunks = ((size_t)1 << (nv - 7)) >> chunk_log;
-  int grid = (int)std::min<size_t>((n_chunks + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
+  int grid = (int)std::min<size_t>(((((size_t)1 << (nv - 7)) >> chunk_log) + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024));
   if (grid < 1) grid = 1;
+  // more chunks than one per wave of a four-wave block per CU: one block per CU with all the waves it holds, which draw
+  // chunks of 32 tiles from a counter in LDS (kernels.hpp; n = 28: 351 -> 333 us on one box, chunks of 128 tiles 340)
+  int threads = sc::kBlock;
+  if ((((size_t)1 << (nv - 7)) >> chunk_log) > (size_t)4 * ctx->num_cus) {
+    threads = ctx->gold ? sc::stream_block<sc::GoldilocksMont>::evaluate : sc::stream_block<sc::MontGeneric>::evaluate;
+    grid = std::min(ctx->num_cus, ctx->max_blocks);
+    chunk_log = std::min(chunk_log, 5);
+  }
   const sc::PassOut out = next_pass_out(ctx, across, challenge_digest(pt_le, std::min(nv, 3), 0, nv), from_mailbox);
   const int nt = nv >= ctx->nt_load_log ? 1 : 0;
   SC_TRY(timer_begin(ctx, SC_KIND_EVALUATE, nv, 0, nv, (u64)8 << nv, 0));
   if (nt)
-    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::evaluate_kernel<F, true>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::evaluate_kernel<F, true>), dim3(grid), dim3(threads), 0, ctx->stream,
                                                     f, d, nv, rv, ta, chunk_log, w_extra, out));
   else
-    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::evaluate_kernel<F, false>), dim3(grid), dim3(sc::kBlock), 0, ctx->stream,
+    SC_DISPATCH_FIELD(ctx, F, f, hipLaunchKernelGGL((sc::evaluate_kernel<F, false>), dim3(grid), dim3(threads), 0, ctx->stream,
                                                     f, d, nv, rv, ta, chunk_log, w_extra, out));
   SC_TRY(commit_pass_out(ctx, out, grid));
   SC_TRY(timer_end(ctx));
