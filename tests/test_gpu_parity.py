@@ -289,6 +289,26 @@ def test_fix_variables_all_k(pkg, p):
         assert np.array_equal(got, o.fix_variables(ot, pt[:k], pkg.ORDER_LE)), (n, k)
 
 
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+@pytest.mark.parametrize("max_blocks", [1, 3, 8])
+def test_block_per_cu_streamers_vs_oracle(pkg, p, max_blocks):
+    """large tables launch evaluate / fix_low / fold with ONE block per CU whose waves draw their work from an LDS counter
+    (kernels.hpp: evaluate_kernel, fix_low_kernel, fold_kernel); the launch shape follows `max_blocks`, so a small cap
+    takes a 2^18..2^20-entry table - sizes the oracle does in a second - down the same path, with odd grids and with
+    fewer units of work than waves"""
+    ctx = ctx_for(pkg, p, max_blocks=max_blocks)
+    o = oracle(p)
+    for n in (18, 20):
+        ot = o.generate(7, n)
+        t = pkg.DenseMultilinearExtension.generate(ctx, 7, n)
+        pt = [o.challenge(8, j) for j in range(n)]
+        assert t.evaluate(pt) == o.evaluate(ot, pt), (n, "evaluate")
+        assert t.evaluate(pt, order=pkg.ORDER_BE) == o.vsbw(ot, pt), (n, "evaluate BE")
+        for k in (1, 2, 3, 8, 12, 17):
+            got = t.fix_variables(pt[:k]).to_evaluations()
+            assert np.array_equal(got, o.fix_variables(ot, pt[:k], pkg.ORDER_LE)), (n, k)
+
+
 def test_relabel_and_clone(pkg):
     ctx = ctx_for(pkg, 389)
     o = oracle(389)

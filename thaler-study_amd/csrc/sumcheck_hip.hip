@@ -1092,7 +1092,7 @@ int fold_chain(sc_ctx* ctx, const u64* in, size_t len, const u64* r, size_t k, i
       // one segment per wave: four-wave blocks while there is at most one segment per wave of one block per CU, beyond that
       // one block per CU with all sixteen waves, which draw their segments from a counter in LDS (kernels.hpp, evaluate_kernel)
       int grid = (int)std::min<size_t>((nlen + 3) / 4, (size_t)std::min(ctx->max_blocks, 1024)), threads = sc::kBlock;
-      if (nlen > (size_t)4 * ctx->num_cus) {
+      if (nlen > (size_t)4 * std::min(ctx->num_cus, ctx->max_blocks)) {
         threads = ctx->gold ? sc::stream_block<sc::GoldilocksMont>::fix_low : sc::stream_block<sc::MontGeneric>::fix_low;
         grid = std::min(ctx->num_cus, ctx->max_blocks);
       }
@@ -1830,7 +1830,7 @@ static int evaluate_local(sc_ctx* ctx, const u64* d, size_t len, const u64* pt_l
   // more chunks than one per wave of a four-wave block per CU: one block per CU with all the waves it holds, which draw
   // chunks of 32 tiles from a counter in LDS (kernels.hpp; n = 28: 351 -> 333 us on one box, chunks of 128 tiles 340)
   int threads = sc::kBlock;
-  if ((((size_t)1 << (nv - 7)) >> chunk_log) > (size_t)4 * ctx->num_cus) {
+  if ((((size_t)1 << (nv - 7)) >> chunk_log) > (size_t)4 * std::min(ctx->num_cus, ctx->max_blocks)) {
     threads = ctx->gold ? sc::stream_block<sc::GoldilocksMont>::evaluate : sc::stream_block<sc::MontGeneric>::evaluate;
     grid = std::min(ctx->num_cus, ctx->max_blocks);
     chunk_log = std::min(chunk_log, 5);
