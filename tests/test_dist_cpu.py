@@ -20,7 +20,7 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 def model_sharded_prove(o, D, plan_proof, p, n, rank, world, opts, allreduce, allgather, pyref):
     """The sharded prover with the oracle in place of the kernels, driven by the ENGINE'S OWN PLANNER: the launches come
-    from sc_plan_proof (the function prover_pass calls at every pass, thaler-study_amd/csrc/sumcheck_hip.hip: plan_pass),
+    from sc_plan_proof (the function prover_pass calls at every pass, thaler-study_amd/csrc/engine/abi_prover.inc: plan_pass),
     this model only executes them - fold the pending challenges, accumulate the 3^ks-cell grid, sum its limbs across
     the ranks, gather when the plan says so - and answers the rounds from the grid like prover_answer."""
     start, length = D.shard_range(n, rank, world)
