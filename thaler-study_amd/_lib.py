@@ -134,7 +134,8 @@ class SumcheckHipError(RuntimeError):
 def build(force=False):
     """compile libsumcheck_hip.so for gfx950 (hipcc cross-compiles without a GPU)"""
     srcs = [os.path.join(CSRC, f) for f in ("sumcheck_hip.hip", "kernels.hpp", "field.hpp")]
-    srcs += [os.path.join(CSRC, "engine", f) for f in sorted(os.listdir(os.path.join(CSRC, "engine"))) if f.endswith(".inc")]
+    for sub, ext in (("engine", ".inc"), ("kernels", ".hpp")):
+        srcs += [os.path.join(CSRC, sub, f) for f in sorted(os.listdir(os.path.join(CSRC, sub))) if f.endswith(ext)]
     srcs.append(os.path.join(_HERE, "..", "include", "sumcheck_hip.h"))
     stale = (not os.path.exists(LIB_PATH) or
              any(os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs if os.path.exists(s)))

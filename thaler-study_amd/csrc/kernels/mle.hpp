@@ -1,0 +1,448 @@
+// Part of kernels.hpp (included there, in order): the single-table kernels (fold, evaluate, fix_low, coldot) and the elementwise ones.
+#pragma once
+
+namespace sc {
+
+// ------------------------------------------------------------------------------------
+// Single-table kernels (DenseMultilinearExtension::fix_variables / evaluate on their own,
+// and the two GEMV-shaped halves of matrix_multiplication::G::new).
+
+// LE fold of KF in {1,2,3} variables in one pass: coalesced 16-byte loads, wave-private LDS
+// transposition (a lane needs 2^(KF+1) consecutive entries), one coalesced 16-byte store
+// per lane.  n_units = number of output pieces (pairs of output entries).
+constexpr int kFoldBlock = 1024;   // fold_kernel: four-wave blocks for small tables, all sixteen waves of a CU beyond (host)
+constexpr int kFoldGrab = 4;       // consecutive tiles per draw from the block's counter
+constexpr size_t fold_kernel_lds_bytes(int kf, int threads) { return (size_t)(threads / kWave) * kWave * (size_t)(1 << kf) * sizeof(ull2); }
+template <class F, int KF, bool NT>
+__global__ void __launch_bounds__(kFoldBlock)
+fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, FoldW fw, size_t n_units) {
+  constexpr int IN = 2 << KF, NP = IN / 2;
+  extern __shared__ ull2 fold_lds[];   // [waves of the block][kWave * NP]: sized by the launch (fold_kernel_lds_bytes)
+  __shared__ unsigned lds_next;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  ull2* const my_lds = fold_lds + wave * kWave * NP;
+  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+  ull2* __restrict__ T2p = reinterpret_cast<ull2*>(T2);
+  const size_t n_tiles = (n_units + kWave - 1) / kWave, in_pieces = n_units * NP;
+  if (threadIdx.x == 0) lds_next = 0;
+  __syncthreads();
+  // the waves of a block draw runs of kFoldGrab tiles from a counter in LDS (evaluate_kernel; block b owns the runs c * grid + b)
+  auto next_run = [&]() -> size_t {
+    unsigned c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return ((size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x) * kFoldGrab;
+  };
+  for (size_t run = next_run(); run < n_tiles; run = next_run())
+  for (size_t tile = run; tile < run + kFoldGrab && tile < n_tiles; ++tile) {
+    ull2 pv[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const size_t q = tile * kWave * NP + (size_t)k * kWave + lane;
+      const ull2 zero = {0, 0};
+      pv[k] = zero;
+      if (q < in_pieces) pv[k] = ld16<NT>(Tp + q);
+    }
+    transpose_to_runs<NP>(my_lds, pv, lane);
+    u64 v[IN];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) { v[2 * k] = pv[k].x; v[2 * k + 1] = pv[k].y; }
+    fold_run<F, KF, IN>(f, v, fw);
+    const size_t qo = tile * kWave + lane;
+    if (qo < n_units) {
+      ull2 o = {v[0], v[1]};
+      T2p[qo] = o;
+    }
+  }
+}
+// LE, scalar tail: outputs that do not fill a 16-byte piece (n_out == 1).
+template <class F>
+__global__ void fold_le_small_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, u64 r,
+                                     size_t n_out) {
+  size_t b = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < n_out) T2[b] = f.add(T[2 * b], f.mul(r, f.sub(T[2 * b + 1], T[2 * b])));
+}
+// BE (variable = current MSB): out[b] = t[b] + r*(t[b+half] - t[b]); two entries per thread
+// when half is even, scalar otherwise.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+fold_be_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, u64 r, size_t half) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  if ((half & 1) == 0) {
+    const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+    ull2* __restrict__ T2p = reinterpret_cast<ull2*>(T2);
+    for (size_t u = (size_t)blockIdx.x * kBlock + threadIdx.x; u < half / 2; u += stride) {
+      const ull2 lo = Tp[u], hi = Tp[half / 2 + u];
+      ull2 o = {f.add(lo.x, f.mul(r, f.sub(hi.x, lo.x))), f.add(lo.y, f.mul(r, f.sub(hi.y, lo.y)))};
+      T2p[u] = o;
+    }
+  } else {
+    for (size_t b = (size_t)blockIdx.x * kBlock + threadIdx.x; b < half; b += stride)
+      T2[b] = f.add(T[b], f.mul(r, f.sub(T[b + half], T[b])));
+  }
+}
+
+// Up to 64 challenges by value (kernel argument).
+struct RVec {
+  u64 v[64];
+};
+
+// out[i] = prod_j ( bit_j(i) ? r[off+j] : 1 - r[off+j] ),  i < 2^nbits   (LE bit order)
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+eq_table_kernel(F f, RVec rv, int off, int nbits, u64* __restrict__ out) {
+  const size_t n = (size_t)1 << nbits;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < n; i += (size_t)gridDim.x * kBlock) {
+    u64 w = f.one();
+    for (int j = 0; j < nbits; ++j) {
+      const u64 rj = rv.v[off + j];
+      w = f.mul(w, ((i >> j) & 1) ? rj : f.sub(f.one(), rj));
+    }
+    out[i] = w;
+  }
+}
+
+// eqA[i] = prod_{j < ta} (bit_j(i) ? r[j] : 1 - r[j]), i < 2^ta <= 1024, by the whole block: products of two half
+// tables (<= 32 entries of <= 5 factors each, then one product per weight).  2^ta weights of ta factors each were ~1000
+// instructions per thread on waves issuing alone - 4 us of a 35 us launch on a 2^24-entry table.  Ends with a barrier.
+template <class F>
+__device__ __forceinline__ void build_eq_weights(const F& f, const u64* r, int ta, u64* eqA /* [1 << ta] */) {
+  __shared__ u64 eqH[2][32];
+  const int lo_bits = ta < 5 ? ta : 5, hi_bits = ta - lo_bits;
+  if (threadIdx.x < 64) {
+    const int half = threadIdx.x >> 5, i = threadIdx.x & 31;
+    const int nb = half ? hi_bits : lo_bits, off = half ? lo_bits : 0;
+    u64 w = f.one();
+    for (int j = 0; j < nb; ++j) {
+      const u64 rj = r[off + j];
+      w = f.mul(w, ((i >> j) & 1) ? rj : f.sub(f.one(), rj));
+    }
+    eqH[half][i] = w;   // entries with bits above nb repeat lower ones and are never read
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (1 << ta); i += blockDim.x) eqA[i] = f.mul(eqH[0][i & ((1 << lo_bits) - 1)], eqH[1][i >> lo_bits]);
+  __syncthreads();
+}
+
+// Polynomial::evaluate of a 2^n-entry table (n >= 8) in ONE streaming pass:
+//   sum_i t[i] * eq(r, i),  eq factored over the index bits as
+//   bit 0 (inside a 16-byte piece) | bits 1..6 (lane) | ta bits (tile within a segment,
+//   weights eqA) | tb bits (segment, weights eqB).
+// Inner sums are unreduced (lazy) accumulations of t * eqA (two per lane, for bit 0 = 0/1);
+// they are reduced once per chunk of tiles and folded into the outer accumulators with
+// eqB; the bit-0 and lane weights are applied once per thread at the end.  This is the
+// streaming form of vsbw_multilinear_from_evaluations' "eq table, then dot product"
+// (multilinear-extensions/src/lib.rs:6-24) without materialising the 2^n eq table.
+// Launched with kBlock threads while every wave gets at most one chunk, with stream_block<F>::evaluate threads = all twelve
+// waves a CU holds of it (three per SIMD) beyond that: the waves of a block then draw their chunks from a counter in LDS.  With three
+// 256-thread blocks per CU and a fixed share per wave the three wave slots of a SIMD left the loop of a 2^28-entry
+// table after 202 / 270 / 336 us - a SIMD issues its oldest wave first (pass_kernel, "Tiles are not dealt out in advance").
+template <class F> struct stream_block {            // threads of the one-block-per-CU launches of the two streaming readers
+  static constexpr int evaluate = 768, fix_low = 1024;
+};
+template <> struct stream_block<MontGeneric> {      // the generic-modulus arithmetic needs more registers per wave
+  static constexpr int evaluate = 512, fix_low = 512;
+};
+template <class F, bool NT>
+__global__ void __launch_bounds__(stream_block<F>::evaluate)
+evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chunk_log, u64 w_extra, PassOut out) {
+  __shared__ u64 eqA[1024];  // ta <= 10
+  __shared__ u64 lds[stream_block<F>::evaluate / kWave];
+  __shared__ int lds_flag;
+  __shared__ unsigned lds_next;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int tb = n - 7 - ta;
+  if (threadIdx.x == 0) lds_next = 0;
+  build_eq_weights(f, rv.v + 7, ta, eqA);   // the tile-in-segment weights (ends with a barrier)
+  auto next_chunk = [&]() -> size_t {
+    unsigned c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
+  };
+  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+  const size_t n_tiles = (size_t)1 << (n - 7);
+  const size_t n_chunks = n_tiles >> chunk_log;
+  const int C = 1 << chunk_log;
+  typename F::Acc o0, o1;
+  f.acc_zero(o0);
+  f.acc_zero(o1);
+  for (size_t chunk = next_chunk(); chunk < n_chunks; chunk = next_chunk()) {
+    const size_t tile0 = chunk << chunk_log;
+    const size_t seg = tile0 >> ta;
+    const int in_seg = (int)(tile0 & (((size_t)1 << ta) - 1));
+    typename F::Acc a0, a1;
+    f.acc_zero(a0);
+    f.acc_zero(a1);
+    // Batches of eight 16-byte loads per lane, DOUBLE-BUFFERED: the next batch is requested before the products of the
+    // current one.  On a 2^24-entry table the launch has one wave per SIMD, and a wave that waits for its loads (~0.7 us)
+    // and then multiplies (240 instructions issued alone, ~0.9 us) in turn reads at 5.2 TB/s whatever the grid shape
+    // (profiles/r03_mle24_sweep.txt); with the next batch in flight during the products the two overlap.  Written as
+    // fixed-count loops because the runtime unroller does not touch loops that contain inline assembly (acc_mac).
+    auto load8 = [&](ull2 (&p8)[8], size_t tile) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) p8[k] = ld16<NT>(Tp + (tile + k) * kWave + lane);
+    };
+    auto mac8 = [&](const ull2 (&p8)[8], int w0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const u64 w = eqA[w0 + k];
+        f.acc_mac(a0, p8[k].x, w);
+        f.acc_mac(a1, p8[k].y, w);
+      }
+    };
+    int i = 0;
+    if (C >= 16) {
+      ull2 pa[8], pb[8];
+      load8(pa, tile0);
+      for (; i + 16 <= C; i += 16) {
+        load8(pb, tile0 + i + 8);
+        mac8(pa, in_seg + i);
+        if (i + 32 <= C) load8(pa, tile0 + i + 16);
+        mac8(pb, in_seg + i + 8);
+      }
+    }
+    for (; i + 8 <= C; i += 8) {
+      ull2 pc[8];
+      load8(pc, tile0 + i);
+      mac8(pc, in_seg + i);
+    }
+    for (; i < C; ++i) {
+      const size_t q = (tile0 + i) * kWave + lane;
+      const ull2 pc = ld16<NT>(Tp + q);
+      const u64 w = eqA[in_seg + i];
+      f.acc_mac(a0, pc.x, w);
+      f.acc_mac(a1, pc.y, w);
+    }
+    u64 wB = f.one();  // segment weight, wave-uniform: tb factors per chunk of 2*C products
+    for (int j = 0; j < tb; ++j) {
+      const u64 rj = rv.v[7 + ta + j];
+      wB = f.mul(wB, ((seg >> j) & 1) ? rj : f.sub(f.one(), rj));
+    }
+    f.acc_mac(o0, f.acc_get(a0), wB);
+    f.acc_mac(o1, f.acc_get(a1), wB);
+  }
+  // bit 0, lane and (sharded evaluate) rank weights
+  const u64 r0 = rv.v[0];
+  u64 v = f.add(f.mul(f.sub(f.one(), r0), f.acc_get(o0)), f.mul(r0, f.acc_get(o1)));
+  u64 wl = w_extra;
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const u64 rj = rv.v[1 + j];
+    wl = f.mul(wl, ((lane >> j) & 1) ? rj : f.sub(f.one(), rj));
+  }
+  u64 res[1] = {f.mul(v, wl)};
+  block_reduce<F, 1>(f, res, lds);
+  finish_pass<F, 1>(f, out, res[0], &lds_flag);
+}
+
+// LE fix of the LOW k variables (8 <= k <= 17) in ONE pass: out[b] = sum_c eq(r, c) * t[b*2^k + c],
+// i.e. evaluate_kernel's inner product on every contiguous segment of 2^k entries, one wave per
+// segment (coalesced 1 KiB wave loads, tile weights eqA in LDS, bit-0 and lane weights applied
+// once per segment, a shuffle reduction, one 8-byte store).  A chain of three-variable folds
+// reads the table 1.14 times and writes an eighth of it; this reads it once.
+// (DenseMultilinearExtension::fix_variables with many variables; the f_B half of G::new.)
+template <class F, bool NT>
+__global__ void __launch_bounds__(stream_block<F>::fix_low)
+fix_low_kernel(F f, const u64* __restrict__ T, u64* __restrict__ out, int k, RVec rv, size_t n_out) {
+  __shared__ u64 eqA[1024];  // k - 7 <= 10
+  __shared__ unsigned lds_next;   // the block's segment counter (see evaluate_kernel)
+  const int lane = threadIdx.x & (kWave - 1);
+  const int ta = k - 7;
+  if (threadIdx.x == 0) lds_next = 0;
+  build_eq_weights(f, rv.v + 7, ta, eqA);
+  auto next_seg = [&]() -> size_t {
+    unsigned c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
+  };
+  u64 wl = f.one();
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const u64 rj = rv.v[1 + j];
+    wl = f.mul(wl, ((lane >> j) & 1) ? rj : f.sub(f.one(), rj));
+  }
+  const u64 r0 = rv.v[0], one_minus_r0 = f.sub(f.one(), r0);
+  __syncthreads();
+  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+  const int tiles = 1 << ta;
+  for (size_t seg = next_seg(); seg < n_out; seg = next_seg()) {
+    const ull2* __restrict__ Sp = Tp + (seg << (k - 1)) + lane;
+    typename F::Acc a0, a1;
+    f.acc_zero(a0);
+    f.acc_zero(a1);
+    // double-buffered batches of eight loads (see evaluate_kernel)
+    auto load8 = [&](ull2 (&p8)[8], int tile) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) p8[q] = ld16<NT>(Sp + (size_t)(tile + q) * kWave);
+    };
+    auto mac8 = [&](const ull2 (&p8)[8], int w0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const u64 w = eqA[w0 + q];
+        f.acc_mac(a0, p8[q].x, w);
+        f.acc_mac(a1, p8[q].y, w);
+      }
+    };
+    int i = 0;
+    if (tiles >= 16) {
+      ull2 pa[8], pb[8];
+      load8(pa, 0);
+      for (; i + 16 <= tiles; i += 16) {
+        load8(pb, i + 8);
+        mac8(pa, i);
+        if (i + 32 <= tiles) load8(pa, i + 16);
+        mac8(pb, i + 8);
+      }
+    }
+    for (; i + 8 <= tiles; i += 8) {
+      ull2 pc[8];
+      load8(pc, i);
+      mac8(pc, i);
+    }
+    for (; i < tiles; ++i) {
+      const ull2 pc = Sp[(size_t)i * kWave];
+      const u64 w = eqA[i];
+      f.acc_mac(a0, pc.x, w);
+      f.acc_mac(a1, pc.y, w);
+    }
+    u64 v = f.add(f.mul(one_minus_r0, f.acc_get(a0)), f.mul(r0, f.acc_get(a1)));
+    v = f.mul(v, wl);
+#pragma unroll
+    for (int off = kWave / 2; off >= 1; off >>= 1) v = f.add(v, shfl_down_u64(v, off));
+    if (lane == 0) out[seg] = v;
+  }
+}
+
+// "Column dot": out[c] = sum_{i in [i0, i1)} w[i] * t[i*M + c]  for one chunk of rows per
+// blockIdx.y; partial[y][c] holds chunk y (reduced by sum_rows_kernel when there are
+// several).  This is fix_variables of the TOP k index bits (BE order), and the f_A half of
+// G::new: f_A[col] = sum_row eq(r1)[row] * A[row][col] (matrix-multiplication/src/lib.rs:81-83,
+// relabel + fold collapsed into one pass).  Lanes own 16-byte pieces of c: coalesced.
+// Row-walking access pattern (this kernel and gkr_phase1_kernel): a WAVE owns PW consecutive 1 KiB spans of every row
+// of its chunk (lane l: pieces span*64*PW + 64 j + l, j < PW).  Measured on this chip (tools/rowwalk.hip,
+// profiles/r03_rowwalk.txt, two 2^13 x 2^13 tables): one 1 KiB span per wave and row reads at 6.3 TB/s, four
+// contiguous KiB at 6.9; FOUR waves per SIMD are slower than one (5.1-5.7 TB/s: more rows open at once than the
+// DRAM pages like) - so the launch is sized for one wave per SIMD and the memory pipe is fed by the loads in flight
+// per lane (rows in flight x PW), not by occupancy.
+template <class F, bool NT, int PW>
+__global__ void __launch_bounds__(kBlock)
+coldot_kernel(F f, const u64* __restrict__ T, const u64* __restrict__ w, size_t rows, size_t rows_per_chunk,
+              size_t M, u64* __restrict__ partial) {
+  constexpr int RIF = 4;   // rows in flight per thread (tools/rowwalk.hip: 4 x 4 KiB reads fastest on one table)
+  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+  ull2* __restrict__ Pp = reinterpret_cast<ull2*>(partial);
+  const size_t mp = M / 2;  // pieces per row
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const size_t i0 = (size_t)blockIdx.y * rows_per_chunk;
+  const size_t i1 = (i0 + rows_per_chunk < rows) ? i0 + rows_per_chunk : rows;
+  const size_t n_spans = (mp + (size_t)kWave * PW - 1) / ((size_t)kWave * PW);
+  for (size_t span = (size_t)blockIdx.x * (kBlock / kWave) + wave; span < n_spans; span += (size_t)gridDim.x * (kBlock / kWave)) {
+    const size_t pc0 = span * kWave * PW + lane;
+    typename F::Acc a0[PW], a1[PW];
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      f.acc_zero(a0[j]);
+      f.acc_zero(a1[j]);
+    }
+    const ull2 zero = {0, 0};
+    size_t i = i0;
+    for (; i + RIF <= i1; i += RIF) {  // fixed-count inner loop: see evaluate_kernel
+      ull2 v[RIF][PW];
+#pragma unroll
+      for (int k = 0; k < RIF; ++k)
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+          const size_t pc = pc0 + (size_t)j * kWave;
+          v[k][j] = (PW == 1 || pc < mp) ? ld16<NT>(Tp + (i + k) * mp + (pc < mp ? pc : 0)) : zero;
+        }
+#pragma unroll
+      for (int k = 0; k < RIF; ++k) {
+        const u64 wi = w[i + k];
+#pragma unroll
+        for (int j = 0; j < PW; ++j) {
+          f.acc_mac(a0[j], v[k][j].x, wi);
+          f.acc_mac(a1[j], v[k][j].y, wi);
+        }
+      }
+    }
+    for (; i < i1; ++i) {
+      const u64 wi = w[i];
+#pragma unroll
+      for (int j = 0; j < PW; ++j) {
+        const size_t pc = pc0 + (size_t)j * kWave;
+        const ull2 v = pc < mp ? ld16<NT>(Tp + i * mp + pc) : zero;
+        f.acc_mac(a0[j], v.x, wi);
+        f.acc_mac(a1[j], v.y, wi);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < PW; ++j) {
+      const size_t pc = pc0 + (size_t)j * kWave;
+      if (pc < mp) Pp[(size_t)blockIdx.y * mp + pc] = ull2{f.acc_get(a0[j]), f.acc_get(a1[j])};
+    }
+  }
+}
+// out[c] = sum_y partial[y][c], for one or two arrays of partial rows (blockIdx.y selects; the second is the L of a GKR
+// phase).  Eight rows in flight per thread: the first version walked the rows one dependent load at a time with 2^13
+// threads - 20 us per array for 64 x 2^13 words, a tenth of the streaming pass it follows.
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+sum_rows_kernel(F f, const u64* __restrict__ partial0, const u64* __restrict__ partial1, size_t chunks, size_t M,
+                u64* __restrict__ out0, u64* __restrict__ out1) {
+  const u64* __restrict__ partial = blockIdx.y ? partial1 : partial0;
+  u64* __restrict__ out = blockIdx.y ? out1 : out0;
+  for (size_t c = (size_t)blockIdx.x * kBlock + threadIdx.x; c < M; c += (size_t)gridDim.x * kBlock) {
+    u64 t = 0;
+    size_t y = 0;
+    for (; y + 8 <= chunks; y += 8) {
+      u64 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = partial[(y + q) * M + c];
+      t = f.add(t, f.add(f.add(f.add(v[0], v[1]), f.add(v[2], v[3])), f.add(f.add(v[4], v[5]), f.add(v[6], v[7]))));
+    }
+    for (; y < chunks; ++y) t = f.add(t, partial[y * M + c]);
+    out[c] = t;
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// Elementwise / utility kernels.
+
+// t[i] = to_mont(splitmix64(seed + start + i) mod p)   
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+generate_kernel(F f, u64 seed, u64 start, size_t len, u64* __restrict__ out) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += stride)
+    out[i] = f.to_mont(f.reduce_word(splitmix64(seed + start + i)));
+}
+
+// G::to_evaluations: out[i] = a[i]*b[i]   (matrix-multiplication/src/lib.rs:137-146)
+template <class F>
+__global__ void __launch_bounds__(kBlock)
+mul_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ out, size_t len) {
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < len; i += stride)
+    out[i] = f.mul(A[i], B[i]);
+}
+
+// DenseMultilinearExtension::relabel: out[swap_fields(i)] = t[i]; the swap is an involution
+// so it is applied to the (coalesced) output index.
+__global__ void __launch_bounds__(kBlock)
+relabel_kernel(const u64* __restrict__ T, u64* __restrict__ out, size_t len, unsigned a, unsigned b,
+               unsigned k) {
+  const size_t mask = ((size_t)1 << k) - 1;
+  const size_t stride = (size_t)gridDim.x * kBlock;
+  for (size_t j = (size_t)blockIdx.x * kBlock + threadIdx.x; j < len; j += stride) {
+    size_t fa = (j >> a) & mask, fb = (j >> b) & mask;
+    size_t i = (j & ~((mask << a) | (mask << b))) | (fb << a) | (fa << b);
+    out[j] = T[i];
+  }
+}
+
+// Sharded evaluate helper: out_split = split limbs of w * v (one thread).
+template <class F>
+__global__ void scale_split_kernel(F f, const u64* __restrict__ v, u64 w, u64* __restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) write_split(out, 0, f.mul(w, v[0]));
+}
+
+}  // namespace sc

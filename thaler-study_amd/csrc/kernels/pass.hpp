@@ -1,0 +1,500 @@
+// Part of kernels.hpp (included there, in order): the hand-off of a pass to the host and the peers (PassOut, finish_pass), and pass_kernel.
+#pragma once
+
+namespace sc {
+
+// ------------------------------------------------------------------------------------
+// The pass kernel: fold KF pending variables of both tables, write the folded tables,
+// and accumulate the round sums of the FOLDED tables for the next KS rounds - one read of
+// the inputs, one write of the outputs (reference: Prover::round =
+// fix_variables + to_univariate, sum-check-protocol/src/lib.rs:105-112).
+//
+// unit = one run of IN = 2^(KF+KS) input entries per table -> OUT = 2^KS output entries,
+// owned by one lane; a wave tile is 64 units.  KF in 0..3, KS in 1..3 (KS = 3, the 27-cell grid
+// of a three-round first pass, is only instantiated with KF = 0).  Sums leave through
+// finish_pass (PassOut).
+// Where a pass leaves its sums.
+//  * grid of one block: that block publishes directly.
+//  * larger grids: every block stores its partial residues (sum-major rows), takes a ticket,
+//    and the block that draws the last ticket reduces all partials and publishes - one
+//    launch per pass instead of pass + reduce (+ copy).  Hand-off follows
+//    cdna_hip_programming.md Guideline 16 (form R1): partials are stored write-through
+//    (sc1), the storing wave drains them (s_waitcnt vmcnt(0)), then lane 0 adds to the
+//    ticket; the block whose add returns the last ticket acquires at agent scope behind a
+//    workgroup barrier and reads the partials with sc1 loads.  The ticket counter only grows
+//    (base = value before this launch), so nothing has to be re-zeroed between launches.
+//  * publish target: `mailbox` (pinned host memory the host spins on: 2*NS split limbs, then
+//    the sequence word at index kMailboxSeq) or, for the sharded transports that still have
+//    to all-reduce on the device, `sums_dev`.
+constexpr int kMailboxSeq = 60;   // 2*27 limbs first, the sequence word after them
+constexpr int kMailboxErr = 62;   // 0, or why the pass's cross-rank exchange failed (kXchg*)
+
+// In-kernel exchange of the round sums between the ranks of a sharded prover (one process per GPU,
+// SURVEY.md section 8e).  Each rank owns an INBOX in its own HBM that every peer maps (HIP IPC) and writes
+// over xGMI: inbox[parity][source rank][kInboxWords] 8-byte granules {tag : 32 | value : 32}.  The values
+// are the 32-bit limbs of the pass's sums (a u64 sum of residues would wrap mod 2^64, not mod p), so the
+// data IS the flag (cdna_hip_programming.md Guideline 16, R2): the last block of a pass stores its 2*NS
+// limbs into every rank's inbox with one store each, sweeps its own inbox until every source's tag is
+// this pass's, adds the limbs and publishes the totals to its host - no collective launch, no separate
+// flag, no ordering requirement between the stores.  Two parities: a rank can be at most one pass ahead
+// of a peer that has not read the previous pass yet.  One more granule carries a digest of the
+// challenges the pass folds; ranks that were fed different challenges fail loudly instead of proving
+// different statements.
+constexpr int kMaxPeers = 8;
+constexpr int kInboxWords = 64 + 512; // 64 for the passes with up to 27 cells (+ digest, gather flag), then the wide part
+constexpr int kInboxWide = 64;       // first granule of the wide part: 2 x 243 limbs of a five-round pass
+constexpr int kInboxDigest = 56;     // granule index of the challenge digest
+constexpr int kInboxGather = 57;     // granule index of the table-gather flag
+// failure codes of an exchange (mailbox word kMailboxErr): a timeout carries the source rank it waited for in bits 8..15
+// and outranks a digest mismatch wherever codes are combined with max()
+constexpr int kXchgDigest = 2, kXchgTimeout = 0x40000000;
+struct PeerX {
+  u64* inbox[kMaxPeers] = {};   // inbox[q]: rank q's inbox as this process maps it (q == rank: the local one)
+  int world = 0;                // 0: no in-kernel exchange
+  int rank = 0;
+  unsigned tag = 0;             // this pass's exchange tag: the same on every rank, never 0
+  unsigned digest = 0;
+  u64 spin_ticks = 0;           // bound of the sweep (wall clock, 100 MHz)
+};
+struct PassOut {
+  u64* partials;
+  int n_rows;
+  unsigned* ticket;
+  unsigned ticket_base;
+  u64* sums_dev;
+  u64* mailbox;
+  u64 seq;
+  PeerX px;
+};
+
+__device__ __forceinline__ void publish_value(const PassOut& o, int s, u64 v) {
+  if (o.mailbox) {
+    __hip_atomic_store(o.mailbox + 2 * s, v & 0xFFFFFFFFull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(o.mailbox + 2 * s + 1, v >> 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  } else {
+    write_split(o.sums_dev, s, v);
+  }
+}
+// after a workgroup barrier that follows every publish_value of the block
+__device__ __forceinline__ void publish_seq(const PassOut& o) {
+  if (o.mailbox && threadIdx.x == 0)
+    __hip_atomic_store(o.mailbox + kMailboxSeq, o.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Cross-rank exchange by ONE workgroup (the pass's last block): xl[0 .. 2*NS) are this rank's limbs.
+// Leaves the limb totals in the host mailbox; every thread of the block must call it.
+template <int NS>
+__device__ __forceinline__ void exchange_and_publish(const PassOut& o, u64* xl) {
+  const PeerX& px = o.px;
+  const int lane = threadIdx.x;
+  __syncthreads();   // xl is complete
+  if (threadIdx.x < kWave) {
+    const bool mine = lane < 2 * NS || lane == kInboxDigest;
+    const u64 val = (lane < 2 * NS) ? xl[lane] : (u64)px.digest;
+    const u64 granule = ((u64)px.tag << 32) | (val & 0xFFFFFFFFull);
+    const size_t slot = ((size_t)(px.tag & 1u) * kMaxPeers + (size_t)px.rank) * kInboxWords + (size_t)lane;
+    if (mine) {
+      for (int q = 0; q < px.world; ++q)
+        __hip_atomic_store(px.inbox[q] + slot, granule, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // sweep the local inbox: one granule per source rank and lane
+    u64 total = 0;
+    int err = 0;
+    const unsigned long long t0 = wall_clock64();
+    if (mine) {
+      const u64* base = px.inbox[px.rank] + (size_t)(px.tag & 1u) * kMaxPeers * kInboxWords + (size_t)lane;
+      for (int r = 0; r < px.world && !err; ++r) {
+        unsigned spins = 0;
+        while (true) {
+          const u64 g = __hip_atomic_load(base + (size_t)r * kInboxWords, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if ((unsigned)(g >> 32) == px.tag) {
+            if (lane == kInboxDigest) err = ((unsigned)g != px.digest) ? kXchgDigest : 0;
+            else total += g & 0xFFFFFFFFull;
+            break;
+          }
+          if ((++spins & 31) == 0 && wall_clock64() - t0 > px.spin_ticks) {
+            // diagnosis for the host's message: which source, and the tag its slot still held
+            err = kXchgTimeout | (r << 8) | ((int)((g >> 32) & 0x3FFF) << 16);
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+      }
+    }
+    if (lane < 2 * NS) __hip_atomic_store(o.mailbox + lane, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // any lane's failure reaches the host before the sequence word does
+    const int any = __any(err != 0) ? 1 : 0;
+    int code = err;
+#pragma unroll
+    for (int off = kWave / 2; off >= 1; off >>= 1) code = max(code, __shfl_down(code, off, kWave));
+    if (lane == 0) __hip_atomic_store(o.mailbox + kMailboxErr, (u64)(any ? code : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  __syncthreads();
+  publish_seq(o);
+}
+
+// Tail of every pass: res[0] of thread s < NS holds the block's residue of sum s.
+template <class F, int NS, int BS = kBlock>
+__device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my_res, int* lds_flag) {
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  __shared__ u64 xl[2 * NS + 2];   // this rank's limbs on their way to the peers (sharded passes only)
+  const bool xchg = o.px.world > 0;
+  if (gridDim.x == 1) {
+    if (xchg) {
+      if (threadIdx.x < NS) write_split(xl, threadIdx.x, my_res);
+      exchange_and_publish<NS>(o, xl);
+      return;
+    }
+    if (threadIdx.x < NS) publish_value(o, threadIdx.x, my_res);
+    __syncthreads();
+    publish_seq(o);
+    return;
+  }
+  if (threadIdx.x < NS)
+    __hip_atomic_store(o.partials + (size_t)threadIdx.x * o.n_rows + blockIdx.x, my_res, __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  if (threadIdx.x == 0) {
+    // wave 0 holds every storing lane: drain its write-through stores, then signal.  No
+    // agent-scope release fence: that is a whole-L2 write-back per block (~2-6 us each and
+    // 2048 of them per launch); sc1 stores + drain is Guideline 16's R1 form.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned t = __hip_atomic_fetch_add(o.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (t - o.ticket_base == gridDim.x - 1) ? 1 : 0;
+    if (last) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *lds_flag = last;
+  }
+  __syncthreads();
+  if (!*lds_flag) return;
+  const int n_blocks = gridDim.x;
+  if constexpr (NS >= 9) {
+    // thread = (cell, slice), the sixteen slices of a cell in adjacent lanes: a load instruction of a wave reads four
+    // 128-byte lines (cell-major partials: slices = consecutive blocks), not 64 scattered words - with the cells in
+    // adjacent lanes the same loads took 4.6 us for 256 x 27 partials (profiles/r03_pass_block_stamps.txt), two thirds
+    // of the last block's work.  Every load of a thread is in flight at once; the slices are summed through LDS.
+    constexpr int K = 16, U = 16;
+    static_assert(BS >= K * NS, "sixteen slices per cell");
+    __shared__ u64 fin[K * NS];
+    const int row = threadIdx.x / K, slice = threadIdx.x % K;
+    if (row < NS) {
+      const u64* src = o.partials + (size_t)row * o.n_rows;
+      u64 part = 0;
+      for (int b0 = slice; b0 < n_blocks; b0 += K * U) {
+        u64 x[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const int b = b0 + u * K;
+          x[u] = (b < n_blocks) ? __hip_atomic_load(src + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U / 2; ++u) x[u] = f.add(x[u], x[u + U / 2]);
+#pragma unroll
+        for (int u = 0; u < U / 4; ++u) x[u] = f.add(x[u], x[u + U / 4]);
+#pragma unroll
+        for (int u = 0; u < U / 4; ++u) part = f.add(part, x[u]);
+      }
+      fin[slice * NS + row] = part;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+      u64 t = 0;
+#pragma unroll
+      for (int q = 0; q < K; ++q) t = f.add(t, fin[q * NS + threadIdx.x]);
+      if (xchg) write_split(xl, threadIdx.x, t);
+      else publish_value(o, threadIdx.x, t);
+    }
+  } else {
+    // each wave takes the rows wave, wave+4, ... two at a time: the loads of one row are a chain of
+    // dependent rounds (~1 us each from L2), so two rows in flight halve the serial tail
+    constexpr int kWavesPerBlock = kBlock / kWave;
+    for (int s = wave; s < NS; s += 2 * kWavesPerBlock) {
+      const int s2 = s + kWavesPerBlock;
+      const bool two = s2 < NS;
+      const u64* row0 = o.partials + (size_t)s * o.n_rows;
+      const u64* row1 = o.partials + (size_t)(two ? s2 : s) * o.n_rows;
+      u64 a0 = 0, a1 = 0, c0 = 0, c1 = 0;
+      int b = lane;
+      for (; b + 3 * kWave < n_blocks; b += 4 * kWave) {  // eight loads in flight per lane
+        u64 x[4], y[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          x[q] = __hip_atomic_load(row0 + b + q * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          y[q] = __hip_atomic_load(row1 + b + q * kWave, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        a0 = f.add(a0, f.add(x[0], x[2])); a1 = f.add(a1, f.add(x[1], x[3]));
+        c0 = f.add(c0, f.add(y[0], y[2])); c1 = f.add(c1, f.add(y[1], y[3]));
+      }
+      for (; b < n_blocks; b += kWave) {
+        a0 = f.add(a0, __hip_atomic_load(row0 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        c0 = f.add(c0, __hip_atomic_load(row1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+      }
+      u64 t = f.add(a0, a1), u = f.add(c0, c1);
+#pragma unroll
+      for (int off = kWave / 2; off >= 1; off >>= 1) {
+        t = f.add(t, shfl_down_u64(t, off));
+        u = f.add(u, shfl_down_u64(u, off));
+      }
+      if (lane == 0) {
+        if (xchg) {
+          write_split(xl, s, t);
+          if (two) write_split(xl, s2, u);
+        } else {
+          publish_value(o, s, t);
+          if (two) publish_value(o, s2, u);
+        }
+      }
+    }
+  }
+  if (xchg) {
+    exchange_and_publish<NS>(o, xl);
+    return;
+  }
+  __syncthreads();
+  publish_seq(o);
+}
+
+// Per-thread accumulators of NS cells -> block sums: thread s ends up with the block's sum of cell s.
+// Nine sums at a time (a 27-cell grid would otherwise hold 27 residues next to the accumulators they come
+// from).  lds: kWaves * min(NS, 9) words of scratch.
+template <class F, int NS>
+__device__ __forceinline__ u64 reduce_cells(const F& f, const typename F::Acc (&acc)[NS], u64* lds) {
+  constexpr int CH = (NS < 9) ? NS : 9;
+  u64 mine = 0;
+#pragma unroll
+  for (int c0 = 0; c0 < NS; c0 += CH) {
+    u64 res[CH];
+#pragma unroll
+    for (int s = 0; s < CH; ++s) res[s] = f.acc_get(acc[c0 + s]);
+    if (c0 > 0) __syncthreads();  // the previous chunk's scratch has been read
+    block_reduce<F, CH>(f, res, lds);
+    if ((int)threadIdx.x >= c0 && (int)threadIdx.x < c0 + CH) mine = res[0];
+    if constexpr (NS > CH) {
+      // block_reduce leaves chunk sum s in thread s; hand it to thread c0 + s
+      __syncthreads();
+      if (threadIdx.x < CH) lds[threadIdx.x] = res[0];
+      __syncthreads();
+      if ((int)threadIdx.x >= c0 && (int)threadIdx.x < c0 + CH) mine = lds[threadIdx.x - c0];
+    }
+  }
+  return mine;
+}
+
+// The same through LDS, on the RAW accumulators: a thread that turns 27 lazy sums into residues and then takes
+// part in 27 x 6 shuffle rounds spends ~2800 instructions on it, on a wave that by then issues alone (~10 us of
+// every launch of the 27-cell pass, ~3.5 us of a 9-cell one: nothing at 2^28 entries, 10 % of a pass on a 2^25-entry
+// shard).  Here the accumulators of eight cells at a time go to LDS, thread (cell, part) adds eight of them as
+// integers, 32 lanes finish with five shuffle rounds and ONE lane per cell reduces to a residue: ~170 instructions
+// per chunk of BS / 32 cells.  scratch: (BS / 32) * BS accumulators (BS = threads of the block); out: NS words.
+template <class A>
+__device__ __forceinline__ A shfl_down_acc(const A& a, int off) {
+  static_assert(sizeof(A) % 4 == 0, "accumulator words");
+  A r;
+  const unsigned* src = reinterpret_cast<const unsigned*>(&a);
+  unsigned* dst = reinterpret_cast<unsigned*>(&r);
+#pragma unroll
+  for (int w = 0; w < (int)(sizeof(A) / 4); ++w) dst[w] = (unsigned)__shfl_down((int)src[w], off, kWave);
+  return r;
+}
+template <class F, int NS, int BS = kBlock>
+__device__ __forceinline__ u64 reduce_cells_lds(const F& f, const typename F::Acc (&acc)[NS], typename F::Acc* scratch, u64* out) {
+  typedef typename F::Acc Acc;
+  constexpr int CH = BS / 32;   // cells per chunk: 32 threads sum one cell
+  const int tid = threadIdx.x, cell = tid >> 5, part = tid & 31;
+#pragma unroll
+  for (int c0 = 0; c0 < NS; c0 += CH) {
+    constexpr int kRest = NS % CH;
+    const int n = (c0 + CH <= NS) ? CH : kRest;
+    if (c0 > 0) __syncthreads();   // the previous chunk's accumulators have been read
+#pragma unroll
+    for (int s = 0; s < CH; ++s)
+      if (s < n) scratch[s * BS + tid] = acc[(c0 + s < NS) ? c0 + s : 0];
+    __syncthreads();
+    if (cell < n) {
+      Acc t = scratch[cell * BS + part];
+#pragma unroll
+      for (int k = 1; k < BS / 32; ++k) f.acc_add(t, scratch[cell * BS + part + 32 * k]);
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1) {
+        const Acc o = shfl_down_acc(t, off);
+        f.acc_add(t, o);
+      }
+      if (part == 0) out[c0 + cell] = f.acc_get(t);
+    }
+  }
+  __syncthreads();
+  return tid < NS ? out[tid] : 0;
+}
+
+// Threads per block of pass_kernel<., KF, KS, .>.  The arithmetic-heavy instantiations hold two or three waves per SIMD
+// (their registers allow no more) and get ALL of a CU's waves into ONE block, so that the waves of a SIMD can share
+// their work through LDS (see the tile loop); the light ones keep 256 threads and several blocks per CU.
+__host__ __device__ constexpr int pass_block_threads(int kf, int ks) {
+  return (ks == 3 || (kf == 3 && ks == 2)) ? 512 : (kf == 2 && ks == 2) ? 768 : kBlock;
+}
+
+// NT: bit 0 = nontemporal loads, bit 1 = nontemporal stores (see ld16 / st16)
+template <class F, int KF, int KS, int NT>
+__global__ void __launch_bounds__(pass_block_threads(KF, KS))
+pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
+            u64* __restrict__ B2, FoldW fw, size_t n_units, PassOut out) {
+  constexpr bool kNtLoad = (NT & 1) != 0, kNtStore = (NT & 2) != 0;
+  constexpr int IN = 1 << (KF + KS), OUT = 1 << KS, NS = (KS == 1) ? 3 : (KS == 2) ? 9 : 27;
+  constexpr int NP = IN / 2, NPO = OUT / 2;  // 16-byte pieces per lane, in and out
+  constexpr int BS = pass_block_threads(KF, KS), kWaves = BS / kWave;
+  static_assert(BS == kBlock || NS >= 9, "reduce_cells (the KS = 1 passes) is written for 256 threads");
+  // the tile transposes; after the loop the same bytes hold a chunk of every thread's accumulators (reduce_cells_lds)
+  constexpr int kTransposeSlots = (NP > 1 || NPO > 1) ? kWaves * kWave * NP : 1;
+  constexpr int kReduceSlots = (NS >= 9) ? (int)((NS < BS / 32 ? NS : BS / 32) * BS * sizeof(typename F::Acc) / sizeof(ull2)) : 1;
+  __shared__ ull2 lds_t[kTransposeSlots > kReduceSlots ? kTransposeSlots : kReduceSlots];
+  __shared__ u64 lds[kWaves * NS];
+  __shared__ int lds_flag;
+  __shared__ unsigned lds_next;   // the block's tile counter
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  ull2* const my_lds = lds_t + ((NP > 1 || NPO > 1) ? wave * kWave * NP : 0);
+
+  typename F::Acc acc[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) f.acc_zero(acc[s]);
+
+  const size_t n_tiles = (n_units + kWave - 1) / kWave;
+  const size_t in_pieces = n_units * NP, out_pieces = n_units * NPO;
+  const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(A);
+  const ull2* __restrict__ Bp = reinterpret_cast<const ull2*>(B);
+  ull2* __restrict__ A2p = reinterpret_cast<ull2*>(A2);
+  ull2* __restrict__ B2p = reinterpret_cast<ull2*>(B2);
+
+  // inactive lanes carry zeros: they add nothing to the sums and store nothing.  Tables far
+  // larger than the 256 MiB Infinity Cache are read once: stream them (nontemporal).
+  auto load_tile = [&](size_t tile, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
+    const size_t q0 = tile * kWave * NP;
+    if (q0 + (size_t)kWave * NP <= in_pieces) {  // full tile (wave-uniform): no per-piece test
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const size_t q = q0 + (size_t)k * kWave + lane;
+        pa[k] = ld16<kNtLoad>(Ap + q);
+        pb[k] = ld16<kNtLoad>(Bp + q);
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        const size_t q = q0 + (size_t)k * kWave + lane;
+        const ull2 zero = {0, 0};
+        pa[k] = (q < in_pieces) ? Ap[q] : zero;
+        pb[k] = (q < in_pieces) ? Bp[q] : zero;
+      }
+    }
+  };
+  // KF = 3: a run is 2^(3+KS) entries; read it back from LDS one output (8 entries) at a time so
+  // that only the staged pieces and OUT folded values are live, not the whole run twice.
+  auto stage_and_fold3 = [&](ull2 (&p)[NP], u64 (&t)[IN]) {
+    if constexpr (KF == 3) {  // (the body only instantiates for run lengths swz_slot supports)
+#pragma unroll
+      for (int k = 0; k < NP; ++k) my_lds[swz_slot<NP>(64 * k + lane)] = p[k];
+      wave_lds_fence();
+#pragma unroll
+      for (int o = 0; o < OUT; ++o) {
+        u64 v[8];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          const ull2 x = my_lds[swz_slot<NP>(NP * lane + 4 * o + m)];
+          v[2 * m] = x.x; v[2 * m + 1] = x.y;
+        }
+        fold_run<F, 3, 8>(f, v, fw);
+        t[o] = v[0];
+      }
+      wave_lds_fence();
+    }
+  };
+  // The 27-cell grid runs at two waves per SIMD and is ALU-heavy: it cannot count on other
+  // waves to cover its loads, so it fetches the wave's next tile before it starts on the
+  // arithmetic of the current one.  (The three-variable fold has no registers for a second tile; asking for one table
+  // of the next tile at a time, while the other table is folded out of LDS, was measured and gave nothing: that pass is
+  // not waiting for its own loads.)
+  constexpr bool kPrefetch = (KS == 3);
+  auto process_tile = [&](size_t tile, size_t next, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
+    u64 a[IN], b[IN];
+    if constexpr (KF == 3) {
+      stage_and_fold3(pa, a);
+      stage_and_fold3(pb, b);
+    } else {
+      transpose_to_runs<NP>(my_lds, pa, lane);
+      transpose_to_runs<NP>(my_lds, pb, lane);
+#pragma unroll
+      for (int k = 0; k < NP; ++k) {
+        a[2 * k] = pa[k].x; a[2 * k + 1] = pa[k].y;
+        b[2 * k] = pb[k].x; b[2 * k + 1] = pb[k].y;
+      }
+      if constexpr (kPrefetch) {
+        if (next < n_tiles) load_tile(next, pa, pb);
+      }
+      fold_run<F, KF, IN>(f, a, fw);
+      fold_run<F, KF, IN>(f, b, fw);
+    }
+    if constexpr (KF > 0) {
+      ull2 oa[NPO], ob[NPO];
+#pragma unroll
+      for (int m = 0; m < NPO; ++m) {
+        oa[m].x = a[2 * m]; oa[m].y = a[2 * m + 1];
+        ob[m].x = b[2 * m]; ob[m].y = b[2 * m + 1];
+      }
+      transpose_to_pieces<NPO>(my_lds, oa, lane);
+      transpose_to_pieces<NPO>(my_lds, ob, lane);
+      const size_t o0 = tile * kWave * NPO;
+#pragma unroll
+      for (int k = 0; k < NPO; ++k) {
+        const size_t q = o0 + (size_t)k * kWave + lane;
+        if (q < out_pieces) {
+          st16<kNtStore>(A2p + q, oa[k]);
+          st16<kNtStore>(B2p + q, ob[k]);
+        }
+      }
+    }
+    if constexpr (KS == 3) accumulate_octet<F>(f, acc, a, b);
+    else accumulate_run<F, KS>(f, acc, a, b);
+  };
+
+  // Tiles are not dealt out in advance.  The waves that share a SIMD are issued oldest-first: with a fixed share each,
+  // the older wave runs at the pace of its arithmetic, the younger one gets the memory bandwidth that is left and
+  // then finishes its share ALONE, at half the SIMD's issue rate (per-block stamps of an n = 28 first pass with
+  // two 256-thread blocks per CU: blocks 0..255 left the loop after 459 us, blocks 256..511 - the second block of
+  // every CU - after 707 us; profiles/r03_pass_block_stamps.txt).  So a block's waves draw their tiles from a
+  // counter in LDS (block b takes the tiles c * gridDim + b, c = 0, 1, ...): whoever is faster takes more, and the
+  // waves of a SIMD finish together.  An LDS atomic is ~100 cycles and not in the way of the global loads (a
+  // global counter per CU was tried: its returns queue behind the tile loads and cost more than the balance gave).
+  if (threadIdx.x == 0) lds_next = 0;
+  __syncthreads();
+  auto next_tile = [&]() -> size_t {
+    unsigned c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
+  };
+  if constexpr (kPrefetch) {
+    ull2 pa[NP], pb[NP];
+    size_t tile = next_tile();
+    if (tile < n_tiles) load_tile(tile, pa, pb);
+    while (tile < n_tiles) {
+      const size_t next = next_tile();
+      process_tile(tile, next, pa, pb);
+      tile = next;
+    }
+  } else {
+    for (size_t tile = next_tile(); tile < n_tiles; tile = next_tile()) {
+      ull2 pa[NP], pb[NP];
+      load_tile(tile, pa, pb);
+      process_tile(tile, 0, pa, pb);
+    }
+  }
+
+  u64 mine;
+  if constexpr (NS >= 9) {
+    __syncthreads();   // every wave is done with its transposes
+    mine = reduce_cells_lds<F, NS, BS>(f, acc, reinterpret_cast<typename F::Acc*>(lds_t), lds);
+  } else {
+    mine = reduce_cells<F, NS>(f, acc, lds);
+  }
+  finish_pass<F, NS, BS>(f, out, mine, &lds_flag);
+}
+
+}  // namespace sc
