@@ -32,7 +32,7 @@ cp $O/bench_${TAG}_$WL.json $O/profiles_$TAG/${TAG}_bench_$WL.json
 tail -3 $O/summary_${TAG}_$WL.log
 # config 3 (n = 26 on one GPU) and the shard of an 8-GPU run (n = 25): the same prover workload at those sizes
 for NV in 26 25; do
-  python3 $R/bench.py --num-vars $NV --cpu-num-vars 22 > $O/bench_${TAG}_prover$NV.json 2> $O/bench_${TAG}_prover$NV.err
+  python3 $R/bench.py --num-vars $NV --cpu-num-vars $NV > $O/bench_${TAG}_prover$NV.json 2> $O/bench_${TAG}_prover$NV.err
   rm -rf $O/prof_stats $O/prof_fetch $O/prof_write
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats -- python3 $R/bench.py --steps 10 --warmup 2 --cpu-num-vars 0 --num-vars $NV > $O/prof_stats_prover$NV.log 2>&1
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/prof_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --cpu-num-vars 0 --num-vars $NV > $O/prof_fetch_prover$NV.log 2>&1
