@@ -136,6 +136,7 @@ struct sc_ctx {
   u64* h_sums = nullptr;      // pinned mirror
   size_t partial_rows = 0;
   unsigned* d_ticket = nullptr;  // arrival counter of finish_pass (only ever grows)
+  bool fold_lds_allowed[4][2] = {};   // fold_kernel<KF, NT>: its dynamic LDS above 64 KiB has been requested
   unsigned ticket_base = 0;
   u64* h_mailbox = nullptr;   // pinned, device-mapped: sums + sequence word written by the kernel
   u64* d_mailbox = nullptr;   // device alias of h_mailbox
