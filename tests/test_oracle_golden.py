@@ -290,3 +290,47 @@ def test_gridk_matches_grid_and_round_evals():
                     for w in range(2):
                         h3 = F.sco_add(o.fp, h3, g3[(3 * u + v) * 3 + w])
                 assert h3 == F.sco_add(o.fp, g2[3 * u], g2[3 * u + 1])
+
+
+def test_gridk_four_and_five_rounds_vs_bigint():
+    """sco_g_gridk_sums for k = 4, 5 (the grids of the five-round passes; the gloo prover model of tests/test_dist_cpu.py
+    runs on them) against a direct big-integer evaluation of the definition:
+    S[c] = sum over blocks of 2^k entries of a~(c) b~(c), c_j in {0, 1, inf}, inf = leading coefficient t1 - t0,
+    variable j = index bit j, cell index = sum_j c_j 3^(k-1-j)"""
+    def grid(a, b, k, p):
+        cells = 3 ** k
+        S = [0] * cells
+
+        def extend(v):                       # v: 2^k values indexed by entry bits -> 3^k extension values
+            ext = {}
+            for c in range(cells):
+                digits = [(c // 3 ** (k - 1 - j)) % 3 for j in range(k)]
+                # sum over the entries with sign: inf on variable j -> (bit_j = 1) - (bit_j = 0); 0 / 1 -> that bit fixed
+                total = 0
+                for e in range(1 << k):
+                    sign = 1
+                    for j, d in enumerate(digits):
+                        bit = (e >> j) & 1
+                        if d == 2:
+                            sign *= 1 if bit else -1
+                        elif d != bit:
+                            sign = 0
+                            break
+                    total += sign * v[e]
+                ext[c] = total % p
+            return ext
+        for blk in range(len(a) >> k):
+            ea = extend([int(x) for x in a[blk << k:(blk + 1) << k]])
+            eb = extend([int(x) for x in b[blk << k:(blk + 1) << k]])
+            for c in range(cells):
+                S[c] = (S[c] + ea[c] * eb[c]) % p
+        return S
+    for p in (389, GOLD):
+        o = Oracle(p)
+        # the oracle's words are Montgomery words for GOLD: compare in the canonical domain through its own conversions
+        for k, n in ((4, 4), (4, 6), (5, 5), (5, 6)):
+            a, b = o.generate(31, n), o.generate(32, n)
+            got = [int(o.from_mont1(int(x))) for x in o.gridk_sums(a, b, k)]
+            ca = [int(o.from_mont1(int(x))) for x in a]
+            cb = [int(o.from_mont1(int(x))) for x in b]
+            assert got == grid(ca, cb, k, p), (p, k, n)
