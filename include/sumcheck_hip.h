@@ -73,6 +73,23 @@ int sc_interpolate_quadratic(const sc_field* f, const uint64_t e[3], uint64_t c[
 /* ---- context ------------------------------------------------------------------------- */
 
 int sc_ctx_create(const sc_field* f, int device, sc_ctx** out);
+/* ONE handle over n_devices GPUs of this process (sc_ctx_create(field, devices[], n_devices); 8e: "one
+ * process drives all 8 devices, so the host-supplied r_j needs no broadcast").  The reference's caller is one process
+ * holding one Prover (sum-check-protocol/src/lib.rs:73-117, mm_benchmark.rs:88-96); with this handle that unchanged caller
+ * uses every GPU of the node - no launcher, no communicator, no replicated verifier randomness.  n_devices: a power of two,
+ * 1..8; devices[] may repeat a device (tests on a one-GPU box).  Every table created on the handle (sc_table_upload /
+ * _generate / _clone / _fix_variables, sc_matmul_g_new, sc_prod2_*) is ONE table whose d-th contiguous 1/n_devices (top
+ * log2(n_devices) index bits = d) lives on devices[d]; sc_table_evaluate, sc_prod2_*, sc_prover_* and sc_prove work on the
+ * whole table.  In one process the exchange step of a pass needs no collective: every device's kernel leaves its own sums
+ * in its own pinned mailbox and the calling thread adds them (split limbs / residues mod p) before it answers the round;
+ * launches go out from one thread per device.  When the shards are down to their pending challenges the host folds the
+ * <= 32 entries per table and device it was handed and serves the rounds of the device bits itself: a sharded proof is one
+ * launch per device SHORTER than a single-device one.  Results are bit-identical to a one-device context.
+ * Not served (SC_ERR_UNSUPPORTED): sc_table_relabel, sc_table_restrict_to_line, sc_gkr_*, sc_tri_* (run those on an
+ * ordinary context), fix_variables across the device bits, and the sc_ctx_comm_* calls (the handle is its own communicator;
+ * sc_ctx_comm_rank reports rank 0 of 1 - its tables are whole tables; option "n_devices" counts the devices).  sc_table_device_ptr returns NULL; sc_ctx_stream, sc_ctx_kernel_time and
+ * sc_ctx_launch_log report the first device (one GPU's launches over its own shard). */
+int sc_ctx_create_multi(const sc_field* f, const int* devices, int n_devices, sc_ctx** out);
 int sc_ctx_destroy(sc_ctx* ctx);
 /* message of the last failing call on ctx (ctx == NULL: last failing sc_ctx_create) */
 const char* sc_last_error(const sc_ctx* ctx);
@@ -106,7 +123,8 @@ const char* sc_last_error(const sc_ctx* ctx);
  *   "time_kernels"     HIP-event timing of pass kernels (see sc_ctx_kernel_time)
  *   "nt_load_log" / "nt_store_log"  table log-size from which loads / stores are nontemporal */
 int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value);
-/* reads any option back; also read-only: "transport" (0 none, 1 RCCL, 2 host callbacks, 3 peer) and "comm_nranks"
+/* reads any option back; also read-only: "n_devices" (1, or the devices behind a multi-device handle), "transport" (0 none,
+ * 1 RCCL, 2 host callbacks, 3 peer, 4 local = a multi-device handle) and "comm_nranks"
  * = the number of ranks the data plane spans as the transport itself reports it (ncclCommCount for RCCL) */
 int sc_ctx_get_option(const sc_ctx* ctx, const char* key, int64_t* value);
 int sc_ctx_synchronize(sc_ctx* ctx);
@@ -237,7 +255,8 @@ int sc_prover_c1(const sc_prover* pr, uint64_t* out);
 /* Prover::num_vars (:114-116) */
 int sc_prover_num_vars(const sc_prover* pr, size_t* out);
 /* The schedule of a proof WITHOUT a device: the launches sc_prove would issue for a proof of num_vars variables on a
- * communicator of `world` ranks over `transport` (0 none, 1 RCCL, 2 host callbacks, 3 peer), computed by the same
+ * communicator of `world` ranks over `transport` (0 none, 1 RCCL, 2 host callbacks, 3 peer, 4 local: the devices of a
+ * multi-device handle), computed by the same
  * planner the engine runs at every pass (pure host logic: callable - and tested - on a machine without a GPU).
  * Steps come in launch order; `kf` challenges are folded and `ks` rounds served by each; `log_in` = log2 entries per
  * table on a rank; `sharded` = its sums are exchanged across the ranks.  SC_PLAN_GATHER is the all-gather of both
@@ -246,6 +265,7 @@ int sc_prover_num_vars(const sc_prover* pr, size_t* out);
 #define SC_PLAN_GRID_PASS 1  /* wgrid_pass_kernel: up to five rounds */
 #define SC_PLAN_RANK_PASS 2  /* rank_pass_kernel (peer transport): the rounds of the rank bits */
 #define SC_PLAN_GATHER 3     /* all-gather of the shards; the proof goes on replicated */
+#define SC_PLAN_HOST_TAIL 4  /* multi-device handle (transport 4): the host folds the shards' pending entries and serves the device-bit rounds; no launch */
 typedef struct sc_plan_options {   /* the context options the schedule depends on (sc_ctx_set_option names) */
   int32_t vars_per_pass, first_pass_vars, grid_pass, grid_log, grid_max_vars, grid_sharded, tail_log, use_mailbox;
 } sc_plan_options;

@@ -90,6 +90,9 @@ extern "C" {
     pub fn sc_interpolate_quadratic(f: *const sc_field, e: *const u64, c: *mut u64) -> c_int;
 
     pub fn sc_ctx_create(f: *const sc_field, device: c_int, out: *mut *mut sc_ctx) -> c_int;
+    /// one handle over `n_devices` GPUs of this process (a power of two, up to 8); every table made on it is split over
+    /// the devices by its top index bits and the prover / evaluate / fix_variables calls work on the whole table
+    pub fn sc_ctx_create_multi(f: *const sc_field, devices: *const c_int, n_devices: c_int, out: *mut *mut sc_ctx) -> c_int;
     pub fn sc_ctx_destroy(ctx: *mut sc_ctx) -> c_int;
     pub fn sc_last_error(ctx: *const sc_ctx) -> *const c_char;
     pub fn sc_ctx_set_option(ctx: *mut sc_ctx, key: *const c_char, value: i64) -> c_int;

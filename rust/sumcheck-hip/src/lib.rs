@@ -68,6 +68,21 @@ impl<T: MontConfig<1>> Context<T> {
         }
         Self { inner: Rc::new(CtxInner(h)), _t: PhantomData }
     }
+    /// ONE handle over several GPUs of this process (`sc_ctx_create_multi`): `devices.len()` a power of two up to 8.
+    /// Everything built on it - `DeviceMle`, `GpuG::new`, `Prover::new(g)` of the unchanged `sum-check-protocol`
+    /// callers - works on tables that are split over the devices by their top index bits; the round sums of the
+    /// shards are added by the calling thread, so the verifier's `r_j` is drawn once and needs no broadcast
+    /// (SURVEY.md section 8e).  Bit-identical to `Context::new`.
+    pub fn new_multi(devices: &[i32]) -> Self {
+        let f = field_of::<T>();
+        let mut h = ptr::null_mut();
+        let rc = unsafe { sys::sc_ctx_create_multi(&f, devices.as_ptr(), devices.len() as i32, &mut h) };
+        if rc != sys::SC_OK {
+            let msg = unsafe { CStr::from_ptr(sys::sc_last_error(ptr::null())) };
+            panic!("sc_ctx_create_multi failed ({rc}): {}", msg.to_string_lossy());
+        }
+        Self { inner: Rc::new(CtxInner(h)), _t: PhantomData }
+    }
     fn raw(&self) -> *mut sys::sc_ctx {
         self.inner.0
     }
@@ -650,6 +665,13 @@ impl<T: MontConfig<1>> Context<T> {
     /// Peer transport, step 2: map the peers, say hello, self-test.  `Err` (the library's message) if this node's
     /// peer memory does not behave as the kernels need - the caller then joins RCCL instead, on every rank.
     pub fn comm_peer_connect(&self, handles: &[[u8; 64]]) -> Result<(), String> {
+        let (mut rank, mut world) = (0i32, 0i32);
+        let rc = unsafe { sys::sc_ctx_comm_rank(self.raw(), &mut rank, &mut world) };
+        self.check(rc, "sc_ctx_comm_rank");
+        if handles.len() != world as usize {
+            // the C side reads 64 * world bytes
+            return Err(format!("comm_peer_connect: expected {} handles, got {}", world, handles.len()));
+        }
         let flat: Vec<u8> = handles.iter().flat_map(|h| h.iter().copied()).collect();
         let rc = unsafe { sys::sc_ctx_comm_peer_connect(self.raw(), flat.as_ptr()) };
         if rc == sys::SC_OK {

@@ -1,0 +1,268 @@
+"""ONE handle, N devices, ONE process (sc_ctx_create_multi; the reference's caller is one process holding
+one Prover, sum-check-protocol/src/lib.rs:73-117).  Every test drives the handle through the same C entry points and the
+same Python mirror as a one-device context - Prover::new / round, sc_prove, evaluate, fix_variables, G::new - and compares
+bit for bit with the CPU oracle, or (at BASELINE's n = 28) with the one-device transcript.  This pool's boxes have one GPU:
+devices[] names device 0 N times (N streams, N launcher threads, N pinned mailboxes - everything but the xGMI hop of
+G::new's block exchange); on a box that shows more devices the same tests spread over them."""
+import numpy as np
+import pytest
+
+from conftest import load_package
+from util import GOLD, TOY_MODULI, challenges, oracle, pid, pyref
+from test_gpu_parity import run_python_protocol
+
+pytestmark = pytest.mark.gpu
+
+
+def device_list(n):
+    import torch
+    have = max(torch.cuda.device_count(), 1)
+    return [d % have for d in range(n)]
+
+
+def multi_ctx(pkg, p, n_dev, **opts):
+    ctx = pkg.Context(pkg.Field(p), devices=device_list(n_dev))
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    return ctx
+
+
+def tables(pkg, ctx, n):
+    a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
+    b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, n)
+    return a, b
+
+
+@pytest.mark.parametrize("n_dev", [1, 2, 4, 8])
+@pytest.mark.parametrize("p", [GOLD] + TOY_MODULI, ids=pid)
+def test_multi_transcripts_match_oracle(p, n_dev):
+    """sc_prove and the round-by-round Prover behind ONE handle == the oracle, from one entry per device (the host serves
+    every round) up to n = 22; c_1, every round triple, the final evaluation, the tables themselves"""
+    pkg = load_package()
+    o = oracle(p)
+    g = n_dev.bit_length() - 1
+    ctx = multi_ctx(pkg, p, n_dev)
+    assert ctx.get_option("n_devices") == n_dev and ctx.get_option("transport") == 4 and ctx.rank_world() == (0, 1)
+    for n in sorted({g, g + 1, g + 2, g + 3, g + 5, g + 6, 9, 12, 13, 16, 19, 22} - set(range(0, max(g, 1)))):
+        oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+        ch = challenges(o, n)
+        ref = o.prove(oa, ob, ch)
+        a, b = tables(pkg, ctx, n)
+        if n <= 16:
+            assert np.array_equal(a.to_evaluations(), oa) and np.array_equal(b.to_evaluations(), ob)
+        G = pkg.matrix_multiplication.G(a, b)
+        assert G.num_vars() == n
+        c1, evals, chn = pkg.matrix_multiplication.prove(ctx, G, pyref.SEED_R)
+        assert c1 == ref["c_1"] and np.array_equal(chn, ch), (n, n_dev)
+        assert np.array_equal(evals, ref["evals"]), (n, n_dev)
+        assert G.evaluate([int(x) for x in ch]) == ref["final_eval"], (n, n_dev)
+        assert G.hypercube_sum() == ref["c_1"]
+        if n <= 13:
+            # the reference's own loop (matrix-multiplication/src/lib.rs:354-370): Prover::new(g.clone()), Verifier, rng draws
+            c_1, polys, final = run_python_protocol(pkg, ctx, G, [int(x) for x in ch])
+            assert c_1 == ref["c_1"] and (final is True or n < 2)
+            for j, poly in enumerate(polys):
+                want = o.interpolate(ref["evals"][j])
+                dense = [0, 0, 0]
+                for d, c in poly.coeffs:
+                    dense[d] = c
+                assert dense == [int(x) for x in want], (n, j)
+    ctx.close()
+
+
+@pytest.mark.parametrize("opts", [{"vars_per_pass": 1}, {"grid_pass": 0}, {"grid_sharded": 0}, {"first_pass_vars": 2}, {"grid_max_vars": 3},
+                                  {"grid_log": 6}, {"first_pass_vars": 1, "grid_max_vars": 2}, {"vars_per_pass": 1, "grid_pass": 0}],
+                         ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()))
+def test_multi_every_schedule_matches_oracle(opts):
+    """the option mixes: passes that end on the pinned tail buffer at every size, shards that go on from it (ping-pong of its
+    two halves), host tails that fold 1..5 pending challenges - and the launches of device 0 are the plan's"""
+    pkg = load_package()
+    o = oracle(GOLD)
+    for n_dev in (2, 8):
+        g = n_dev.bit_length() - 1
+        ctx = multi_ctx(pkg, GOLD, n_dev, **opts)
+        for n in (g, g + 1, g + 2, g + 4, g + 7, 11, 14, 17):
+            oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+            ch = challenges(o, n)
+            ref = o.prove(oa, ob, ch)
+            a, b = tables(pkg, ctx, n)
+            G = pkg.matrix_multiplication.G(a, b)
+            ctx.set_option("time_kernels", 1)
+            ctx.launch_log(reset=True)
+            c1, evals, _ = pkg.matrix_multiplication.prove(ctx, G, pyref.SEED_R)
+            log = [(r["kind"], r["kf"], r["ks"], r["log_in"]) for r in ctx.launch_log(reset=True)]
+            ctx.set_option("time_kernels", 0)
+            assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]), (n, n_dev, opts)
+            plan = pkg.schedule.plan_proof(n, n_dev, "local", **opts)
+            assert plan[-1]["action"] == "host_tail" and plan[-1]["ks"] == g
+            assert log == [(s["action"], s["kf"], s["ks"], s["log_in"]) for s in plan[:-1]], (n, n_dev, opts)
+        ctx.close()
+
+
+def test_multi_n28_equals_one_device():
+    """BASELINE config 4's shape behind one handle: n = 28 over 8 shards of 2^25 entries == the one-device transcript (and
+    the verifier's identities hold); six launches per device, the host serves the last three rounds"""
+    pkg = load_package()
+    from util import verifier_identities
+    n = 28
+    one = pkg.Context(pkg.Field(GOLD))
+    a, b = tables(pkg, one, n)
+    G1 = pkg.matrix_multiplication.G(a, b)
+    c1, evals, ch = pkg.matrix_multiplication.prove(one, G1, pyref.SEED_R)
+    final = G1.evaluate([int(x) for x in ch])
+    assert verifier_identities(one.field, c1, evals, ch, final) is None
+    del G1, a, b
+    one.close()
+    for n_dev in (8, 2):
+        ctx = multi_ctx(pkg, GOLD, n_dev)
+        a, b = tables(pkg, ctx, n)
+        G = pkg.matrix_multiplication.G(a, b)
+        ctx.set_option("time_kernels", 1)
+        ctx.launch_log(reset=True)
+        c8, ev8, ch8 = pkg.matrix_multiplication.prove(ctx, G, pyref.SEED_R)
+        log = ctx.launch_log(reset=True)
+        ctx.set_option("time_kernels", 0)
+        assert c8 == c1 and np.array_equal(ev8, evals) and np.array_equal(ch8, ch), n_dev
+        assert G.evaluate([int(x) for x in ch]) == final
+        if n_dev == 8:
+            assert [(r["kind"], r["kf"], r["ks"], r["log_in"]) for r in log] == [
+                ("pass", 0, 3, 25), ("pass", 3, 2, 25), ("grid_pass", 2, 5, 22), ("grid_pass", 5, 5, 20), ("grid_pass", 5, 5, 15), ("grid_pass", 5, 5, 10)]
+        del G, a, b
+        ctx.close()
+
+
+@pytest.mark.parametrize("n_dev", [2, 8])
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+def test_multi_table_calls_match_oracle(p, n_dev):
+    """upload / download / clone, evaluate in both orders (vsbw_/cti_multilinear_from_evaluations are the BE one), fix_variables
+    inside the shards, the product calls (G::to_evaluations, to_univariate, fix + to_univariate fused) == the oracle"""
+    pkg = load_package()
+    o = oracle(p)
+    g = n_dev.bit_length() - 1
+    ctx = multi_ctx(pkg, p, n_dev)
+    rng = np.random.default_rng(5)
+    for n in (g, g + 1, g + 3, 9, 12, 15):
+        ta = o.to_mont(rng.integers(0, p, size=1 << n, dtype=np.uint64))
+        tb = o.to_mont(rng.integers(0, p, size=1 << n, dtype=np.uint64))
+        a = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, ta)
+        b = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, tb)
+        assert np.array_equal(a.to_evaluations(), ta) and np.array_equal(a.clone().to_evaluations(), ta)
+        pt = o.to_mont(rng.integers(0, p, size=n, dtype=np.uint64))
+        want = o.evaluate(ta, pt)
+        assert a.evaluate(pt) == want, (n, "LE")
+        assert a.evaluate(pt[::-1].copy(), pkg.ORDER_BE) == want == o.vsbw(ta, pt[::-1].copy()), (n, "BE")
+        G = pkg.matrix_multiplication.G(a, b)
+        assert np.array_equal(G.to_evaluations(), o.to_evaluations(ta, tb))
+        assert G.evaluate(pt) == o.g_evaluate(ta, tb, pt)
+        if n - g >= 1:
+            assert G.round_evals() == [int(x) for x in o.round_evals(ta, tb)]
+        for k in range(0, n - g + 1):
+            if k in (0, 1, 2, 3, 4, 5, 8, n - g):
+                got = a.fix_variables(pt[:k])
+                assert np.array_equal(got.to_evaluations(), o.fix_variables(ta, pt[:k])), (n, k)
+        if n - g >= 2:
+            g2, poly = G.fold_and_univariate(pt[0])
+            fa, fb = o.fix_variables(ta, pt[:1]), o.fix_variables(tb, pt[:1])
+            assert np.array_equal(g2.f_a.to_evaluations(), fa) and np.array_equal(g2.f_b.to_evaluations(), fb)
+            want_c = [int(x) for x in o.interpolate(o.round_evals(fa, fb))]
+            dense = [0, 0, 0]
+            for d, c in poly.coeffs:
+                dense[d] = c
+            assert dense == want_c
+        if n - g >= 1 and n_dev > 1:
+            with pytest.raises(pkg.SumcheckHipError) as ei:
+                a.fix_variables(pt[:n - g + 1])       # would cross the device shards
+            assert ei.value.code == 6
+    ctx.close()
+
+
+@pytest.mark.parametrize("n_dev", [1, 2, 8])
+def test_multi_g_new_matches_oracle(n_dev):
+    """G::new (matrix-multiplication/src/lib.rs:77-92) on row-block shards: f_b local, f_a through the column-block exchange
+    between the devices; then the proof on (f_a, f_b) - BASELINE config 5's shape in one process"""
+    pkg = load_package()
+    o = oracle(GOLD)
+    ctx = multi_ctx(pkg, GOLD, n_dev)
+    rng = np.random.default_rng(11)
+    for n in (4, 6, 9):
+        A = o.to_mont(rng.integers(0, GOLD, size=1 << (2 * n), dtype=np.uint64))
+        B = o.to_mont(rng.integers(0, GOLD, size=1 << (2 * n), dtype=np.uint64))
+        point = o.to_mont(rng.integers(0, GOLD, size=2 * n, dtype=np.uint64))
+        G = pkg.matrix_multiplication.G.new(ctx, n, A, B, point)
+        fa, fb = o.g_new(n, A, B, point)
+        assert np.array_equal(G.f_a.to_evaluations(), fa) and np.array_equal(G.f_b.to_evaluations(), fb), n
+        ch = challenges(o, n)
+        ref = o.prove(fa, fb, ch)
+        c1, evals, _ = pkg.matrix_multiplication.prove(ctx, G, pyref.SEED_R)
+        assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+    ctx.close()
+
+
+def test_multi_argument_checks_and_unsupported_calls():
+    pkg = load_package()
+    lib = pkg._lib.load()
+    F = pkg.Field(GOLD)
+    for bad in ([0, 0, 0], [0] * 16, []):
+        with pytest.raises(pkg.SumcheckHipError) as ei:
+            pkg.Context(F, devices=bad)
+        assert ei.value.code == 1
+    with pytest.raises(pkg.SumcheckHipError):
+        pkg.Context(F, devices=[0, 9999])
+    ctx = multi_ctx(pkg, GOLD, 4)
+    one = pkg.Context(F)
+    a, b = tables(pkg, ctx, 10)
+    t1 = pkg.DenseMultilinearExtension.generate(one, pyref.SEED_A, 10)
+    with pytest.raises(pkg.SumcheckHipError) as ei:
+        pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, 1)      # fewer entries than devices
+    assert ei.value.code == 1
+    # tables do not cross between a handle and a one-device context
+    with pytest.raises(pkg.SumcheckHipError):
+        pkg.matrix_multiplication.prove(one, pkg.matrix_multiplication.G(a, b), pyref.SEED_R)
+    with pytest.raises(pkg.SumcheckHipError):
+        pkg.matrix_multiplication.prove(ctx, pkg.matrix_multiplication.G(t1, t1), pyref.SEED_R)
+    for call in (lambda: a.relabel(0, 5, 5), lambda: ctx.comm_peer_export(0, 1), lambda: ctx.set_option("use_mailbox", 0),
+                 lambda: ctx.set_option("peer_spin_ms", 5)):
+        with pytest.raises(pkg.SumcheckHipError) as ei:
+            call()
+        assert ei.value.code in (5, 6), ei.value
+    with pytest.raises(pkg.SumcheckHipError) as ei:
+        ctx.set_option("vars_per_pass", 7)
+    assert ei.value.code == 1
+    # the round order is enforced like on a one-device prover, and a prover outlives nothing it borrowed
+    pr = pkg.matrix_multiplication.G(a, b).native_prover()
+    with pytest.raises(pkg.SumcheckHipError) as ei:
+        pr.round_evals(1, 3)
+    assert ei.value.code == 5
+    del pr, a, b, t1
+    one.close()
+    ctx.close()
+
+
+def test_multi_interleaved_provers_and_reuse():
+    """two provers on one handle, rounds interleaved, with table calls in between: each keeps its own shards and tail-buffer
+    state... and a handle that sat idle (its launcher threads parked) picks up again"""
+    import time
+    pkg = load_package()
+    o = oracle(GOLD)
+    ctx = multi_ctx(pkg, GOLD, 8)
+    n1, n2 = 13, 9
+    refs, provers, chs = [], [], []
+    for n, seed in ((n1, pyref.SEED_A), (n2, pyref.SEED_B)):
+        oa, ob = o.generate(seed, n), o.generate(seed + 17, n)
+        ch = challenges(o, n)
+        refs.append(o.prove(oa, ob, ch))
+        chs.append(ch)
+        a = pkg.DenseMultilinearExtension.generate(ctx, seed, n)
+        b = pkg.DenseMultilinearExtension.generate(ctx, seed + 17, n)
+        provers.append((pkg.matrix_multiplication.G(a, b).native_prover(), a, b))
+    time.sleep(0.05)      # long enough for the launcher threads to park
+    for j in range(max(n1, n2)):
+        for k, n in enumerate((n1, n2)):
+            if j < n:
+                e = provers[k][0].round_evals(int(chs[k][j - 1]) if j else 1, j)
+                assert e == [int(x) for x in refs[k]["evals"][j]], (k, j)
+        if j % 3 == 0:
+            assert provers[0][1].evaluate([int(x) for x in chs[0]]) == o.evaluate(o.generate(pyref.SEED_A, n1), chs[0])
+    assert provers[0][0].c1() == refs[0]["c_1"] and provers[1][0].c1() == refs[1]["c_1"]
+    del provers
+    ctx.close()

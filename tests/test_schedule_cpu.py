@@ -24,7 +24,7 @@ def check(steps, n, world, transport, opts):
     g = world.bit_length() - 1
     served = sum(s["ks"] for s in steps)
     assert served == n, (served, n)
-    cur_log, kf, sharded = n - g, 0, transport != "none"
+    cur_log, kf, sharded = n - g, 0, transport != "none" and not (transport == "local" and world == 1)
     gmax = opts.get("grid_max_vars", 5)
     for s in steps:
         assert s["log_in"] == cur_log and s["sharded"] == (sharded if s["action"] != "gather" else True), (s, cur_log, sharded)
@@ -34,7 +34,13 @@ def check(steps, n, world, transport, opts):
             sharded = False
             continue
         assert s["kf"] == kf, (s, kf)
-        if s["action"] == "rank_pass":
+        if transport == "local" and world > 1:
+            # the devices of one multi-device handle: never a gather or a rank pass; the host finishes the device bits
+            assert s["action"] in ("pass", "grid_pass", "host_tail")
+        if s["action"] == "host_tail":
+            assert transport == "local" and sharded and cur_log == kf and s["ks"] == g and kf <= 5 and s is steps[-1]
+            cur_log, sharded = 0, False
+        elif s["action"] == "rank_pass":
             assert transport == "peer" and sharded and cur_log == kf and s["ks"] == g and 1 <= g <= 3 and kf <= 5
             cur_log, sharded = g, False
         elif s["action"] == "pass":
@@ -53,7 +59,8 @@ def check(steps, n, world, transport, opts):
 
 @pytest.mark.parametrize("opts", OPTION_SETS, ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()) or "default")
 def test_plan_invariants(plan, opts):
-    for world, transport in [(1, "none"), (1, "peer"), (1, "rccl"), (2, "peer"), (2, "rccl"), (4, "host"), (8, "peer"), (8, "rccl"), (8, "host")]:
+    for world, transport in [(1, "none"), (1, "peer"), (1, "rccl"), (2, "peer"), (2, "rccl"), (4, "host"), (8, "peer"), (8, "rccl"), (8, "host"),
+                             (1, "local"), (2, "local"), (4, "local"), (8, "local")]:
         g = world.bit_length() - 1
         for n in range(max(g, 1), 41):
             steps = plan(n, world, transport, **opts)     # none of these combinations may be refused
@@ -75,6 +82,12 @@ def test_known_schedules(plan):
     # the same over RCCL: the shard is gathered when it is down to its pending challenges, the rank bits are one more pass
     r8 = plan(28, 8, "rccl")
     assert sig(r8)[:6] == sig(s8)[:6] and sig(r8)[6:] == [("gather", 0, 0, 5), ("grid_pass", 5, 3, 8)]
+    # ONE process over 8 devices (sc_ctx_create_multi): the same six launches per device, then the host folds the 32 entries
+    # per table and device it was handed and serves the three device-bit rounds - no seventh launch, no gather
+    l8 = plan(28, 8, "local")
+    assert sig(l8)[:6] == sig(s8)[:6] and sig(l8)[6:] == [("host_tail", 5, 3, 5)]
+    assert sig(plan(3, 8, "local")) == [("host_tail", 0, 3, 0)]      # one entry per device: the host serves every round
+    assert sig(plan(28, 1, "local")) == sig(plan(28))                  # one device behind the handle: the plain schedule
     # two rounds per pass with a gather at 2^16-entry shards (grid_sharded 0): round 1's sharded schedule
     t8 = plan(28, 8, "rccl", grid_sharded=0)
     assert [s["action"] for s in t8].count("gather") == 1 and t8[[s["action"] for s in t8].index("gather")]["log_in"] == 16

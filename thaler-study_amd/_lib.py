@@ -35,8 +35,8 @@ class ScPlanStep(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in ("action", "kf", "ks", "log_in", "sharded")]
 
 
-PLAN_ACTIONS = {0: "pass", 1: "grid_pass", 2: "rank_pass", 3: "gather"}
-TRANSPORTS = {"none": 0, "rccl": 1, "host": 2, "peer": 3}
+PLAN_ACTIONS = {0: "pass", 1: "grid_pass", 2: "rank_pass", 3: "gather", 4: "host_tail"}
+TRANSPORTS = {"none": 0, "rccl": 1, "host": 2, "peer": 3, "local": 4}
 
 
 class ScLaunchRecord(ctypes.Structure):
@@ -57,6 +57,7 @@ SIGNATURES = {
     "sc_field_from_mont": (u64, [ctypes.POINTER(ScField), u64]),
     "sc_interpolate_quadratic": (ctypes.c_int, [ctypes.POINTER(ScField), u64p, u64p]),
     "sc_ctx_create": (ctypes.c_int, [ctypes.POINTER(ScField), ctypes.c_int, ctypes.POINTER(voidp)]),
+    "sc_ctx_create_multi": (ctypes.c_int, [ctypes.POINTER(ScField), ctypes.POINTER(ctypes.c_int), ctypes.c_int, ctypes.POINTER(voidp)]),
     "sc_ctx_destroy": (ctypes.c_int, [voidp]),
     "sc_last_error": (ctypes.c_char_p, [voidp]),
     "sc_ctx_set_option": (ctypes.c_int, [voidp, ctypes.c_char_p, ctypes.c_int64]),

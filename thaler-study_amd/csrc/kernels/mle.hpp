@@ -15,7 +15,7 @@ constexpr int kFoldGrab = 4;       // consecutive tiles per draw from the block'
 constexpr size_t fold_kernel_lds_bytes(int kf, int threads) { return (size_t)(threads / kWave) * kWave * (size_t)(1 << kf) * sizeof(ull2); }
 template <class F, int KF, bool NT>
 __global__ void __launch_bounds__(kFoldBlock)
-fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, FoldW fw, size_t n_units) {
+fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, FoldW fw, size_t n_units, int grab) {
   constexpr int IN = 2 << KF, NP = IN / 2;
   extern __shared__ ull2 fold_lds[];   // [waves of the block][kWave * NP]: sized by the launch (fold_kernel_lds_bytes)
   __shared__ unsigned lds_next;
@@ -26,14 +26,17 @@ fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, FoldW fw, size
   const size_t n_tiles = (n_units + kWave - 1) / kWave, in_pieces = n_units * NP;
   if (threadIdx.x == 0) lds_next = 0;
   __syncthreads();
-  // the waves of a block draw runs of kFoldGrab tiles from a counter in LDS (evaluate_kernel; block b owns the runs c * grid + b)
+  // the waves of a block draw runs of `grab` tiles from a counter in LDS (evaluate_kernel; block b owns the runs c * grid + b).
+  // grab = kFoldGrab for the one-block-per-CU launches of large tables; 1 for the four-wave blocks of small ones, whose grid
+  // is sized for one tile per wave (with runs of four there, one wave of each block folded its four tiles serially while
+  // the other three drew a run past the end and left: a quarter of the memory-level parallelism - ADVICE r03)
   auto next_run = [&]() -> size_t {
     unsigned c = 0;
     if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    return ((size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x) * kFoldGrab;
+    return ((size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x) * (size_t)grab;
   };
   for (size_t run = next_run(); run < n_tiles; run = next_run())
-  for (size_t tile = run; tile < run + kFoldGrab && tile < n_tiles; ++tile) {
+  for (size_t tile = run; tile < run + (size_t)grab && tile < n_tiles; ++tile) {
     ull2 pv[NP];
 #pragma unroll
     for (int k = 0; k < NP; ++k) {

@@ -251,6 +251,9 @@ __device__ __forceinline__ void finish_pass(const F& f, const PassOut& o, u64 my
     exchange_and_publish<NS>(o, xl);
     return;
   }
+  // the NS < 9 branch publishes from lane 0 of EVERY wave and a workgroup barrier does not drain vmcnt: each wave waits
+  // for its own mailbox stores here, so thread 0's release of the sequence word cannot pass a late value of waves 1..3
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   publish_seq(o);
 }

@@ -20,7 +20,11 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <thread>
@@ -82,7 +86,12 @@ bool load_rccl(std::string* why) {
   return true;
 }
 
-enum class Transport { kNone, kRccl, kHost, kPeer };
+// kLocal: the shards are the per-device contexts of ONE multi-device handle of this process (sc_ctx_create_multi): a sharded
+// launch leaves this shard's own sums in its own mailbox and the handle's host thread adds them - no collective at all
+enum class Transport { kNone, kRccl, kHost, kPeer, kLocal };
+constexpr int kMaxSubs = 8;          // devices behind one multi-device handle (one node)
+constexpr int kTailEntries = 32;     // a pass of such a handle whose outputs have <= this many entries per table writes them to
+                                     // pinned host memory (sc_ctx::h_tail): the host finishes the proof from them
 constexpr int kWgMaxBlocks = 1024;   // blocks of a wgrid_pass_kernel launch at most: 32 groups of 32
 
 }  // namespace
@@ -175,6 +184,16 @@ struct sc_ctx {
   int dbg_delay_ms = 0;
   int dbg_skip_tag = 0;
 
+  // multi-device handle (sc_ctx_create_multi, engine/multi.inc).  The handle itself owns no device state: `subs` are ordinary
+  // contexts, one per entry of devices[], shard d = rank d of world subs.size() on Transport::kLocal; `mrt` holds one
+  // launcher thread per further device.  In a sub, `parent` points back and h_tail / d_tail are its pinned tail buffers:
+  // [parity][table][kTailEntries] words
+  std::vector<sc_ctx*> subs;
+  sc_ctx* parent = nullptr;
+  struct MultiRuntime* mrt = nullptr;
+  u64* h_tail = nullptr;
+  u64* d_tail = nullptr;
+
   // kernel timing
   // pass-kernel timing (option "time_kernels"): a ring of event pairs, read back only when the
   // ring is full or the totals are queried, so that timing adds two event records per launch
@@ -192,6 +211,8 @@ struct sc_ctx {
 struct sc_table {
   u64* d = nullptr;
   size_t len = 0;
+  // a table of a multi-device handle: parts[d] = the d-th contiguous shard, a table of subs[d]; d stays null, len = whole length
+  std::vector<sc_table*> parts;
 };
 
 namespace {
@@ -225,6 +246,14 @@ int fail(const sc_ctx* ctx, int code, const char* fmt, ...) {
   do {                          \
     int rc_ = (expr);           \
     if (rc_ != SC_OK) return rc_; \
+  } while (0)
+
+// entry points a multi-device handle does not serve (the callers' own polynomial types, SURVEY 8f: they run on an ordinary
+// context of one device)
+#define SC_NO_MULTI(ctx, what)                                                                                        \
+  do {                                                                                                                \
+    if ((ctx) && is_multi(ctx))                                                                                       \
+      return fail(ctx, SC_ERR_UNSUPPORTED, "%s: not available on a multi-device handle (use a context of one device)", what); \
   } while (0)
 
 inline bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
@@ -313,14 +342,19 @@ int new_table(sc_ctx* ctx, size_t len, sc_table** out) {
   return SC_OK;
 }
 
-int set_device(sc_ctx* ctx) {
+// connecting: the call is the peer connect itself (the only thing an exported, not yet connected context may do)
+int set_device(sc_ctx* ctx, bool connecting = false) {
   if (ctx->poisoned)
     return fail(ctx, SC_ERR_STATE, "context is unusable after an earlier HIP failure (%s); destroy it", ctx->err.c_str());
+  if (ctx->world > 1 && ctx->transport == Transport::kNone && !connecting)
+    return fail(ctx, SC_ERR_STATE, "rank %d of %d has exported its peer region but is not connected (sc_ctx_comm_peer_connect "
+                "failed or was not called): connect, or destroy the context", ctx->rank, ctx->world);
   SC_HIP(ctx, hipSetDevice(ctx->device));
   return SC_OK;
 }
 
 inline bool is_sharded(const sc_ctx* ctx) { return ctx->transport != Transport::kNone; }
+inline bool is_multi(const sc_ctx* ctx) { return !ctx->subs.empty(); }
 
 int grid_for(const sc_ctx* ctx, size_t n_threads_needed) {
   size_t g = (n_threads_needed + sc::kBlock - 1) / sc::kBlock;
@@ -340,9 +374,29 @@ int grid_for_wide(const sc_ctx* ctx, size_t n_threads_needed) {
 
 }  // namespace
 
+// the same calls on a multi-device handle (engine/abi_multi.inc); the single-device entry points dispatch to them
+static int multi_destroy(sc_ctx* m);
+static int multi_set_option(sc_ctx* m, const char* key, int64_t value);
+static int multi_synchronize(sc_ctx* m);
+static int multi_table_upload(sc_ctx* m, const uint64_t* host, size_t len, sc_table** out);
+static int multi_table_generate(sc_ctx* m, uint64_t seed, uint64_t start, size_t len, sc_table** out);
+static int multi_table_clone(sc_ctx* m, const sc_table* t, sc_table** out);
+static int multi_table_download(sc_ctx* m, const sc_table* t, uint64_t* host, size_t len);
+static int multi_table_free(sc_ctx* m, sc_table* t);
+static int multi_table_fix_variables(sc_ctx* m, const sc_table* in, const uint64_t* r, size_t k, int order, sc_table** out);
+static int multi_table_evaluate(sc_ctx* m, const sc_table* t, const uint64_t* r, size_t n, int order, uint64_t* out);
+static int multi_matmul_g_new(sc_ctx* m, const sc_table* A, const sc_table* B, size_t n, const uint64_t* point, sc_table** a_out,
+                              sc_table** b_out);
+static int multi_prod2_to_evaluations(sc_ctx* m, const sc_table* a, const sc_table* b, sc_table** out);
+static int multi_prod2_round_sums(sc_ctx* m, const sc_table* a, const sc_table* b, uint64_t out_e[3]);
+static int multi_prod2_sum(sc_ctx* m, const sc_table* a, const sc_table* b, uint64_t* out_c1);
+static int multi_prod2_fold_and_sums(sc_ctx* m, const sc_table* a, const sc_table* b, const uint64_t r[1], sc_table** a_out,
+                                     sc_table** b_out, uint64_t out_e[3]);
+
 // The rest of the engine, in the order it builds on itself (one translation unit; the parts are not stand-alone headers)
 #include "engine/launch.inc"
 #include "engine/collectives.inc"
+#include "engine/multi.inc"
 #include "engine/table_helpers.inc"
 #include "engine/abi_context.inc"
 #include "engine/abi_sharding.inc"
@@ -351,3 +405,4 @@ int grid_for_wide(const sc_ctx* ctx, size_t n_threads_needed) {
 #include "engine/abi_gkr.inc"
 #include "engine/abi_triangle.inc"
 #include "engine/abi_restrict.inc"
+#include "engine/abi_multi.inc"

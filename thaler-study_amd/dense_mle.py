@@ -23,13 +23,21 @@ def _words(xs):
 
 
 class Context:
-    """one GPU, one stream, one field (sc_ctx).  Not thread-safe, like `&mut Prover`."""
+    """one GPU, one stream, one field (sc_ctx).  Not thread-safe, like `&mut Prover`.
 
-    def __init__(self, field, device=0):
+    devices=[d0, d1, ...] (a power of two of them, up to 8; entries may repeat): ONE handle over several GPUs of this
+    process (sc_ctx_create_multi) - every table made on it is one table split over the devices by its top index bits,
+    and Prover / evaluate / fix_variables work on the whole table with no launcher and no communicator."""
+
+    def __init__(self, field, device=0, devices=None):
         self.lib = _lib.load()
         self.field = field if isinstance(field, Field) else Field(field)
         h = voidp()
-        rc = self.lib.sc_ctx_create(self.field.ref(), device, ctypes.byref(h))
+        if devices is not None:
+            devs = (ctypes.c_int * len(devices))(*[int(d) for d in devices])
+            rc = self.lib.sc_ctx_create_multi(self.field.ref(), devs, len(devices), ctypes.byref(h))
+        else:
+            rc = self.lib.sc_ctx_create(self.field.ref(), device, ctypes.byref(h))
         if rc != SC_OK:
             raise SumcheckHipError(rc, self.lib.sc_last_error(None).decode())
         self.h = h
@@ -116,12 +124,17 @@ class Context:
 
     def comm_peer_connect(self, handles):
         """handles: the world 64-byte handles in rank order (other processes' regions are mapped over IPC)"""
+        world = self.rank_world()[1]
+        if len(handles) != world or any(len(bytes(h)) != 64 for h in handles):   # the C side reads 64 * world bytes
+            raise ValueError("comm_peer_connect: expected %d handles of 64 bytes, got %d" % (world, len(handles)))
         blob = b"".join(bytes(h) for h in handles)
         buf = (ctypes.c_uint8 * len(blob)).from_buffer_copy(blob)
         self.check(self.lib.sc_ctx_comm_peer_connect(self.h, buf))
 
     def comm_peer_connect_local(self, peers):
         """peers: the world Context objects of this process, in rank order"""
+        if len(peers) != self.rank_world()[1]:   # the C side reads world pointers
+            raise ValueError("comm_peer_connect_local: expected %d contexts, got %d" % (self.rank_world()[1], len(peers)))
         arr = (voidp * len(peers))(*[p.h for p in peers])
         self.check(self.lib.sc_ctx_comm_peer_connect_local(self.h, arr))
 
