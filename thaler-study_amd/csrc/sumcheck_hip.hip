@@ -92,6 +92,8 @@ enum class Transport { kNone, kRccl, kHost, kPeer, kLocal };
 constexpr int kMaxSubs = 8;          // devices behind one multi-device handle (one node)
 constexpr int kTailEntries = 32;     // a pass of such a handle whose outputs have <= this many entries per table writes them to
                                      // pinned host memory (sc_ctx::h_tail): the host finishes the proof from them
+constexpr int kTailSlots = 64;       // provers of one handle that can hold a tail slot at a time (the others use pool memory)
+constexpr size_t kTailSlotWords = 4 * (size_t)kTailEntries;   // [parity][table][kTailEntries]
 constexpr int kWgMaxBlocks = 1024;   // blocks of a wgrid_pass_kernel launch at most: 32 groups of 32
 
 }  // namespace
@@ -183,16 +185,19 @@ struct sc_ctx {
   // makes the next sharded launch skip a tag (a rank that is out of step with its peers)
   int dbg_delay_ms = 0;
   int dbg_skip_tag = 0;
+  int dbg_fold_grab = 0;   // measurements: tiles per draw of fold_kernel's four-wave launches (0 = 1, the default; 4 = round 3's behaviour)
 
   // multi-device handle (sc_ctx_create_multi, engine/multi.inc).  The handle itself owns no device state: `subs` are ordinary
   // contexts, one per entry of devices[], shard d = rank d of world subs.size() on Transport::kLocal; `mrt` holds one
   // launcher thread per further device.  In a sub, `parent` points back and h_tail / d_tail are its pinned tail buffers:
-  // [parity][table][kTailEntries] words
+  // kTailSlots slots of [parity][table][kTailEntries] words; a prover of the handle holds one slot (the same index on every
+  // shard, handed out from the handle's tail_free) from creation to destruction
   std::vector<sc_ctx*> subs;
   sc_ctx* parent = nullptr;
   struct MultiRuntime* mrt = nullptr;
   u64* h_tail = nullptr;
   u64* d_tail = nullptr;
+  std::vector<int> tail_free;
 
   // kernel timing
   // pass-kernel timing (option "time_kernels"): a ring of event pairs, read back only when the
