@@ -49,6 +49,8 @@ sys.path.insert(0, ROOT)
 
 ABANDONED = []   # contexts whose stream may be stuck in a collective that never completes: never destroyed; the process
                  # leaves through os._exit once rank 0's line is out
+FIELD = {"p": None, "name": "GoldilocksMont", "label": "Goldilocks p=2^64-2^32+1"}   # set by main() from --field
+GENERIC_P = 2**64 - 59   # --field generic: the largest 64-bit prime, through the kernels every modulus but Goldilocks' takes
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is achievable
 INT8_PEAK_TOPS = 5000.0  # dense int8 matrix-core peak: 2 x the ~2.5 PF dense bf16 figure (MI355X_MICROARCH.md, matrix cores)
 
@@ -74,6 +76,10 @@ def check_identities(F, c1, evals, ch, final_eval):
 
 
 def kernel_name(rec):
+    return _kernel_name(rec).replace("GoldilocksMont", FIELD["name"])      # the field policy the kernels were instantiated with
+
+
+def _kernel_name(rec):
     k = rec["kind"]
     if k == "pass":
         return "sc::pass_kernel<GoldilocksMont,%d,%d> on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
@@ -113,6 +119,18 @@ def aggregate_launches(log, steps_sampled):
                     "ms_per_step": g["ms"] / max(steps_sampled, 1), "_key": key})
     out.sort(key=lambda x: -x["ms_per_step"])
     return out
+
+
+PROVING_FAILED = []   # data planes that came up and then failed while proving: the run still prints its line, and exits non-zero
+
+
+def all_agree(torch, dist, ok):
+    """True iff `ok` on every rank (one control-plane all-reduce that EVERY rank executes, whatever happened locally)"""
+    if dist is None:
+        return bool(ok)
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    return int(flag.item()) == 1
 
 
 def load_traffic(key):
@@ -230,10 +248,12 @@ def planes_to_time(world):
             return [want or "rccl"]     # diagnostic: the sharded code path with one rank on a single-GPU box
         return ["none"]
     if want:
-        if want not in ("peer", "rccl", "host"):
-            raise SystemExit("SC_BENCH_TRANSPORT must be peer, rccl or host")
+        if want not in ("peer", "rccl", "host", "inproc"):
+            raise SystemExit("SC_BENCH_TRANSPORT must be peer, rccl, host or inproc")
         return [want]
-    return ["peer", "rccl"]
+    # "inproc": ONE process (rank 0) drives all N devices through one multi-device handle (sc_ctx_create_multi) - the form the
+    # reference's single-process caller uses; the other ranks wait at the barriers of its timed region
+    return ["peer", "rccl", "inproc"]
 
 
 def cpu_sample_size(requested):
@@ -264,20 +284,44 @@ def context_options():
 def time_plane(args, pkg, torch, dist, rank, world, local_rank, plane, n):
     """One data plane end to end: context, this rank's shards, exactly W untimed and K timed proofs (barrier +
     synchronize on both sides, max over ranks), the verifier-identity gate on the last transcript.  Returns a dict;
-    {"ok": False, "error": ...} when the plane could not be set up on every rank."""
+    {"ok": False, "error": ...} when the plane could not be set up on every rank or failed while proving on any.
+    Every rank runs the same sequence of control-plane collectives whatever happens to it locally: a failure is
+    caught where it happens, the rank keeps walking through the barriers, and the ranks agree on the outcome at the end.
+    plane "inproc": rank 0 alone proves, over ALL `world` devices through one multi-device handle; the other ranks only take
+    part in the barriers, so the region is timed exactly like the others."""
     mm, D, syn = pkg.matrix_multiplication, pkg.distributed, pkg.synthetic
-    F = pkg.Field(pkg.GOLDILOCKS)
+    F = pkg.Field(FIELD["p"])
+    inproc = plane == "inproc"
+    working = (rank == 0) or not inproc        # does this rank launch anything on this plane?
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    ctx = pkg.Context(F, device=local_rank)
-    ctx.set_option("vars_per_pass", args.vars_per_pass)
-    for k, v in context_options():
-        ctx.set_option(k, v)
-    label = plane
-    if plane != "none":
+    ctx, label, comm_nranks, err = None, plane, world, None
+    a = b = g = None
+    try:
+        if inproc and os.environ.get("SC_BENCH_FAIL_TRANSPORT_RANK") in (str(rank), "all"):
+            raise pkg.SumcheckHipError(2, "injected transport failure (SC_BENCH_FAIL_TRANSPORT_RANK)")   # test hook
+        if inproc:
+            if working:
+                ndev = 1 if os.environ.get("SC_BENCH_SINGLE_DEVICE") == "1" else max(torch.cuda.device_count(), 1)
+                devices = [d % ndev for d in range(world)]
+                ctx = pkg.Context(F, devices=devices)
+                label = "inproc (one process, one handle over devices %s)" % devices
+        else:
+            ctx = pkg.Context(F, device=local_rank)
+        if ctx is not None:
+            ctx.set_option("vars_per_pass", args.vars_per_pass)
+            for k, v in context_options():
+                ctx.set_option(k, v)
+    except pkg.SumcheckHipError as e:
+        err = "context: %s" % e
+    if not all_agree(torch, dist, err is None):
+        if ctx is not None:
+            ctx.close()
+        return {"ok": False, "plane": plane, "error": (err or "failed on another rank")[:300]}
+    if plane not in ("none", "inproc"):
         if world == 1:
             (D.attach_peer if plane == "peer" else D.attach_rccl)(ctx, 0, 1)
             label = "%s(world=1, diagnostic)" % plane
@@ -287,47 +331,72 @@ def time_plane(args, pkg, torch, dist, rank, world, local_rank, plane, n):
                 if ctx not in ABANDONED:
                     ctx.close()
                 return {"ok": False, "plane": plane, "error": why[:300]}
-    comm_nranks = ctx.get_option("comm_nranks")
-    start, length = D.shard_range(n, rank, world)
-    nl = length.bit_length() - 1
-    a, b = syn.tables(ctx, nl, start=start)
-    g = mm.G(a, b)
-    assert g.num_vars() == n
+    step_ms, steps_with_events, timed_every = [], 0, 4
+    c1 = evals = ch = None
+    try:
+        if working:
+            comm_nranks = ctx.get_option("comm_nranks")
+            if inproc:
+                a, b = syn.tables(ctx, n)                  # whole tables: the handle splits them over its devices
+            else:
+                start, length = D.shard_range(n, rank, world)
+                a, b = syn.tables(ctx, length.bit_length() - 1, start=start)
+            g = mm.G(a, b)
+            assert g.num_vars() == n
+    except pkg.SumcheckHipError as e:
+        err = "tables: %s" % e
 
     barrier()                                 # the ranks enter every proof together (peer_spin_ms bounds their skew)
-    for _ in range(args.warmup):              # exactly W untimed steps
-        mm.prove(ctx, g, syn.SEED_R)
-
-    # HIP events around every kernel (on the library's stream) on every fourth timed step: the event
-    # records cost ~25 us per proof, so sampling keeps the probe from moving `value` by more than
-    # ~0.3 %; the sampled launches are inside the timed region
-    timed_every = 4
-    ctx.kernel_time(reset=True)
-    ctx.launch_log(reset=True)
-    step_ms = []
+    if working and err is None:
+        try:
+            for _ in range(args.warmup):      # exactly W untimed steps
+                mm.prove(ctx, g, syn.SEED_R)
+            # HIP events around every kernel (on the library's stream) on every fourth timed step: the event
+            # records cost ~25 us per proof, so sampling keeps the probe from moving `value` by more than
+            # ~0.3 %; the sampled launches are inside the timed region
+            ctx.kernel_time(reset=True)
+            ctx.launch_log(reset=True)
+        except pkg.SumcheckHipError as e:
+            err = "failed while proving (warm-up): %s" % e
     barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps_with_events = 0
-    for i in range(args.steps):
-        sample = (i % timed_every) == 0
-        if sample:
-            ctx.set_option("time_kernels", 1)
-            steps_with_events += 1
-        ts = time.perf_counter()
-        c1, evals, ch = mm.prove(ctx, g, syn.SEED_R)     # synchronous: returns after the last round's sums
-        step_ms.append((time.perf_counter() - ts) * 1e3)
-        if sample:
-            ctx.set_option("time_kernels", 0)
-    torch.cuda.synchronize()
+    if working and err is None:
+        try:
+            for i in range(args.steps):
+                sample = (i % timed_every) == 0
+                if sample:
+                    ctx.set_option("time_kernels", 1)
+                    steps_with_events += 1
+                ts = time.perf_counter()
+                c1, evals, ch = mm.prove(ctx, g, syn.SEED_R)     # synchronous: returns after the last round's sums
+                step_ms.append((time.perf_counter() - ts) * 1e3)
+                if sample:
+                    ctx.set_option("time_kernels", 0)
+        except pkg.SumcheckHipError as e:
+            err = "failed while proving: %s" % e
+    try:
+        torch.cuda.synchronize()
+    except RuntimeError as e:  # pragma: no cover - a faulted device
+        err = err or "device synchronize: %s" % e
     barrier()
     elapsed = time.perf_counter() - t0
-    n_launch, kernel_ms = ctx.kernel_time(reset=True)
-    log = ctx.launch_log(reset=True)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    if not all_agree(torch, dist, err is None):
+        # a plane that came up but failed while proving (a collective that never completed, a peer that fell out of step): the
+        # other planes' measurements survive it; its context may hold a stream that never drains and is not destroyed
+        if ctx is not None:
+            ABANDONED.append(ctx)
+        PROVING_FAILED.append(plane)
+        return {"ok": False, "plane": plane, "error": (err or "failed while proving on another rank")[:300]}
+    if not working:
+        return {"ok": True, "plane": plane, "label": label, "ctx": None, "tables": None, "elapsed": elapsed, "step_ms": [], "n_launch": 0,
+                "kernel_ms": 0.0, "log": [], "steps_with_events": 0, "timed_every": timed_every, "comm_nranks": world, "transcript": None}
+    n_launch, kernel_ms = ctx.kernel_time(reset=True)
+    log = ctx.launch_log(reset=True)
 
     # ---- correctness gate (outside the timed region) ----------------------------------------
     final_eval = g.evaluate([int(x) for x in ch])
@@ -343,36 +412,31 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
     import numpy as np
     mm, syn = pkg.matrix_multiplication, pkg.synthetic
     n = args.num_vars if args.num_vars > 0 else 28
-    F = pkg.Field(pkg.GOLDILOCKS)
+    F = pkg.Field(FIELD["p"])
 
     runs, failed = [], {}
     for plane in planes_to_time(world):
-        try:
-            r = time_plane(args, pkg, torch, dist, rank, world, local_rank, plane, n)
-        except pkg.SumcheckHipError as e:
-            # a plane that came up but failed while proving (a collective that never completed, a peer that fell out of
-            # step): the other plane's measurement must survive it.  Parity failures are SystemExit and do propagate.
-            r = {"ok": False, "plane": plane, "error": "failed while proving: %s" % str(e)[:240]}
-            ABANDONED.append(plane)
-        if dist is not None:          # a plane counts only if it worked on every rank
-            flag = torch.tensor([1 if r["ok"] else 0], dtype=torch.int64)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0 and r["ok"]:
-                r.pop("tables", None)
-                ABANDONED.append(r.pop("ctx"))
-                r = {"ok": False, "plane": plane, "error": "failed on another rank"}
+        r = time_plane(args, pkg, torch, dist, rank, world, local_rank, plane, n)     # (never raises SumcheckHipError: see there)
         if not r["ok"]:
             failed[plane] = r["error"]
             if rank == 0:
                 sys.stderr.write("bench.py: data plane '%s' is not usable here: %s\n" % (plane, r["error"]))
             continue
+        if dist is not None and plane == "inproc":
+            # only rank 0 holds this plane's transcript and launch log: the ranks compare on rank 0's word
+            box = [r["transcript"]]
+            dist.broadcast_object_list(box, src=0)
+            if rank != 0:
+                r["transcript"] = box[0]
         if runs:                      # one plane's tables at a time in HBM
-            if r["transcript"] != runs[0]["transcript"]:
+            same = r["transcript"] == runs[0]["transcript"]
+            if not same:
                 raise SystemExit("PARITY FAILURE: the %s and %s data planes produced different transcripts" % (runs[0]["plane"], plane))
             if r["elapsed"] < runs[0]["elapsed"]:
                 runs[0], r = r, runs[0]
             r.pop("tables")
-            r.pop("ctx").close()
+            if r["ctx"] is not None:
+                r.pop("ctx").close()
         runs.append(r)
     if not runs:
         # a scaling run must never silently measure something else: no in-library data plane, no line
@@ -380,11 +444,11 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                          "to run over the host (gloo) transport on purpose" % "; ".join("%s: %s" % kv for kv in failed.items()))
     best = runs[0]
     ctx = best["ctx"]
-    a, b, g = best.pop("tables")
+    a, b, g = best.pop("tables") or (None, None, None)     # (None on the ranks that only waited for an "inproc" plane)
     elapsed, step_ms, log = best["elapsed"], best["step_ms"], best["log"]
     n_launch, kernel_ms, steps_with_events, timed_every = best["n_launch"], best["kernel_ms"], best["steps_with_events"], best["timed_every"]
     transport = best["label"]
-    transports = {r["plane"]: {"ms_per_step": r["elapsed"] / args.steps * 1e3, "ms_per_step_median": statistics.median(r["step_ms"]),
+    transports = {r["plane"]: {"ms_per_step": r["elapsed"] / args.steps * 1e3, "ms_per_step_median": statistics.median(r["step_ms"]) if r["step_ms"] else None,
                                "comm_nranks": r["comm_nranks"]} for r in runs}
     for plane, why in failed.items():
         transports[plane] = {"ms_per_step": None, "error": why}
@@ -398,14 +462,22 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
     kernel_ms_per_step = kernel_ms / max(steps_with_events, 1)
     moved = sum(k["bytes_per_launch"] * k["launches_per_step"] for k in kernels)    # this rank's launches
     ms_per_step = elapsed / args.steps * 1e3
-    median_ms = statistics.median(step_ms)
+    median_ms = statistics.median(step_ms) if step_ms else None
     unsampled = [m for i, m in enumerate(step_ms) if i % timed_every]
+    # the first folding pass of a 2^28-entry proof has two speeds, box to box and context to context (DESIGN.md section 11,
+    # experiments/r03_fold_pass_two_modes.md, experiments/r04_vmm_placement.md): say which one this run drew
+    fold_pass_mode = None
+    fp_rec = next((k for k in kernels if k["_key"][0] == "pass" and k["_key"][1] == 3 and k["_key"][2] == 2 and k["_key"][3] >= 27), None)
+    if fp_rec and fp_rec["GBps"]:
+        fold_pass_mode = {"mode": "fast" if fp_rec["GBps"] >= 5900.0 else "slow", "GBps": fp_rec["GBps"], "avg_us": fp_rec["avg_us"],
+                          "note": "pass_kernel<3,2> on the caller's tables: 'fast' >= 5.9 TB/s (reads at 6.9 + writes at 4.6 TB/s add up), "
+                                  "'slow' is what a plain 8:1 read/write stream gets on the same box (5.4-5.8 TB/s)"}
 
     result = None
     if rank == 0:
         dom = kernels[0] if kernels else None
         first_pass = next((r["ks"] for r in log if r["kind"] == "pass" and r["kf"] == 0), 0)
-        tkey = "n%d_gpus%d_vpp%d_first%d" % (n, world, args.vars_per_pass, first_pass)
+        tkey = "n%d_gpus%d_vpp%d_first%d" % (n, world, args.vars_per_pass, first_pass) + ("" if FIELD["name"] == "GoldilocksMont" else "_generic")
         tj = load_traffic(tkey)
         traffic, traffic_step, traffic_check = None, None, "no PMC record for %s in profiles/traffic.json" % tkey
         if tj:
@@ -422,7 +494,7 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                     traffic, traffic_step = None, None
                     sys.stderr.write("bench.py: " + traffic_check + "\n")
         result = {
-            "metric": "field mul-adds/sec in sumcheck prover, n=%d vars" % n,
+            "metric": "field mul-adds/sec in sumcheck prover, n=%d vars" % n + ("" if FIELD["name"] == "GoldilocksMont" else " (generic modulus)"),
             "value": value,
             "unit": "field mul-adds/s",
             "n_gpus": world,
@@ -430,16 +502,16 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
             "ms_per_step_median": median_ms,
-            "value_at_median": muladds / (median_ms * 1e-3),
+            "value_at_median": muladds / (median_ms * 1e-3) if median_ms else None,
             "higher_is_better": True,
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "u64",
             "data": "synthetic",
             "config": {
-                "workload": "full sumcheck prover, g=a*b, n=%d, Goldilocks p=2^64-2^32+1, hypercube sharded by top "
+                "workload": "full sumcheck prover, g=a*b, n=%d, %s, hypercube sharded by top "
                             "index bits over %d GPU(s), %s" % (
-                                n, world, ("%s exchange per pass" % transport) if world > 1 else "no collective"),
+                                n, FIELD["label"], world, ("%s exchange per pass" % transport) if world > 1 else "no collective"),
                 "num_vars": n,
                 "field_mul_adds_per_step": muladds,
                 "algorithmic_bytes_per_step": alg_bytes,
@@ -462,6 +534,8 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                 "unit": "GB/s",
                 "frac": dom["GBps"] / HBM_PEAK_GBS if dom and dom["GBps"] else None,
                 "traffic": traffic,
+                "traffic_source": ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same command on the builder's box "
+                                   "(not collected in this run; used only if this run's launch-log bytes agree within 2 %)") if traffic else None,
                 "bytes_per_launch": dom["bytes_per_launch"] if dom else None,
                 "avg_launch_us": dom["avg_us"] if dom else None,
                 "per_gpu": True,
@@ -471,6 +545,7 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                     "launches": n_launch / max(steps_with_events, 1),
                     "frac_of_kernel_time": moved / (kernel_ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS if kernel_ms_per_step else None,
                     "frac_of_wall_time": moved / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                    "fold_pass_mode": fold_pass_mode,
                     "pmc_traffic": traffic_step,
                     "traffic_check": traffic_check,
                     "sec8d_algorithmic_bytes": alg_bytes / world,
@@ -494,7 +569,7 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
         from oracle import Oracle   # the checker / CPU baseline: only this leg touches oracle/
         import pyref
         assert (pyref.SEED_A, pyref.SEED_B, pyref.SEED_R) == (syn.SEED_A, syn.SEED_B, syn.SEED_R)
-        o = Oracle(pkg.GOLDILOCKS)
+        o = Oracle(FIELD["p"])
         oa, ob = o.generate(pyref.SEED_A, nc), o.generate(pyref.SEED_B, nc)
         och = np.array([o.challenge(pyref.SEED_R, j + 1) for j in range(nc)], dtype=np.uint64)
         tc = time.perf_counter()
@@ -537,12 +612,12 @@ def run_mle(args, pkg, torch, dist, rank, world, local_rank):
         raise SystemExit("--workload mle is a single-GPU workload (run --gpus N as N replicas by hand)")
     syn = pkg.synthetic
     n = args.num_vars if args.num_vars > 0 else 24
-    F = pkg.Field(pkg.GOLDILOCKS)
+    F = pkg.Field(FIELD["p"])
     ctx = pkg.Context(F, device=local_rank)
     t = pkg.DenseMultilinearExtension.generate(ctx, syn.SEED_A, n)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import Oracle    # challenge derivation + the checker (after the timed region)
-    o = Oracle(pkg.GOLDILOCKS)
+    o = Oracle(FIELD["p"])
     pt = [int(o.challenge(syn.SEED_PT, j)) for j in range(n)]
     ks = [1, 3, n // 2]
     ops = [("evaluate_le", n), ("evaluate_be", n)] + [("fix_variables_k%d" % k, k) for k in ks]
@@ -749,7 +824,7 @@ def run_gkr(args, pkg, torch, dist, rank, world, local_rank):
         raise SystemExit("--workload gkr is a single-GPU workload")
     gp = pkg.gkr_protocol
     k = args.num_vars if args.num_vars > 0 else 13
-    F = pkg.Field(pkg.GOLDILOCKS)
+    F = pkg.Field(FIELD["p"])
     ctx = pkg.Context(F, device=local_rank)
     rng = random.Random(2026)
     circuit = random_layer(pkg, rng, k)
@@ -776,7 +851,7 @@ def run_gkr(args, pkg, torch, dist, rank, world, local_rank):
     # the same layer shape at a size the oracle finishes in seconds, bit for bit; that run is the CPU baseline
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import Oracle
-    o = Oracle(pkg.GOLDILOCKS)
+    o = Oracle(FIELD["p"])
     kc = min(k, args.cpu_num_vars if args.cpu_num_vars > 0 else 12)
     crng = random.Random(7)
     ccirc = random_layer(pkg, crng, kc)
@@ -823,11 +898,11 @@ def run_gnew(args, pkg, torch, dist, rank, world, local_rank):
         raise SystemExit("--workload gnew is a single-GPU workload")
     mm, syn = pkg.matrix_multiplication, pkg.synthetic
     n = args.num_vars if args.num_vars > 0 else 14
-    F = pkg.Field(pkg.GOLDILOCKS)
+    F = pkg.Field(FIELD["p"])
     ctx = pkg.Context(F, device=local_rank)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import Oracle
-    o = Oracle(pkg.GOLDILOCKS)
+    o = Oracle(FIELD["p"])
     A = pkg.DenseMultilinearExtension.generate(ctx, 11, 2 * n)
     B = pkg.DenseMultilinearExtension.generate(ctx, 12, 2 * n)
     pt = [int(o.challenge(syn.SEED_PT, t)) for t in range(2 * n)]
@@ -888,7 +963,7 @@ def run_triangle(args, pkg, torch, dist, rank, world, local_rank):
         raise SystemExit("--workload triangle is a single-GPU workload")
     tc_mod = pkg.triangle_counting
     k = args.num_vars if args.num_vars > 0 else 10
-    F = pkg.Field(pkg.GOLDILOCKS)
+    F = pkg.Field(FIELD["p"])
     ctx = pkg.Context(F, device=local_rank)
     seed = pkg.synthetic.SEED_R
 
@@ -917,7 +992,7 @@ def run_triangle(args, pkg, torch, dist, rank, world, local_rank):
     parity = ["k=%d: c_1 == 6 x %d triangles (numpy), verifier identities, final G::evaluate" % (k, tri)]
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import Oracle
-    o = Oracle(pkg.GOLDILOCKS)
+    o = Oracle(FIELD["p"])
     kc = min(k, args.cpu_num_vars if args.cpu_num_vars > 0 else 9)
     mc = graph(kc, 78)
     gc = table(mc, kc)
@@ -993,7 +1068,16 @@ def main():
     ap.add_argument("--cpu-num-vars", type=int, default=int(os.environ.get("SC_BENCH_CPU_N", "-1")),
                     help="size of the bounded CPU-baseline sample (0 disables; -1 = as large as host memory allows, <= 28)")
     ap.add_argument("--vars-per-pass", type=int, default=2)
+    ap.add_argument("--field", default=os.environ.get("SC_BENCH_FIELD", "goldilocks"),
+                    help="goldilocks (BASELINE's 64-bit prime field, the headline) | generic (p = 2^64-59 through the kernels of "
+                         "every other modulus: the reference's Fp64<MontBackend<T,1>>) | an odd prime below 2^64")
     args = ap.parse_args()
+    if args.field == "goldilocks":
+        FIELD["p"] = 2**64 - 2**32 + 1
+    else:
+        FIELD["p"] = GENERIC_P if args.field == "generic" else int(args.field, 0)
+        FIELD["name"] = "MontGeneric"
+        FIELD["label"] = "generic-modulus Montgomery field p=%d%s" % (FIELD["p"], " (2^64-59)" if FIELD["p"] == GENERIC_P else "")
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # plain `python bench.py --gpus N`: start the N rank processes ourselves.  This process has not touched the GPU
@@ -1031,13 +1115,16 @@ def main():
         flag = torch.tensor([1 if abandoned else 0], dtype=torch.int64)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         abandoned = int(flag.item()) == 1
+    # a plane that failed WHILE PROVING is a failure of the run even though the other planes' line is out
+    code = 3 if PROVING_FAILED else 0
     if abandoned:                 # something may never return (a stuck collective): leave without destroying it
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
+        os._exit(code)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return code
 
 
 if __name__ == "__main__":

@@ -59,6 +59,36 @@ u64 fh_gen_dot(u64 p, const u64* a, const u64* b, size_t n) {
   for (size_t i = 0; i < n; ++i) F.acc_mac(acc, a[i], b[i]);
   return F.acc_get(acc);
 }
+// the three-class accumulator of the folds, and a sum split over two accumulators joined by acc_add (block reductions)
+u64 fh_gen_dot3(u64 p, const u64* a, const u64* b, size_t n) {
+  FieldParams fp;
+  field_params_from_modulus(p, &fp);
+  MontGeneric F(fp);
+  MontGeneric::Acc3 acc;
+  F.acc3_zero(acc);
+  for (size_t i = 0; i < n; ++i) F.acc3_mac(acc, a[i], b[i]);
+  return F.acc3_get(acc);
+}
+u64 fh_gen_dot_split(u64 p, const u64* a, const u64* b, size_t n) {
+  FieldParams fp;
+  field_params_from_modulus(p, &fp);
+  MontGeneric F(fp);
+  MontGeneric::Acc lo, hi;
+  F.acc_zero(lo);
+  F.acc_zero(hi);
+  for (size_t i = 0; i < n; ++i) F.acc_mac((i & 1) ? hi : lo, a[i], b[i]);
+  F.acc_add(lo, hi);
+  return F.acc_get(lo);
+}
+u64 fh_gold_dot_split(const u64* a, const u64* b, size_t n) {
+  GoldilocksMont F;
+  GoldilocksMont::Acc lo, hi;
+  F.acc_zero(lo);
+  F.acc_zero(hi);
+  for (size_t i = 0; i < n; ++i) F.acc_mac((i & 1) ? hi : lo, a[i], b[i]);
+  F.acc_add(lo, hi);
+  return F.acc_get(lo);
+}
 void fh_params(u64 p, u64* out4) {
   FieldParams fp;
   field_params_from_modulus(p, &fp);

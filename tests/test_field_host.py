@@ -28,6 +28,11 @@ def fh(tmp_path_factory):
     lib.fh_gold_dot3.restype = ctypes.c_uint64
     lib.fh_gen_dot.argtypes = [ctypes.c_uint64, u64p, u64p, ctypes.c_size_t]
     lib.fh_gen_dot.restype = ctypes.c_uint64
+    for name in ("fh_gen_dot3", "fh_gen_dot_split"):
+        getattr(lib, name).argtypes = [ctypes.c_uint64, u64p, u64p, ctypes.c_size_t]
+        getattr(lib, name).restype = ctypes.c_uint64
+    lib.fh_gold_dot_split.argtypes = [u64p, u64p, ctypes.c_size_t]
+    lib.fh_gold_dot_split.restype = ctypes.c_uint64
     lib.fh_params.argtypes = [ctypes.c_uint64, u64p]
     lib.fh_splitmix64.argtypes = [ctypes.c_uint64]
     lib.fh_splitmix64.restype = ctypes.c_uint64
@@ -117,11 +122,23 @@ def test_lazy_accumulator(fh):
     exp = n * (GOLD - 1) ** 2 * rinv % GOLD
     assert int(fh.fh_gold_dot(_p(a), _p(a), n)) == exp
     assert int(fh.fh_gold_dot3(_p(a), _p(a), n)) == exp
-    for p in (5, 389, 2**64 - 59):
-        a = _arr([rng.randrange(p) for _ in range(5000)])
-        b = _arr([rng.randrange(p) for _ in range(5000)])
-        exp = sum(int(x) * int(y) for x, y in zip(a, b)) * pow(R, -1, p) % p
-        assert int(fh.fh_gen_dot(p, _p(a), _p(b), a.size)) == exp
+    assert int(fh.fh_gold_dot_split(_p(a), _p(a), n)) == exp
+    # the generic modulus (the reference's Fp64<MontBackend<T,1>> with any T): 160-bit lazy sums, reduced once
+    for p in (3, 5, 389, 1572869, 2**61 - 1, 2**63 + 29, 2**64 - 59, GOLD):
+        for n in (0, 1, 2, 7, 5000):
+            a = _arr([rng.randrange(p) for _ in range(n)])
+            b = _arr([rng.randrange(p) for _ in range(n)])
+            exp = sum(int(x) * int(y) for x, y in zip(a, b)) * pow(R, -1, p) % p
+            assert int(fh.fh_gen_dot(p, _p(a), _p(b), a.size)) == exp
+            assert int(fh.fh_gen_dot3(p, _p(a), _p(b), a.size)) == exp
+            assert int(fh.fh_gen_dot_split(p, _p(a), _p(b), a.size)) == exp
+        # worst case: every product is (p-1)^2 and there are enough of them to carry well into the fifth limb / the counters
+        n = 300000
+        a = np.full(n, p - 1, dtype=np.uint64)
+        exp = n * (p - 1) ** 2 * pow(R, -1, p) % p
+        assert int(fh.fh_gen_dot(p, _p(a), _p(a), n)) == exp
+        assert int(fh.fh_gen_dot3(p, _p(a), _p(a), n)) == exp
+        assert int(fh.fh_gen_dot_split(p, _p(a), _p(a), n)) == exp
 
 
 def test_splitmix_matches_pyref(fh):

@@ -59,15 +59,18 @@ def test_bench_two_ranks_on_one_device():
     d = _one_line(_bench(args, {"SC_BENCH_TRANSPORT": "host"}, port=port))
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["value"] > 0
     assert "host" in d["config"]["transport"] and list(d["config"]["transports"]) == ["host"]
-    # default: BOTH in-library data planes are attempted and timed.  In-kernel exchange through peer-mapped inboxes
+    # default: EVERY in-library data plane is attempted and timed.  In-kernel exchange through peer-mapped inboxes
     # (HIP IPC between the two processes) works on one device; RCCL refuses two ranks on one GPU ("Duplicate GPU
-    # detected"), which the line must say instead of hiding - on a multi-GPU node both carry a time.
+    # detected"), which the line must say instead of hiding - on a multi-GPU node both carry a time; and the one-process
+    # plane: rank 0 alone over ONE handle of two devices (sc_ctx_create_multi), the other rank only at the barriers.
     d = _one_line(_bench(args, port=port + 1))
     tr = d["config"]["transports"]
-    assert d["n_gpus"] == 2 and d["config"]["transport"] == "peer" and d["value"] > 0
-    assert set(tr) == {"peer", "rccl"}
+    assert d["n_gpus"] == 2 and d["config"]["transport"].split(" ")[0].split("(")[0] in ("peer", "inproc") and d["value"] > 0
+    assert set(tr) == {"peer", "rccl", "inproc"}
     assert tr["peer"]["ms_per_step"] > 0 and tr["peer"]["comm_nranks"] == 2
+    assert tr["inproc"]["ms_per_step"] > 0 and tr["inproc"]["comm_nranks"] == 2
     assert tr["rccl"]["ms_per_step"] is None and tr["rccl"]["error"]
+    assert "same transcript" in d["config"]["parity_gate"]
     assert d["roofline"]["per_gpu"] is True and 0 < d["roofline"]["frac"] <= 1
 
 

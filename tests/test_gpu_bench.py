@@ -87,3 +87,17 @@ def test_bench_widened_workloads(workload, size, cpu_size, kernel):
     assert abs(sum(k["bytes_per_launch"] * k["launches_per_step"] for k in r["kernels"]) - r["step"]["bytes_moved"]) < 1
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_generic_field():
+    """--field generic: p = 2^64-59 through the kernels of every non-Goldilocks modulus (the reference's Fp64<MontBackend<T,1>>),
+    same contract, its own roofline object, bit-exact against the oracle inside the run"""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--field", "generic", "--num-vars", "18", "--steps", "8", "--warmup", "2",
+                          "--cpu-num-vars", "16"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][0])
+    assert "generic modulus" in d["metric"] and "18446744073709551557" in d["config"]["workload"]
+    assert "MontGeneric" in d["roofline"]["kernel"] and 0 < d["roofline"]["frac"] <= 1.0
+    assert "bit-exact vs CPU oracle at n=16 ok" in d["config"]["parity_gate"]
+    assert d["cpu_baseline"]["value"] > 0

@@ -8,7 +8,8 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsumcheck_hip.so")
+# SUMCHECK_HIP_LIB: another build of the same ABI (A/B measurements: tools/generic_ab.sh); default: the in-tree library
+LIB_PATH = os.environ.get("SUMCHECK_HIP_LIB") or os.path.join(_HERE, "libsumcheck_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 u64 = ctypes.c_uint64

@@ -8,8 +8,9 @@
 //   GoldilocksMont - p = 2^64 - 2^32 + 1.  p^-1 = 2^32 + 1 (mod 2^64), so the Montgomery
 //                    reduction is shifts/adds only, and sums of products are accumulated
 //                    unreduced in a signed 128-bit word (2^96 = -1 mod p; one reduction per thread, not per product).
-//   MontGeneric    - any odd p < 2^64 with runtime constants (toy moduli 5 / 389 / 1572869
-//                    used by the reference's tests); every product is reduced.
+//   MontGeneric    - any odd p < 2^64 with runtime constants (the reference's field type, Fp64<MontBackend<T,1>> with any
+//                    modulus: toy moduli 5 / 389 / 1572869 in its tests); sums of products are accumulated unreduced in
+//                    160 bits and reduced once per thread (round 4; before, every product was reduced).
 //
 // Interface (F = policy object, passed by value to kernels):
 //   F.add(a,b) F.sub(a,b) F.dbl(a) F.mul(a,b)         residues in, residue out
@@ -126,16 +127,131 @@ struct MontGeneric {
   // canonical value of an arbitrary 64-bit word
   SC_HD u64 reduce_word(u64 z) const { return z % p; }
 
-  typedef u64 Acc;
-  SC_HD void acc_zero(Acc& a) const { a = 0; }
-  SC_HD void acc_mac(Acc& a, u64 x, u64 y) const { a = add(a, mul(x, y)); }
-  SC_HD void acc_mac(Acc& a, X64 x, X64 y) const { acc_mac(a, join64(x), join64(y)); }
-  SC_HD u64 acc_get(const Acc& a) const { return a; }
-  SC_HD void acc_add(Acc& a, const Acc& b) const { a = add(a, b); }   // sum of two accumulators (block reductions)
-  typedef u64 Acc3;  // short sums (folds): same thing for a generic modulus
-  SC_HD void acc3_zero(Acc3& a) const { a = 0; }
-  SC_HD void acc3_mac(Acc3& a, u64 x, u64 y) const { a = add(a, mul(x, y)); }
-  SC_HD u64 acc3_get(const Acc3& a) const { return a; }
+  // (w2*2^128 + w1*2^64 + w0) * 2^-64 mod p for ANY three words: w0 * R^-1 + (w1 mod p) + w2 * R, each term one
+  // Montgomery product - mul(w1, R mod p) = w1 mod p and mul(w2, R^2 mod p) = w2 * R mod p are valid because one factor
+  // of each is below p.  Once per accumulator, not per product.
+  SC_HD u64 wide_get(u64 w0, u64 w1, u64 w2) const { return add(add(redc(0, w0), mul(w1, r1)), mul(w2, r2)); }
+
+  // Unreduced sum of products (round 4; until then every product of the generic field was reduced on its own - a full
+  // Montgomery REDC, ~35 instructions, per multiply-accumulate).  A product of two residues is below 2^128 whatever the
+  // modulus, so a 160-bit unsigned accumulator - FIVE registers - takes 2^32 of them; kAccMaxTerms (the bound the host
+  // checks caller-sized sums against) is the Goldilocks accumulator's 2^28.  Device: four v_mad_u64_u32 (t = x0 y0,
+  // m = x0 y1 + x1 y0 with its carry sC, q = x1 y1) and eleven add-with-carry in three interleaved chains (A adds t and q,
+  // B adds m, C adds sC at 2^96), every carry consumer three slots behind its producer as gfx950 wants (two wait states
+  // between a VALU that writes VCC / an SGPR pair and the VALU that reads it; GoldilocksMont::acc_mac has the same shape),
+  // two s_nop where only two chains are left: 17 issue slots, the same order as the 15 of the Goldilocks sequence.
+  static constexpr u64 kAccMaxTerms = (u64)1 << 28;
+  struct Acc {
+    u32 l0, l1, l2, l3, l4;   // little-endian 32-bit limbs
+  };
+  SC_HD void acc_zero(Acc& a) const { a.l0 = a.l1 = a.l2 = a.l3 = a.l4 = 0; }
+  SC_HD void acc_add(Acc& a, const Acc& b) const {
+    const u64 s0 = (u64)a.l0 + b.l0;
+    const u64 s1 = (u64)a.l1 + b.l1 + (s0 >> 32);
+    const u64 s2 = (u64)a.l2 + b.l2 + (s1 >> 32);
+    const u64 s3 = (u64)a.l3 + b.l3 + (s2 >> 32);
+    a.l0 = (u32)s0;
+    a.l1 = (u32)s1;
+    a.l2 = (u32)s2;
+    a.l3 = (u32)s3;
+    a.l4 = a.l4 + b.l4 + (u32)(s3 >> 32);
+  }
+  SC_HD void acc_mac(Acc& a, u64 x, u64 y) const { acc_mac(a, split64(x), split64(y)); }
+  SC_HD void acc_mac(Acc& a, X64 xs, X64 ys) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 x0 = xs.lo, x1 = xs.hi, y0 = ys.lo, y1 = ys.hi;
+    u64 t, m, q, sC, sB, sD;
+    asm("v_mad_u64_u32 %1, vcc, %4, %7, 0\n\t"
+        "v_mad_u64_u32 %1, %3, %5, %6, %1\n\t"
+        "v_mad_u64_u32 %0, vcc, %4, %6, 0\n\t"
+        "v_mad_u64_u32 %2, vcc, %5, %7, 0"
+        : "=&v"(t), "=&v"(m), "=&v"(q), "=&s"(sC)
+        : "v"(x0), "v"(x1), "v"(y0), "v"(y1)
+        : "vcc");
+    const u32 t0 = (u32)t, t1 = (u32)(t >> 32), m0 = (u32)m, m1 = (u32)(m >> 32), q0 = (u32)q,
+              q1 = (u32)(q >> 32);
+    asm("v_add_co_u32_e32 %0, vcc, %0, %7\n\t"           // A1  l0 += t0
+        "v_add_co_u32_e64 %1, %5, %1, %9\n\t"            // B1  l1 += m0
+        "v_addc_co_u32_e64 %3, %6, %3, 0, %13\n\t"       // C1  l3 += sC
+        "v_addc_co_u32_e32 %1, vcc, %1, %8, vcc\n\t"     // A2  l1 += t1 + c
+        "v_addc_co_u32_e64 %2, %5, %2, %10, %5\n\t"      // B2  l2 += m1 + c
+        "v_addc_co_u32_e64 %4, %6, %4, 0, %6\n\t"        // C2  l4 += c
+        "v_addc_co_u32_e32 %2, vcc, %2, %11, vcc\n\t"    // A3  l2 += q0 + c
+        "v_addc_co_u32_e64 %3, %5, %3, 0, %5\n\t"        // B3  l3 += c
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e32 %3, vcc, %3, %12, vcc\n\t"    // A4  l3 += q1 + c
+        "v_addc_co_u32_e64 %4, %5, %4, 0, %5\n\t"        // B4  l4 += c
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e32 %4, vcc, 0, %4, vcc"            // A5  l4 += c
+        : "+v"(a.l0), "+v"(a.l1), "+v"(a.l2), "+v"(a.l3), "+v"(a.l4), "=&s"(sB), "=&s"(sD)
+        : "v"(t0), "v"(t1), "v"(m0), "v"(m1), "v"(q0), "v"(q1), "s"(sC)
+        : "vcc");
+#else
+    u64 hi, lo;
+    mul_wide(join64(xs), join64(ys), hi, lo);
+    typedef unsigned __int128 u128;
+    u128 s = ((u128)a.l3 << 96) | ((u128)a.l2 << 64) | ((u128)a.l1 << 32) | a.l0;
+    const u128 s2 = s + (((u128)hi << 64) | lo);
+    a.l4 += (s2 < s) ? 1u : 0u;
+    a.l0 = (u32)s2;
+    a.l1 = (u32)(s2 >> 32);
+    a.l2 = (u32)(s2 >> 64);
+    a.l3 = (u32)(s2 >> 96);
+#endif
+  }
+  SC_HD u64 acc_get(const Acc& a) const {
+    u32 l0 = a.l0, l1 = a.l1, l2 = a.l2, l3 = a.l3, l4 = a.l4;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm("" : "+v"(l0), "+v"(l1), "+v"(l2), "+v"(l3), "+v"(l4));   // see GoldilocksMont::acc_get: keeps the limbs unpaired in the loops
+#endif
+    return wide_get(((u64)l1 << 32) | l0, ((u64)l3 << 32) | l2, (u64)l4);
+  }
+
+  // Three-class accumulator for short sums (folds): the four 32x32 partial products are added into three 64-bit words by
+  // v_mad_u64_u32 itself, each with a carry counter - 4 multiply-adds + 4 add-with-carry per product, nine registers
+  // (GoldilocksMont::Acc3: the arithmetic does not depend on the modulus, only the final reduction does)
+  struct Acc3 {
+    u64 a00, a01, a11;
+    u32 c00, c01, c11;
+  };
+  SC_HD void acc3_zero(Acc3& A) const { A.a00 = A.a01 = A.a11 = 0; A.c00 = A.c01 = A.c11 = 0; }
+  SC_HD void acc3_mac(Acc3& A, u64 x, u64 y) const {
+    const u32 x0 = (u32)x, x1 = (u32)(x >> 32), y0 = (u32)y, y1 = (u32)(y >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    u64 s0, s1, s2, s3;
+    asm volatile(
+        "v_mad_u64_u32 %0, %6, %10, %12, %0\n\t"
+        "v_mad_u64_u32 %1, %7, %10, %13, %1\n\t"
+        "v_mad_u64_u32 %2, %8, %11, %13, %2\n\t"
+        "v_addc_co_u32_e64 %3, %6, %3, 0, %6\n\t"
+        "v_mad_u64_u32 %1, %9, %11, %12, %1\n\t"
+        "v_addc_co_u32_e64 %4, %7, %4, 0, %7\n\t"
+        "v_addc_co_u32_e64 %5, %8, %5, 0, %8\n\t"
+        "v_addc_co_u32_e64 %4, %9, %4, 0, %9\n\t"
+        : "+v"(A.a00), "+v"(A.a01), "+v"(A.a11), "+v"(A.c00), "+v"(A.c01), "+v"(A.c11), "=&s"(s0), "=&s"(s1),
+          "=&s"(s2), "=&s"(s3)
+        : "v"(x0), "v"(x1), "v"(y0), "v"(y1));
+#else
+    u64 t;
+    bool c;
+    c = __builtin_add_overflow((u64)x0 * y0, A.a00, &t); A.a00 = t; A.c00 += c ? 1u : 0u;
+    c = __builtin_add_overflow((u64)x0 * y1, A.a01, &t); A.a01 = t; A.c01 += c ? 1u : 0u;
+    c = __builtin_add_overflow((u64)x1 * y1, A.a11, &t); A.a11 = t; A.c11 += c ? 1u : 0u;
+    c = __builtin_add_overflow((u64)x1 * y0, A.a01, &t); A.a01 = t; A.c01 += c ? 1u : 0u;
+#endif
+  }
+  SC_HD u64 acc3_get(const Acc3& A) const {
+    // w0 + w1*2^64 + w2*2^128 = a00 + c00*2^64 + (a01 + c01*2^64)*2^32 + (a11 + c11*2^64)*2^64
+    u64 w0, w1, t;
+    bool k = __builtin_add_overflow(A.a00, A.a01 << 32, &w0);
+    u32 carry = k ? 1u : 0u;
+    t = (A.a01 >> 32) + ((u64)A.c01 << 32);          // < 2^64: c01 < 2^31 for any sum used here
+    k = __builtin_add_overflow(t, (u64)A.c00 + carry, &t);
+    carry = k ? 1u : 0u;
+    k = __builtin_add_overflow(t, A.a11, &w1);
+    carry += k ? 1u : 0u;
+    return wide_get(w0, w1, (u64)A.c11 + carry);
+  }
 };
 
 // ---------------------------------------------------------------------------------

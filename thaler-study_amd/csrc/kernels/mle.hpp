@@ -142,9 +142,8 @@ __device__ __forceinline__ void build_eq_weights(const F& f, const u64* r, int t
 template <class F> struct stream_block {            // threads of the one-block-per-CU launches of the two streaming readers
   static constexpr int evaluate = 768, fix_low = 1024;
 };
-template <> struct stream_block<MontGeneric> {      // the generic-modulus arithmetic needs more registers per wave
-  static constexpr int evaluate = 512, fix_low = 512;
-};
+// (until round 4 the generic modulus reduced every product and needed 174-186 VGPRs here: 512-thread blocks.  With its lazy
+// sums it is at the Goldilocks kernels' 122-126 and takes the same launch shapes.)
 template <class F, bool NT>
 __global__ void __launch_bounds__(stream_block<F>::evaluate)
 evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chunk_log, u64 w_extra, PassOut out) {

@@ -300,10 +300,16 @@ __device__ __forceinline__ A shfl_down_acc(const A& a, int off) {
   for (int w = 0; w < (int)(sizeof(A) / 4); ++w) dst[w] = (unsigned)__shfl_down((int)src[w], off, kWave);
   return r;
 }
+// cells per chunk: 32 threads sum one cell, and a chunk's accumulators (BS of them per cell) stay within 256 bytes of LDS per
+// thread - sixteen 16-byte Goldilocks accumulators, twelve 20-byte ones of the generic field
+template <class Acc, int BS>
+__host__ __device__ constexpr int reduce_chunk_cells() {
+  return (BS / 32 < 256 / (int)sizeof(Acc)) ? BS / 32 : 256 / (int)sizeof(Acc);
+}
 template <class F, int NS, int BS = kBlock>
 __device__ __forceinline__ u64 reduce_cells_lds(const F& f, const typename F::Acc (&acc)[NS], typename F::Acc* scratch, u64* out) {
   typedef typename F::Acc Acc;
-  constexpr int CH = BS / 32;   // cells per chunk: 32 threads sum one cell
+  constexpr int CH = reduce_chunk_cells<Acc, BS>();
   const int tid = threadIdx.x, cell = tid >> 5, part = tid & 31;
 #pragma unroll
   for (int c0 = 0; c0 < NS; c0 += CH) {
@@ -317,7 +323,7 @@ __device__ __forceinline__ u64 reduce_cells_lds(const F& f, const typename F::Ac
     if (cell < n) {
       Acc t = scratch[cell * BS + part];
 #pragma unroll
-      for (int k = 1; k < BS / 32; ++k) f.acc_add(t, scratch[cell * BS + part + 32 * k]);
+      for (int k = 1; k < BS / 32; ++k) f.acc_add(t, scratch[cell * BS + part + 32 * k]);   // (BS / 32 slices of 32 threads each)
 #pragma unroll
       for (int off = 16; off >= 1; off >>= 1) {
         const Acc o = shfl_down_acc(t, off);
@@ -349,7 +355,8 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   static_assert(BS == kBlock || NS >= 9, "reduce_cells (the KS = 1 passes) is written for 256 threads");
   // the tile transposes; after the loop the same bytes hold a chunk of every thread's accumulators (reduce_cells_lds)
   constexpr int kTransposeSlots = (NP > 1 || NPO > 1) ? kWaves * kWave * NP : 1;
-  constexpr int kReduceSlots = (NS >= 9) ? (int)((NS < BS / 32 ? NS : BS / 32) * BS * sizeof(typename F::Acc) / sizeof(ull2)) : 1;
+  constexpr int kChunkCells = reduce_chunk_cells<typename F::Acc, BS>();
+  constexpr int kReduceSlots = (NS >= 9) ? (int)(((NS < kChunkCells ? NS : kChunkCells) * BS * sizeof(typename F::Acc) + sizeof(ull2) - 1) / sizeof(ull2)) : 1;
   __shared__ ull2 lds_t[kTransposeSlots > kReduceSlots ? kTransposeSlots : kReduceSlots];
   __shared__ u64 lds[kWaves * NS];
   __shared__ int lds_flag;
