@@ -848,6 +848,26 @@ def run_gkr(args, pkg, torch, dist, rank, world, local_rank):
     if sparse.c1() != c1 or any(sparse.round_evals(int(ch[j - 1]) if j else F.one, j) != [int(x) for x in evals[j]] for j in range(2 * k)):
         raise SystemExit("PARITY FAILURE: dense and sparse W provers disagree at k=%d" % k)
     parity = ["k=%d: c_1 == W_i~(r_i), verifier identities, final W::evaluate, dense == sparse prover every round" % k]
+    # The layer's last message: restrict_poly(b*, c*, W_{i+1}) (gkr-protocol/src/lib.rs:291-321, sent by round_msg :439-456) - the k + 1
+    # evaluations of W~ on the line through the two halves of the challenge vector.  ONE pass over the table since round 4
+    # (sc_table_evaluate_many); the k + 1 single evaluations it replaced are timed beside it.  Outside the timed steps.
+    wt = w.w_b
+    bpt, cpt = [int(x) for x in ch[:k]], [int(x) for x in ch[k:]]
+    reps, t_one, t_many = 30, [], []
+    q_ref = gp.restrict_poly(bpt, cpt, wt)
+    line_pts = [[F.add(bi, F.mul(F.from_int(j), F.sub(ci, bi))) for bi, ci in zip(bpt, cpt)] for j in range(k + 1)]
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        gp.restrict_poly(bpt, cpt, wt)
+        t_one.append((time.perf_counter() - t0) * 1e6)
+        t0 = time.perf_counter()
+        singles = [wt.evaluate(pt) for pt in line_pts]
+        t_many.append((time.perf_counter() - t0) * 1e6)
+    if [q_ref.evaluate(F.from_int(j)) for j in range(k + 1)] != singles:
+        raise SystemExit("PARITY FAILURE: restrict_poly disagrees with the k + 1 single evaluations at k=%d" % k)
+    parity.append("restrict_poly(t = 0..k) == the k + 1 single W~ evaluations")
+    restrict = {"one_pass_us_median": statistics.median(t_one), "k_plus_1_single_evaluations_us_median": statistics.median(t_many),
+                "points": k + 1, "note": "host wall clock incl. the Python wrapper; the second figure has k + 1 wrapper calls"}
     # the same layer shape at a size the oracle finishes in seconds, bit for bit; that run is the CPU baseline
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     from oracle import Oracle
@@ -878,6 +898,7 @@ def run_gkr(args, pkg, torch, dist, rank, world, local_rank):
     config = {"workload": "GKR layer sumcheck (W round polynomial, dense two-phase prover), 2^%d gates over 2^%d values, add/mul tables "
                           "of 4^%d entries, Goldilocks (BASELINE configs[4] inner loop on 1 GPU)" % (k, k, k),
               "k": k, "num_vars": 2 * k, "field_mul_adds_per_step": muladds(k), "algorithmic_bytes_per_step": alg_bytes,
+              "restrict_poly": restrict,
               "parity_gate": "; ".join(parity),
               "schedule": [[r["kind"], r["kf"], r["ks"], r["log_in"]] for r in log[: len(log) // args.steps]]}
     cpu = {"value": muladds(kc) / cpu_s, "unit": "field mul-adds/s", "cores": 1, "host_cores_total": os.cpu_count(), "kind": "port",

@@ -85,7 +85,7 @@ int sc_ctx_create(const sc_field* f, int device, sc_ctx** out);
  * launches go out from one thread per device.  When the shards are down to their pending challenges the host folds the
  * <= 32 entries per table and device it was handed and serves the rounds of the device bits itself: a sharded proof is one
  * launch per device SHORTER than a single-device one.  Results are bit-identical to a one-device context.
- * Not served (SC_ERR_UNSUPPORTED): sc_table_relabel, sc_table_restrict_to_line, sc_gkr_*, sc_tri_* (run those on an
+ * Not served (SC_ERR_UNSUPPORTED): sc_table_relabel, sc_gkr_*, sc_tri_* (run those on an
  * ordinary context), fix_variables across the device bits, and the sc_ctx_comm_* calls (the handle is its own communicator;
  * sc_ctx_comm_rank reports rank 0 of 1 - its tables are whole tables; option "n_devices" counts the devices).  sc_table_device_ptr returns NULL; sc_ctx_stream, sc_ctx_kernel_time and
  * sc_ctx_launch_log report the first device (one GPU's launches over its own shard). */
@@ -221,6 +221,12 @@ int sc_table_fix_variables(sc_ctx* ctx, const sc_table* in, const uint64_t* r, s
  * SC_ORDER_BE.  n must equal log2(len) (times world when sharded: r then holds all n). */
 int sc_table_evaluate(sc_ctx* ctx, const sc_table* t, const uint64_t* r, size_t n, int order,
                       uint64_t* out);
+/* The same at m points in ONE pass over the table: points = m rows of n words, out = m values.  Callers that evaluate one
+ * table several times - restrict_poly's k + 1 points on a line (gkr-protocol/src/lib.rs:291-321), a verifier's oracle
+ * queries - pay one read of the table, one launch and one hand-off instead of m (batches of 16 points per launch; up to 4
+ * points the pass stays memory-bound, beyond it is bound by the 2 m multiply-accumulates per 16 bytes).  Works on sharded
+ * contexts and multi-device handles like sc_table_evaluate. */
+int sc_table_evaluate_many(sc_ctx* ctx, const sc_table* t, const uint64_t* points, size_t m, size_t n, int order, uint64_t* out);
 /* DenseMultilinearExtension::relabel(a, b, k) (matrix-multiplication/src/lib.rs:82) */
 int sc_table_relabel(sc_ctx* ctx, const sc_table* in, size_t a, size_t b, size_t k, sc_table** out);
 
@@ -356,9 +362,10 @@ int sc_gkr_prover_destroy(sc_gkr_prover* pr);
 
 /* restrict_poly (gkr-protocol/src/lib.rs:291-321): the univariate
  * q(t) = W~(l(t)) for the line l(0) = b, l(1) = c (`line`, :278-289), as dense coefficients
- * out_coeffs[0..k] (degree <= k = number of variables).  Computed as k+1 streaming evaluations
- * at t = 0..k plus exact interpolation on the host, instead of the reference's O(k 2^k) product
- * of linear factors; needs p > k.  The reference returns a SparsePolynomial: drop zero terms. */
+ * out_coeffs[0..k] (degree <= k = number of variables).  Computed as the evaluations at t = 0..k - ONE
+ * pass over the table for all k + 1 points (sc_table_evaluate_many) - plus exact interpolation on the host, instead
+ * of the reference's O(k 2^k) product of linear factors; needs p > k.  Sharded contexts and multi-device handles: t is
+ * split by its top index bits like every table there.  The reference returns a SparsePolynomial: drop zero terms. */
 int sc_table_restrict_to_line(sc_ctx* ctx, const sc_table* t, const uint64_t* b, const uint64_t* c, size_t k,
                               uint64_t* out_coeffs);
 

@@ -146,6 +146,8 @@ extern "C" {
         order: c_int,
         out: *mut u64,
     ) -> c_int;
+    /// `sc_table_evaluate` at `m` points (rows of `n` words) in one pass over the table
+    pub fn sc_table_evaluate_many(ctx: *mut sc_ctx, t: *const sc_table, points: *const u64, m: usize, n: usize, order: c_int, out: *mut u64) -> c_int;
     pub fn sc_table_relabel(
         ctx: *mut sc_ctx,
         input: *const sc_table,

@@ -1,0 +1,173 @@
+"""sc_table_evaluate_many: one table, m points, ONE pass - bit-exact against the oracle's evaluate for
+m = 1 .. 17 (and a batch boundary beyond 16), table sizes on both sides of the small / streaming kernels, LE and BE points,
+Goldilocks and the generic moduli, on sharded contexts (virtual ranks over host callbacks) and on a multi-device handle; and
+restrict_poly (gkr-protocol/src/lib.rs:291-321) rebuilt on it: the reference's [32, 385, 383] KAT, random lines vs pyref up to
+k = 17, one launch instead of k + 1."""
+import random
+import threading
+
+import numpy as np
+import pytest
+
+from conftest import load_package
+from util import GOLD, TOY_MODULI, load_golden, oracle, pid, pyref
+from test_gpu_sharded import Loopback
+
+pytestmark = pytest.mark.gpu
+
+
+def rand_mont(o, rng, p, shape):
+    return o.to_mont(rng.integers(0, p, size=int(np.prod(shape)), dtype=np.uint64)).reshape(shape)
+
+
+@pytest.mark.parametrize("p", [GOLD] + TOY_MODULI + [2**64 - 59], ids=pid)
+def test_evaluate_many_matches_oracle(p):
+    pkg = load_package()
+    o = oracle(p)
+    ctx = pkg.Context(pkg.Field(p))
+    rng = np.random.default_rng(21)
+    for n in (0, 1, 3, 7, 8, 9, 12, 14, 15, 18, 21):
+        t = rand_mont(o, rng, p, (1 << n,))
+        mle = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, t)
+        for m in ([1, 2, 3, 4, 5, 7, 8, 9, 13, 16, 17] if n in (7, 9, 14) else [2, 5, 17, 33]):
+            pts = rand_mont(o, rng, p, (m, max(n, 1)))[:, :n]
+            want = [o.evaluate(t, pts[j]) for j in range(m)]
+            assert mle.evaluate_many(pts) == want, (n, m, "LE")
+            if m in (3, 17) and n:
+                want_be = [o.vsbw(t, pts[j]) for j in range(m)]       # multilinear-extensions/src/lib.rs:6-24 (BE order)
+                assert mle.evaluate_many(pts, pkg.ORDER_BE) == want_be, (n, m, "BE")
+    assert mle.evaluate_many(np.zeros((0, 21), dtype=np.uint64)) == []
+    with pytest.raises(pkg.SumcheckHipError) as ei:
+        mle.evaluate_many(np.zeros((3, 20), dtype=np.uint64))
+    assert ei.value.code == 1
+    ctx.close()
+
+
+def test_evaluate_many_n24_against_single_evaluations():
+    """BASELINE config 2's size: 16 points in one pass == 16 single evaluations == the oracle for two of them; the launch
+    log shows ONE evaluate launch for the batch"""
+    pkg = load_package()
+    o = oracle(GOLD)
+    ctx = pkg.Context(pkg.Field(GOLD))
+    n = 24
+    t = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
+    rng = np.random.default_rng(3)
+    pts = rand_mont(o, rng, GOLD, (16, n))
+    ctx.set_option("time_kernels", 1)
+    ctx.launch_log(reset=True)
+    got = t.evaluate_many(pts)
+    log = ctx.launch_log(reset=True)
+    ctx.set_option("time_kernels", 0)
+    assert [(r["kind"], r["kf"], r["ks"]) for r in log] == [("evaluate", n, 16)]
+    assert got == [t.evaluate(pts[j]) for j in range(16)]
+    host = o.generate(pyref.SEED_A, n)
+    for j in (0, 15):
+        assert got[j] == o.evaluate(host, pts[j])
+    ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_evaluate_many_sharded_and_multi(world):
+    """virtual ranks over host callbacks (every rank gets every value), and the same table behind ONE multi-device handle"""
+    pkg = load_package()
+    import thaler_study_amd.distributed  # noqa: F401
+    o = oracle(GOLD)
+    rng = np.random.default_rng(world)
+    g = world.bit_length() - 1
+    for n in (g, g + 2, 11, 14):
+        t = rand_mont(o, rng, GOLD, (1 << n,))
+        pts = rand_mont(o, rng, GOLD, (7, n))
+        want = [o.evaluate(t, pts[j]) for j in range(7)]
+        want_be = [o.vsbw(t, pts[j]) for j in range(7)]
+        lb = Loopback(world)
+        got, errors = [None] * world, []
+
+        def body(rank):
+            try:
+                ctx = pkg.Context(pkg.Field(GOLD))
+                ar, ag = lb.collectives(rank)
+                ctx.comm_init_host(rank, world, ar, ag)
+                start, length = pkg.distributed.shard_range(n, rank, world)
+                mle = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n - g, t[start:start + length])
+                got[rank] = (mle.evaluate_many(pts), mle.evaluate_many(pts, pkg.ORDER_BE))
+                ctx.close()
+            except Exception as e:  # pragma: no cover
+                import traceback
+                traceback.print_exc()
+                errors.append(e)
+                lb.barrier.abort()
+
+        threads = [threading.Thread(target=body, args=(r,)) for r in range(world)]
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=300)
+        assert not errors, errors
+        for rank in range(world):
+            assert got[rank] == (want, want_be), (n, rank)
+        import torch
+        have = max(torch.cuda.device_count(), 1)
+        mctx = pkg.Context(pkg.Field(GOLD), devices=[d % have for d in range(world)])
+        mle = pkg.DenseMultilinearExtension.from_evaluations_vec(mctx, n, t)
+        assert mle.evaluate_many(pts) == want and mle.evaluate_many(pts, pkg.ORDER_BE) == want_be, n
+        # restrict_poly on the handle: the line through two of the points
+        b, c = [int(x) for x in pts[0]], [int(x) for x in pts[1]]
+        poly = pkg.gkr_protocol.restrict_poly(b, c, mle)
+        F = mctx.field
+        expect = pyref.restrict_poly(F.to_ints(b), F.to_ints(c), F.to_ints(t), GOLD)
+        dense = [0] * (n + 1)
+        for d, cf in poly.coeffs:
+            dense[d] = F.to_int(cf)
+        while len(dense) > 1 and dense[-1] == 0:
+            dense.pop()
+        assert dense == expect, n
+        mctx.close()
+
+
+def test_restrict_poly_is_one_pass_up_to_k17():
+    """[32, 385, 383] over F_389 (gkr-protocol/src/lib.rs:507-548) and random lines vs pyref for k up to 17 (m = 18 points: two
+    batches); at k = 13 - a GKR layer of the profiled size - the launch log holds ONE evaluate launch of 14 points"""
+    pkg = load_package()
+    gp = pkg.gkr_protocol
+    kat = load_golden("reference_kats.json")["restrict_poly_389"]
+    ctx = pkg.Context(pkg.Field(kat["p"]))
+    F = ctx.field
+    mle = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2, F.from_ints(kat["evals"]))
+    poly = gp.restrict_poly(F.from_ints(kat["b"]).tolist(), F.from_ints(kat["c"]).tolist(), mle)
+    dense = [0] * 3
+    for d, cf in poly.coeffs:
+        dense[d] = F.to_int(cf)
+    assert dense == kat["expected_coeffs"]
+    ctx.close()
+    rng = random.Random(12)
+    for q in (GOLD, 1572869):
+        ctx = pkg.Context(pkg.Field(q))
+        F = ctx.field
+        for k in (7, 8, 12, 13, 16, 17):
+            ev = [rng.randrange(q) for _ in range(1 << k)]
+            b = [rng.randrange(q) for _ in range(k)]
+            c = [rng.randrange(q) for _ in range(k)]
+            mle = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, k, F.from_ints(ev))
+            ctx.set_option("time_kernels", 1)
+            ctx.launch_log(reset=True)
+            poly = gp.restrict_poly(F.from_ints(b).tolist(), F.from_ints(c).tolist(), mle)
+            log = ctx.launch_log(reset=True)
+            ctx.set_option("time_kernels", 0)
+            got = [0] * (k + 1)
+            for d, cf in poly.coeffs:
+                got[d] = F.to_int(cf)
+            while len(got) > 1 and got[-1] == 0:
+                got.pop()
+            if k <= 13:
+                assert got == pyref.restrict_poly(b, c, ev, q), (q, k)
+            else:
+                # (the big-integer restatement is O(k^2 2^k)): q(t) == W~(b + t (c - b)) at t = 0, 1 and random t, by the oracle
+                o = oracle(q)
+                tm = o.to_mont(ev)
+                for tt in (0, 1, rng.randrange(q), rng.randrange(q)):
+                    pt = o.to_mont([(bi + tt * (ci - bi)) % q for bi, ci in zip(b, c)])
+                    val = sum(cf * pow(tt, d, q) for d, cf in enumerate(got)) % q
+                    assert val == o.from_mont1(o.evaluate(tm, pt)), (q, k, tt)
+            if k == 13:
+                assert [(r["kind"], r["ks"]) for r in log] == [("evaluate", 14)], log
+        ctx.close()

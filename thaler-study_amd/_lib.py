@@ -83,6 +83,7 @@ SIGNATURES = {
     "sc_table_free": (ctypes.c_int, [voidp, voidp]),
     "sc_table_fix_variables": (ctypes.c_int, [voidp, voidp, u64p, size_t, ctypes.c_int, ctypes.POINTER(voidp)]),
     "sc_table_evaluate": (ctypes.c_int, [voidp, voidp, u64p, size_t, ctypes.c_int, u64p]),
+    "sc_table_evaluate_many": (ctypes.c_int, [voidp, voidp, u64p, size_t, size_t, ctypes.c_int, u64p]),
     "sc_table_relabel": (ctypes.c_int, [voidp, voidp, size_t, size_t, size_t, ctypes.POINTER(voidp)]),
     "sc_matmul_g_new": (ctypes.c_int, [voidp, voidp, voidp, size_t, u64p, ctypes.POINTER(voidp), ctypes.POINTER(voidp)]),
     "sc_prod2_to_evaluations": (ctypes.c_int, [voidp, voidp, voidp, ctypes.POINTER(voidp)]),

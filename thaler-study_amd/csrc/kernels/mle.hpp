@@ -236,6 +236,152 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
   finish_pass<F, 1>(f, out, res[0], &lds_flag);
 }
 
+// Polynomial::evaluate of ONE table at M points in ONE streaming pass (round 4): m separate evaluations read the table m
+// times and pay m launches and m hand-offs - restrict_poly's k + 1 points on a line (gkr-protocol/src/lib.rs:291-321), the
+// verifier's oracle queries.  Same factoring of eq(r, i) as evaluate_kernel, per point j:
+//   E[j][tile bits | bit 0] (LDS, built per block from half tables), lane weights L[j][lane] (LDS), segment weight (per chunk).
+// A lane keeps ONE lazy accumulator per point - both entries of its 16-byte piece go into it, each with its own weight
+// (bit 0 is an index of E) - and one outer residue per point; a piece costs 2 M multiply-accumulates, so the pass is
+// memory-bound up to M = 4 and bound by instruction issue beyond (M = 16: ~1 TB/s of table, which is still 16 evaluations
+// for the price of ~5).  pts: M points of n words each in device memory (point j at pts + 64 j); w_extra[j]: the weight
+// of this rank's bits at point j (1 unless sharded).  Sums leave through finish_pass as M values.
+constexpr int kEvalManyTa = 7;   // at most 2^7 tiles per segment: E is M x 256 words
+struct EvalManyW {
+  u64 w[16];
+};
+template <class F, int M, bool NT>
+__global__ void __launch_bounds__(kBlock)
+evaluate_many_kernel(F f, const u64* __restrict__ T, int n, const u64* __restrict__ pts, int ta, int chunk_log, EvalManyW wx, PassOut out) {
+  constexpr int kWaves = kBlock / kWave;
+  __shared__ __attribute__((aligned(16))) u64 E[M][2 << kEvalManyTa];   // E[j][2 t + b]: weight of entry b of the piece in tile t of a segment
+  __shared__ u64 L[M][kWave];
+  __shared__ u64 H[M][3][16];              // half tables: [0] bits 0..3 of E's index, [1] bits 4..7, [2] unused / lane halves
+  __shared__ u64 R[M][64];                 // the points
+  __shared__ u64 lds[kWaves * M];
+  __shared__ int lds_flag;
+  __shared__ unsigned lds_next;
+  const int lane = threadIdx.x & (kWave - 1);
+  const int tb = n - 7 - ta, ebits = ta + 1;
+  if (threadIdx.x == 0) lds_next = 0;
+  for (int i = threadIdx.x; i < M * 64; i += kBlock) R[i >> 6][i & 63] = ((i & 63) < n) ? pts[i] : 0;
+  __syncthreads();
+  // E's index bits, low to high: bit 0 of the table index (variable 0), then the tile-in-segment bits (variables 7 .. 7+ta-1)
+  auto evar = [&](int j, int q) -> u64 { return q == 0 ? R[j][0] : R[j][7 + q - 1]; };
+  const int lo_bits = ebits < 4 ? ebits : 4, hi_bits = ebits - lo_bits;
+  for (int i = threadIdx.x; i < M * 32; i += kBlock) {
+    const int j = i >> 5, half = (i >> 4) & 1, e = i & 15;
+    const int nb = half ? hi_bits : lo_bits, off = half ? lo_bits : 0;
+    u64 w = f.one();
+    for (int q = 0; q < nb; ++q) {
+      const u64 rq = evar(j, off + q);
+      w = f.mul(w, ((e >> q) & 1) ? rq : f.sub(f.one(), rq));
+    }
+    H[j][half][e] = w;
+  }
+  // lane weights: variables 1..6, as products of two 8-entry halves
+  for (int i = threadIdx.x; i < M * 16; i += kBlock) {
+    const int j = i >> 4, half = (i >> 3) & 1, e = i & 7;
+    u64 w = f.one();
+    for (int q = 0; q < 3; ++q) {
+      const u64 rq = R[j][1 + 3 * half + q];
+      w = f.mul(w, ((e >> q) & 1) ? rq : f.sub(f.one(), rq));
+    }
+    H[j][2][8 * half + e] = w;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < (M << ebits); i += kBlock) {
+    const int j = i >> ebits, e = i & ((1 << ebits) - 1);
+    E[j][e] = f.mul(H[j][0][e & ((1 << lo_bits) - 1)], H[j][1][e >> lo_bits]);
+  }
+  for (int i = threadIdx.x; i < M * kWave; i += kBlock) {
+    const int j = i >> 6, l = i & 63;
+    L[j][l] = f.mul(f.mul(H[j][2][l & 7], H[j][2][8 + (l >> 3)]), wx.w[j]);
+  }
+  __syncthreads();
+  auto next_chunk = [&]() -> size_t {
+    unsigned c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
+  };
+  const ull2* __restrict__ Tp = reinterpret_cast<const ull2*>(T);
+  const size_t n_tiles = (size_t)1 << (n - 7), n_chunks = n_tiles >> chunk_log;
+  const int C = 1 << chunk_log;
+  u64 o[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) o[j] = 0;
+  for (size_t chunk = next_chunk(); chunk < n_chunks; chunk = next_chunk()) {
+    const size_t tile0 = chunk << chunk_log, seg = tile0 >> ta;
+    const int in_seg = (int)(tile0 & (((size_t)1 << ta) - 1));
+    typename F::Acc a[M];
+#pragma unroll
+    for (int j = 0; j < M; ++j) f.acc_zero(a[j]);
+    constexpr int B = 4;   // pieces in flight per lane
+    int i = 0;
+    for (; i + B <= C; i += B) {   // fixed-count inner loops: see evaluate_kernel
+      ull2 p[B];
+#pragma unroll
+      for (int k = 0; k < B; ++k) p[k] = ld16<NT>(Tp + (tile0 + i + k) * kWave + lane);
+#pragma unroll
+      for (int k = 0; k < B; ++k) {
+#pragma unroll
+        for (int j = 0; j < M; ++j) {
+          const ull2 w = *reinterpret_cast<const ull2*>(&E[j][2 * (in_seg + i + k)]);
+          f.acc_mac(a[j], p[k].x, w.x);
+          f.acc_mac(a[j], p[k].y, w.y);
+        }
+      }
+    }
+    for (; i < C; ++i) {
+      const ull2 p = ld16<NT>(Tp + (tile0 + i) * kWave + lane);
+#pragma unroll
+      for (int j = 0; j < M; ++j) {
+        const ull2 w = *reinterpret_cast<const ull2*>(&E[j][2 * (in_seg + i)]);
+        f.acc_mac(a[j], p.x, w.x);
+        f.acc_mac(a[j], p.y, w.y);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < M; ++j) {
+      u64 wB = f.one();   // segment weight, wave-uniform
+      for (int q = 0; q < tb; ++q) {
+        const u64 rq = R[j][7 + ta + q];
+        wB = f.mul(wB, ((seg >> q) & 1) ? rq : f.sub(f.one(), rq));
+      }
+      o[j] = f.add(o[j], f.mul(f.acc_get(a[j]), wB));
+    }
+  }
+  u64 res[M];
+#pragma unroll
+  for (int j = 0; j < M; ++j) res[j] = f.mul(o[j], L[j][lane]);
+  block_reduce<F, M>(f, res, lds);
+  finish_pass<F, M>(f, out, res[0], &lds_flag);
+}
+// the same for a table of fewer than 2^8 entries: one block, a wave per point (lane = entry)
+template <class F, int M>
+__global__ void __launch_bounds__(kBlock)
+evaluate_many_small_kernel(F f, const u64* __restrict__ T, int n, const u64* __restrict__ pts, EvalManyW wx, PassOut out) {
+  __shared__ u64 val[M];
+  __shared__ int lds_flag;
+  const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+  const size_t len = (size_t)1 << n;
+  for (int j = wave; j < M; j += kBlock / kWave) {
+    u64 v = 0;
+    for (size_t i = lane; i < len; i += kWave) {
+      u64 w = T[i];
+      for (int q = 0; q < n; ++q) {
+        const u64 rq = pts[64 * j + q];
+        w = f.mul(w, ((i >> q) & 1) ? rq : f.sub(f.one(), rq));
+      }
+      v = f.add(v, w);
+    }
+#pragma unroll
+    for (int off = kWave / 2; off >= 1; off >>= 1) v = f.add(v, shfl_down_u64(v, off));
+    if (lane == 0) val[j] = f.mul(v, wx.w[j]);
+  }
+  __syncthreads();
+  finish_pass<F, M>(f, out, threadIdx.x < M ? val[threadIdx.x] : 0, &lds_flag);
+}
+
 // LE fix of the LOW k variables (8 <= k <= 17) in ONE pass: out[b] = sum_c eq(r, c) * t[b*2^k + c],
 // i.e. evaluate_kernel's inner product on every contiguous segment of 2^k entries, one wave per
 // segment (coalesced 1 KiB wave loads, tile weights eqA in LDS, bit-0 and lane weights applied

@@ -198,6 +198,9 @@ struct sc_ctx {
   u64* h_tail = nullptr;
   u64* d_tail = nullptr;
   std::vector<int> tail_free;
+  // sc_table_evaluate_many: the points of one launch (16 x 64 words), pinned staging and its device copy (allocated on first use)
+  u64* h_points = nullptr;
+  u64* d_points = nullptr;
 
   // kernel timing
   // pass-kernel timing (option "time_kernels"): a ring of event pairs, read back only when the

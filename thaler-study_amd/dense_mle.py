@@ -216,6 +216,16 @@ class DenseMultilinearExtension:
                                                      ctypes.byref(out)))
         return int(out.value)
 
+    def evaluate_many(self, points, order=_lib.ORDER_LE):
+        """evaluate at every point of `points` (m rows of num_vars words) in one pass over the table"""
+        pts = np.ascontiguousarray(np.array([[int(x) for x in row] for row in points], dtype=np.uint64))
+        m = pts.shape[0]
+        n = pts.shape[1] if m else 0
+        out = np.zeros(max(m, 1), dtype=np.uint64)
+        self.ctx.check(self.ctx.lib.sc_table_evaluate_many(self.ctx.h, self.h, _u64p(pts.reshape(-1)) if pts.size else None, m, n, order,
+                                                          _u64p(out)))
+        return [int(x) for x in out[:m]]
+
     def relabel(self, a, b, k):
         h = voidp()
         self.ctx.check(self.ctx.lib.sc_table_relabel(self.ctx.h, self.h, a, b, k, ctypes.byref(h)))
