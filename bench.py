@@ -347,6 +347,42 @@ def time_plane(args, pkg, torch, dist, rank, world, local_rank, plane, n):
         err = "tables: %s" % e
 
     barrier()                                 # the ranks enter every proof together (peer_spin_ms bounds their skew)
+    # ---- setup, untimed: bring the device to its steady clocks -------------------------------------------------------------
+    # An MI355X that has idled for as little as 50 ms runs its first ~10-20 proofs below its steady clocks: the VALU-bound first
+    # pass takes 770-815 us instead of 665-680 and a proof 1.92-2.00 ms instead of 1.81 (profiles/r04_clock_ramp.txt).  A run of
+    # W = 5 + K = 20 proofs (46 ms) is over before the ramp is, so its number was a property of the power state the run began
+    # in, not of the kernels.  Like the reference's own harness (criterion warms up for 3 s before it samples:
+    # matrix-multiplication/benches/mm_benchmark.rs), the bench first keeps the device busy for SC_BENCH_RAMP_MS (default 80 ms)
+    # with the workload itself - setup, before the W warm-up steps, reported in config.clock_ramp with the COLD figure beside
+    # it.  Every rank runs the same number of proofs (the count is agreed through the control plane).
+    ramp = None
+    ramp_ms = float(os.environ.get("SC_BENCH_RAMP_MS", "80"))
+    if ramp_ms > 0:
+        cold = 0.0
+        if working and err is None:
+            try:
+                tr = time.perf_counter()
+                mm.prove(ctx, g, syn.SEED_R)
+                mm.prove(ctx, g, syn.SEED_R)
+                cold = (time.perf_counter() - tr) / 2 * 1e3
+            except pkg.SumcheckHipError as e:
+                err = "failed while proving (clock ramp): %s" % e
+        est = cold
+        if dist is not None:
+            t = torch.tensor([est], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            est = float(t.item())
+        count = min(4000, int(ramp_ms / est) + 1) if est > 0 else 0
+        if working and err is None:
+            try:
+                for _ in range(count):
+                    mm.prove(ctx, g, syn.SEED_R)
+            except pkg.SumcheckHipError as e:
+                err = "failed while proving (clock ramp): %s" % e
+        ramp = {"untimed_ms": ramp_ms, "proofs": count + 2, "cold_ms_per_proof": cold,
+                "note": "setup before the W warm-up steps: the workload itself, run until the device is at its steady clocks "
+                        "(SC_BENCH_RAMP_MS=0 switches it off); cold_ms_per_proof = the first two proofs after the idle setup phase"}
+        barrier()
     if working and err is None:
         try:
             for _ in range(args.warmup):      # exactly W untimed steps
@@ -405,7 +441,7 @@ def time_plane(args, pkg, torch, dist, rank, world, local_rank, plane, n):
         raise SystemExit("PARITY FAILURE at n=%d (%s): %s" % (n, label, problem))
     return {"ok": True, "plane": plane, "label": label, "ctx": ctx, "tables": (a, b, g), "elapsed": elapsed, "step_ms": step_ms,
             "n_launch": n_launch, "kernel_ms": kernel_ms, "log": log, "steps_with_events": steps_with_events,
-            "timed_every": timed_every, "comm_nranks": comm_nranks, "transcript": (c1, evals.tobytes())}
+            "timed_every": timed_every, "comm_nranks": comm_nranks, "transcript": (c1, evals.tobytes()), "ramp": ramp}
 
 
 def run_prover(args, pkg, torch, dist, rank, world, local_rank):
@@ -524,6 +560,7 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                 # the fastest); comm_nranks = the ranks the plane spans as the transport reports it (ncclCommCount for RCCL)
                 "transports": transports,
                 "options": dict(context_options()), "schedule": schedule,
+                "clock_ramp": best.get("ramp"),
                 "ms_per_step_median_unsampled": statistics.median(unsampled) if unsampled else None,
             },
             "roofline": {
@@ -678,6 +715,31 @@ def run_mle(args, pkg, torch, dist, rank, world, local_rank):
             raise SystemExit("PARITY FAILURE: fix_variables(k=%d) then evaluate != evaluate at n=%d" % (k, n))
     parity.append("fix(k) o evaluate == evaluate at n=%d" % n)
 
+    # several points per pass (sc_table_evaluate_many; outside the timed steps, own HIP-event timing): what ONE evaluation costs
+    # when m of them share a read of the table - the amortisation VERDICT r03 asked for beside the ~0.6 ceiling of a single
+    # n = 24 evaluate, whose launch carries ~8-10 us that do not shrink with the table
+    many = []
+    rngp = np.random.default_rng(9)
+    for m_pts in (1, 2, 4, 8, 16):
+        pts_m = [[int(o.challenge(syn.SEED_PT + 31 * j, i)) for i in range(n)] for j in range(m_pts)]
+        t.evaluate_many(pts_m)
+        ctx.set_option("time_kernels", 1)
+        ctx.launch_log(reset=True)
+        reps_m = 10
+        tw = time.perf_counter()
+        for _ in range(reps_m):
+            vals = t.evaluate_many(pts_m)
+        wall_us = (time.perf_counter() - tw) / reps_m * 1e6
+        lg = [r for r in ctx.launch_log(reset=True) if r["kind"] == "evaluate"]
+        ctx.set_option("time_kernels", 0)
+        if vals[0] != t.evaluate(pts_m[0], pkg.ORDER_LE) or vals[-1] != t.evaluate(pts_m[-1], pkg.ORDER_LE):
+            raise SystemExit("PARITY FAILURE: evaluate_many(m=%d) differs from single evaluations at n=%d" % (m_pts, n))
+        us = statistics.median(r["ms"] for r in lg) * 1e3
+        many.append({"points": m_pts, "launch_us": us, "us_per_point": us / m_pts, "wall_us_per_call": wall_us,
+                     "table_GBps": 8 * 2**n / (us * 1e-6) / 1e9,
+                     "frac_of_peak_per_point": m_pts * 8 * 2**n / (us * 1e-6) / 1e9 / HBM_PEAK_GBS})
+    parity.append("evaluate_many(m = 1, 2, 4, 8, 16) == single evaluations at n=%d" % n)
+
     tkey = "mle_n%d" % n
     tj = load_traffic(tkey)
     traffic = None
@@ -702,6 +764,9 @@ def run_mle(args, pkg, torch, dist, rank, world, local_rank):
                         "table (BASELINE configs[1])" % n,
             "num_vars": n,
             "ops": [name for name, _ in ops],
+            "evaluate_many": {"rows": many, "note": "sc_table_evaluate_many: m points in ONE pass over the table (not part of the "
+                              "timed step); frac_of_peak_per_point credits every point with a full read of the table - what m single "
+                              "evaluations would have to reach to match - so it may exceed 1"},
             "field_mul_adds_per_step": muladds,
             "algorithmic_bytes_per_step": alg_bytes,
             "parity_gate": "; ".join(parity),

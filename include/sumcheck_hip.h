@@ -199,6 +199,10 @@ int sc_ctx_comm_rank(const sc_ctx* ctx, int* rank, int* world);
 
 /* DenseMultilinearExtension::from_evaluations_vec (matrix-multiplication/src/lib.rs:81,85) */
 int sc_table_upload(sc_ctx* ctx, const uint64_t* host, size_t len, sc_table** out);
+/* The same over device memory the caller already owns (its own kernels' output, another library's buffer, a mapping it made
+ * with the HIP virtual-memory API): zero-copy and BORROWED - never written, never freed by the library (sc_table_free drops
+ * the handle only); it must stay valid, and unchanged, while any table or prover made from it lives.  16-byte aligned. */
+int sc_table_from_device(sc_ctx* ctx, const uint64_t* device_ptr, size_t len, sc_table** out);
 /* Synthetic fill on the device:
  * t[i] = to_mont(splitmix64(seed + start + i) mod p), i < len. */
 int sc_table_generate(sc_ctx* ctx, uint64_t seed, uint64_t start, size_t len, sc_table** out);

@@ -124,6 +124,8 @@ extern "C" {
     pub fn sc_ctx_comm_rank(ctx: *const sc_ctx, rank: *mut c_int, world: *mut c_int) -> c_int;
 
     pub fn sc_table_upload(ctx: *mut sc_ctx, host: *const u64, len: usize, out: *mut *mut sc_table) -> c_int;
+    /// a table over device memory the caller owns (borrowed: never written, never freed by the library)
+    pub fn sc_table_from_device(ctx: *mut sc_ctx, device_ptr: *const u64, len: usize, out: *mut *mut sc_table) -> c_int;
     pub fn sc_table_generate(ctx: *mut sc_ctx, seed: u64, start: u64, len: usize, out: *mut *mut sc_table) -> c_int;
     pub fn sc_table_clone(ctx: *mut sc_ctx, t: *const sc_table, out: *mut *mut sc_table) -> c_int;
     pub fn sc_table_download(ctx: *mut sc_ctx, t: *const sc_table, host: *mut u64, len: usize) -> c_int;

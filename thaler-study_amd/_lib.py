@@ -75,6 +75,7 @@ SIGNATURES = {
     "sc_ctx_comm_peer_connect_local": (ctypes.c_int, [voidp, ctypes.POINTER(voidp)]),
     "sc_ctx_comm_rank": (ctypes.c_int, [voidp, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int)]),
     "sc_table_upload": (ctypes.c_int, [voidp, u64p, size_t, ctypes.POINTER(voidp)]),
+    "sc_table_from_device": (ctypes.c_int, [voidp, voidp, size_t, ctypes.POINTER(voidp)]),
     "sc_table_generate": (ctypes.c_int, [voidp, u64, u64, size_t, ctypes.POINTER(voidp)]),
     "sc_table_clone": (ctypes.c_int, [voidp, voidp, ctypes.POINTER(voidp)]),
     "sc_table_download": (ctypes.c_int, [voidp, voidp, u64p, size_t]),

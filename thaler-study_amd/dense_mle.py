@@ -171,6 +171,15 @@ class DenseMultilinearExtension:
         return cls(ctx, h)
 
     @classmethod
+    def from_device(cls, ctx, device_ptr, num_vars, keep=None):
+        """a table over device memory the caller owns (borrowed; `keep`: whatever must stay alive with it, e.g. a torch tensor)"""
+        h = voidp()
+        ctx.check(ctx.lib.sc_table_from_device(ctx.h, voidp(int(device_ptr)), 1 << num_vars, ctypes.byref(h)))
+        t = cls(ctx, h)
+        t._keep = keep
+        return t
+
+    @classmethod
     def generate(cls, ctx, seed, num_vars, start=0):
         h = voidp()
         ctx.check(ctx.lib.sc_table_generate(ctx.h, seed, start, 1 << num_vars, ctypes.byref(h)))
