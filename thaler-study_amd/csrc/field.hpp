@@ -97,12 +97,75 @@ struct MontGeneric {
     return (a < b) ? d + p : d;
   }
   SC_HD u64 dbl(u64 a) const { return add(a, a); }
+  // Four independent differences d[k] = a[k] - b[k] (mod p), the four borrow chains interleaved by hand as in
+  // GoldilocksMont::sub4: per chain a 64-bit subtract (borrow in an SGPR pair), p masked by the borrow (two v_cndmask),
+  // a 64-bit add - 6 VALU per difference, every carry consumer four slots behind its producer, no s_nop; the compiler's
+  // own sequence for `a < b ? a - b + p : a - b` is 7 instructions + 2-4 wait states.  (p sits in two VGPRs: a VOP3
+  // instruction of this ISA reads one scalar operand, and the mask is it.)
   SC_HD void sub4(X64 (&d)[4], const X64 (&a)[4], const X64 (&b)[4]) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 p0 = (u32)p, p1 = (u32)(p >> 32);
+    u32 t0, t1, t2, t3, t4, t5, t6, t7;
+    asm("v_sub_co_u32_e64 %0, vcc, %16, %24\n\t"
+        "v_sub_co_u32_e64 %1, s[72:73], %17, %25\n\t"
+        "v_sub_co_u32_e64 %2, s[74:75], %18, %26\n\t"
+        "v_sub_co_u32_e64 %3, s[76:77], %19, %27\n\t"
+        "v_subb_co_u32_e64 %4, vcc, %20, %28, vcc\n\t"
+        "v_subb_co_u32_e64 %5, s[72:73], %21, %29, s[72:73]\n\t"
+        "v_subb_co_u32_e64 %6, s[74:75], %22, %30, s[74:75]\n\t"
+        "v_subb_co_u32_e64 %7, s[76:77], %23, %31, s[76:77]\n\t"
+        "v_cndmask_b32_e64 %8, 0, %32, vcc\n\t"
+        "v_cndmask_b32_e64 %9, 0, %32, s[72:73]\n\t"
+        "v_cndmask_b32_e64 %10, 0, %32, s[74:75]\n\t"
+        "v_cndmask_b32_e64 %11, 0, %32, s[76:77]\n\t"
+        "v_cndmask_b32_e64 %12, 0, %33, vcc\n\t"
+        "v_cndmask_b32_e64 %13, 0, %33, s[72:73]\n\t"
+        "v_cndmask_b32_e64 %14, 0, %33, s[74:75]\n\t"
+        "v_cndmask_b32_e64 %15, 0, %33, s[76:77]\n\t"
+        "v_add_co_u32_e64 %0, vcc, %0, %8\n\t"
+        "v_add_co_u32_e64 %1, s[72:73], %1, %9\n\t"
+        "v_add_co_u32_e64 %2, s[74:75], %2, %10\n\t"
+        "v_add_co_u32_e64 %3, s[76:77], %3, %11\n\t"
+        "v_addc_co_u32_e64 %4, vcc, %4, %12, vcc\n\t"
+        "v_addc_co_u32_e64 %5, s[72:73], %5, %13, s[72:73]\n\t"
+        "v_addc_co_u32_e64 %6, s[74:75], %6, %14, s[74:75]\n\t"
+        "v_addc_co_u32_e64 %7, s[76:77], %7, %15, s[76:77]"
+        : "=&v"(d[0].lo), "=&v"(d[1].lo), "=&v"(d[2].lo), "=&v"(d[3].lo), "=&v"(d[0].hi), "=&v"(d[1].hi),
+          "=&v"(d[2].hi), "=&v"(d[3].hi), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+        : "v"(a[0].lo), "v"(a[1].lo), "v"(a[2].lo), "v"(a[3].lo), "v"(a[0].hi), "v"(a[1].hi), "v"(a[2].hi),
+          "v"(a[3].hi), "v"(b[0].lo), "v"(b[1].lo), "v"(b[2].lo), "v"(b[3].lo), "v"(b[0].hi), "v"(b[1].hi),
+          "v"(b[2].hi), "v"(b[3].hi), "v"(p0), "v"(p1)
+        : "vcc", "s72", "s73", "s74", "s75", "s76", "s77");
+#else
     for (int k = 0; k < 4; ++k) d[k] = split64(sub(join64(a[k]), join64(b[k])));
+#endif
   }
   SC_HD X64 sub(X64 a, X64 b) const { return split64(sub(join64(a), join64(b))); }
   SC_HD void sub2(X64 (&d)[2], const X64 (&a)[2], const X64 (&b)[2]) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const u32 p0 = (u32)p, p1 = (u32)(p >> 32);
+    u32 t0, t1, t2, t3;
+    asm("v_sub_co_u32_e64 %0, vcc, %8, %12\n\t"
+        "v_sub_co_u32_e64 %1, s[72:73], %9, %13\n\t"
+        "s_nop 0\n\t"
+        "v_subb_co_u32_e64 %2, vcc, %10, %14, vcc\n\t"
+        "v_subb_co_u32_e64 %3, s[72:73], %11, %15, s[72:73]\n\t"
+        "s_nop 0\n\t"
+        "v_cndmask_b32_e64 %4, 0, %16, vcc\n\t"
+        "v_cndmask_b32_e64 %5, 0, %16, s[72:73]\n\t"
+        "v_cndmask_b32_e64 %6, 0, %17, vcc\n\t"
+        "v_cndmask_b32_e64 %7, 0, %17, s[72:73]\n\t"
+        "v_add_co_u32_e64 %0, vcc, %0, %4\n\t"
+        "v_add_co_u32_e64 %1, s[72:73], %1, %5\n\t"
+        "s_nop 0\n\t"
+        "v_addc_co_u32_e64 %2, vcc, %2, %6, vcc\n\t"
+        "v_addc_co_u32_e64 %3, s[72:73], %3, %7, s[72:73]"
+        : "=&v"(d[0].lo), "=&v"(d[1].lo), "=&v"(d[0].hi), "=&v"(d[1].hi), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+        : "v"(a[0].lo), "v"(a[1].lo), "v"(a[0].hi), "v"(a[1].hi), "v"(b[0].lo), "v"(b[1].lo), "v"(b[0].hi), "v"(b[1].hi), "v"(p0), "v"(p1)
+        : "vcc", "s72", "s73");
+#else
     for (int k = 0; k < 2; ++k) d[k] = split64(sub(join64(a[k]), join64(b[k])));
+#endif
   }
 
   // (hi:lo) < p * 2^64  ->  (hi:lo) * 2^-64 mod p

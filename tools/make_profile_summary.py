@@ -14,6 +14,7 @@ import sys
 
 tag, workload, d_stats, d_fetch, d_write, bench_json = sys.argv[1:7]
 n = int(sys.argv[7]) if len(sys.argv) > 7 else (28 if workload == "prover" else 24)
+FIELD = sys.argv[8] if len(sys.argv) > 8 else "GoldilocksMont"      # the field policy of the kernels (MontGeneric: bench.py --field generic)
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 P = os.path.join(ROOT, "profiles")
 os.makedirs(P, exist_ok=True)
@@ -102,6 +103,10 @@ assert len(fetch) == len(last) == len(write), (len(fetch), len(last), len(write)
 
 
 def bench_name(kind, kf, ks, log_in):
+    return _bench_name(kind, kf, ks, log_in).replace("GoldilocksMont", FIELD)
+
+
+def _bench_name(kind, kf, ks, log_in):
     if kind == "pass":
         return "sc::pass_kernel<GoldilocksMont,%d,%d> on 2^%d-entry tables" % (kf, ks, log_in)
     if kind == "grid_pass":
@@ -116,7 +121,8 @@ def bench_name(kind, kf, ks, log_in):
 
 
 lines = []
-cmd = "python3 bench.py --steps 10 --warmup 2 --cpu-num-vars 0" + (" --workload mle --num-vars %d" % n if workload == "mle" else "")
+cmd = "python3 bench.py --steps 10 --warmup 2 --cpu-num-vars 0" + (" --workload mle --num-vars %d" % n if workload == "mle" else "") + (
+    " --field generic" if FIELD != "GoldilocksMont" else "") + "  (SC_BENCH_RAMP_MS=0 exported: the profiled runs skip bench.py's clock-ramp setup phase)"
 lines.append("# %s: rocprofv3 summary, %s workload, n=%d, 1 x MI355X\n" % (tag, workload, n))
 lines.append("Command (on the GPU box): `rocprofv3 --kernel-trace --stats --output-format csv -- %s`;" % cmd)
 lines.append("counters from two more runs of the same command with `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (+ `--kernel-trace`), `--steps 2 --warmup 1`.\n")
@@ -174,7 +180,7 @@ tj_path = os.path.join(P, "traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
 if workload == "prover":
     first = describe(last[0]["Kernel_Name"])[2]
-    key = "n%d_gpus1_vpp2_first%d" % (n, first)
+    key = "n%d_gpus1_vpp2_first%d" % (n, first) + ("" if FIELD == "GoldilocksMont" else "_generic")
 else:
     key = "mle_n%d" % n
 tj[key] = {
