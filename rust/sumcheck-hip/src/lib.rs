@@ -282,6 +282,28 @@ impl<T: MontConfig<1>> DeviceMle<T> {
     fn from_raw(ctx: &Context<T>, h: *mut sys::sc_table) -> Self {
         Self { ctx: ctx.clone(), h }
     }
+    /// The table at every point of `points` in ONE pass over it (`sc_table_evaluate_many`): a verifier's several oracle
+    /// queries, or the k + 1 points of `restrict_to_line`, for one read of the table.
+    pub fn evaluate_many(&self, points: &[Vec<F64<T>>]) -> Vec<F64<T>> {
+        let n = self.num_vars();
+        let flat: Vec<u64> = points.iter().flat_map(|p| { assert_eq!(p.len(), n); words::<T>(p) }).collect();
+        let mut out = vec![0u64; points.len()];
+        let rc = unsafe {
+            sys::sc_table_evaluate_many(self.ctx.raw(), self.h, flat.as_ptr(), points.len(), n, sys::SC_ORDER_LE, out.as_mut_ptr())
+        };
+        self.ctx.check(rc, "sc_table_evaluate_many");
+        out.into_iter().map(from_word::<T>).collect()
+    }
+    /// A table over device memory the caller owns (`sc_table_from_device`): borrowed, never written or freed by the library.
+    /// # Safety
+    /// `device_ptr` must point to `1 << num_vars` Montgomery words in device memory that outlive the returned table and
+    /// everything made from it, and must not change while they are in use.
+    pub unsafe fn from_device(ctx: &Context<T>, device_ptr: *const u64, num_vars: usize) -> Self {
+        let mut h = ptr::null_mut();
+        let rc = sys::sc_table_from_device(ctx.raw(), device_ptr, 1usize << num_vars, &mut h);
+        ctx.check(rc, "sc_table_from_device");
+        Self::from_raw(ctx, h)
+    }
     /// `restrict_poly(b, c, &mle)` (gkr-protocol/src/lib.rs:291-321): the MLE on the line l(0) = b, l(1) = c.
     pub fn restrict_to_line(&self, b: &[F64<T>], c: &[F64<T>]) -> SparsePolynomial<F64<T>> {
         let k = self.num_vars();

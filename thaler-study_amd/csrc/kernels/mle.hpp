@@ -242,8 +242,7 @@ evaluate_kernel(F f, const u64* __restrict__ T, int n, RVec rv, int ta, int chun
 //   E[j][tile bits | bit 0] (LDS, built per block from half tables), lane weights L[j][lane] (LDS), segment weight (per chunk).
 // A lane keeps ONE lazy accumulator per point - both entries of its 16-byte piece go into it, each with its own weight
 // (bit 0 is an index of E) - and one outer residue per point; a piece costs 2 M multiply-accumulates, so the pass is
-// memory-bound up to M = 4 and bound by instruction issue beyond (M = 16: ~1 TB/s of table, which is still 16 evaluations
-// for the price of ~5).  pts: M points of n words each in device memory (point j at pts + 64 j); w_extra[j]: the weight
+// bound by instruction issue, not by the table's bytes: what is amortised is the read, the launch and the hand-off.  pts: M points of n words each in device memory (point j at pts + 64 j); w_extra[j]: the weight
 // of this rank's bits at point j (1 unless sharded).  Sums leave through finish_pass as M values.
 constexpr int kEvalManyTa = 7;   // at most 2^7 tiles per segment: E is M x 256 words
 struct EvalManyW {
@@ -312,9 +311,11 @@ evaluate_many_kernel(F f, const u64* __restrict__ T, int n, const u64* __restric
   for (size_t chunk = next_chunk(); chunk < n_chunks; chunk = next_chunk()) {
     const size_t tile0 = chunk << chunk_log, seg = tile0 >> ta;
     const int in_seg = (int)(tile0 & (((size_t)1 << ta) - 1));
-    typename F::Acc a[M];
+    // the three-class accumulator (eight instructions per multiply-accumulate, nine registers) instead of the four-register
+    // lazy sum (fifteen): with 2 M products per piece the pass is bound by instruction issue, and M accumulators fit
+    typename F::Acc3 a[M];
 #pragma unroll
-    for (int j = 0; j < M; ++j) f.acc_zero(a[j]);
+    for (int j = 0; j < M; ++j) f.acc3_zero(a[j]);
     constexpr int B = 4;   // pieces in flight per lane
     int i = 0;
     for (; i + B <= C; i += B) {   // fixed-count inner loops: see evaluate_kernel
@@ -326,8 +327,8 @@ evaluate_many_kernel(F f, const u64* __restrict__ T, int n, const u64* __restric
 #pragma unroll
         for (int j = 0; j < M; ++j) {
           const ull2 w = *reinterpret_cast<const ull2*>(&E[j][2 * (in_seg + i + k)]);
-          f.acc_mac(a[j], p[k].x, w.x);
-          f.acc_mac(a[j], p[k].y, w.y);
+          f.acc3_mac(a[j], p[k].x, w.x);
+          f.acc3_mac(a[j], p[k].y, w.y);
         }
       }
     }
@@ -336,8 +337,8 @@ evaluate_many_kernel(F f, const u64* __restrict__ T, int n, const u64* __restric
 #pragma unroll
       for (int j = 0; j < M; ++j) {
         const ull2 w = *reinterpret_cast<const ull2*>(&E[j][2 * (in_seg + i)]);
-        f.acc_mac(a[j], p.x, w.x);
-        f.acc_mac(a[j], p.y, w.y);
+        f.acc3_mac(a[j], p.x, w.x);
+        f.acc3_mac(a[j], p.y, w.y);
       }
     }
 #pragma unroll
@@ -347,7 +348,7 @@ evaluate_many_kernel(F f, const u64* __restrict__ T, int n, const u64* __restric
         const u64 rq = R[j][7 + ta + q];
         wB = f.mul(wB, ((seg >> q) & 1) ? rq : f.sub(f.one(), rq));
       }
-      o[j] = f.add(o[j], f.mul(f.acc_get(a[j]), wB));
+      o[j] = f.add(o[j], f.mul(f.acc3_get(a[j]), wB));
     }
   }
   u64 res[M];

@@ -3,7 +3,8 @@ of 4 tiles (round 3: one wave per block works) against one tile per draw (now). 
 import statistics
 import sys
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from __graft_entry__ import load_package
 
 pkg = load_package()

@@ -3,7 +3,8 @@ import statistics
 import sys
 import time
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 from __graft_entry__ import load_package
 
 pkg = load_package()
