@@ -266,3 +266,45 @@ def test_multi_interleaved_provers_and_reuse():
     assert provers[0][0].c1() == refs[0]["c_1"] and provers[1][0].c1() == refs[1]["c_1"]
     del provers
     ctx.close()
+
+
+@pytest.mark.parametrize("n_dev", [1, 2, 8])
+def test_multi_gkr_layer_matches_oracle(n_dev):
+    """gkr_protocol::round_polynomial::W behind ONE handle (BASELINE config 5 names gkr on 8 GPUs): sc_gkr_wiring builds the
+    devices' rows of add_i(r_i,.,.) / mul_i(r_i,.,.), every device streams its part twice per layer, the 2^(k+1)-entry product
+    proofs run on the first device - wiring tables, c_1, every round triple and the final W::evaluate == the oracle, through the
+    round-by-round prover and through sc_gkr_prove"""
+    import random
+    from test_gpu_gkr import make_circuit, random_circuit
+    pkg = load_package()
+    p = GOLD
+    o = oracle(p)
+    ctx = multi_ctx(pkg, p, n_dev)
+    F = ctx.field
+    gp = pkg.gkr_protocol
+    rng = random.Random(31)
+    for ks in ([3, 3], [5, 4], [6, 7], [4, 9]):
+        layers = random_circuit(rng, ks)
+        circuit = make_circuit(pkg, layers, 1 << ks[-1])
+        inputs = [F.from_int(rng.randrange(p)) for _ in range(1 << ks[-1])]
+        evaluation = circuit.evaluate(F, inputs)
+        k_i, k_next = ks[0], ks[1]
+        r_i = [F.from_int(rng.randrange(p)) for _ in range(k_i)]
+        oadd, omul = o.wiring_fixed(layers[0], k_next, r_i)
+        ow = np.array(evaluation[1], dtype=np.uint64)
+        ch = [F.from_int(rng.randrange(p)) for _ in range(2 * k_next)]
+        ref = o.w_prove(oadd, omul, ow, ow, ch)
+        assert ref["status"] == 0
+        w = gp.start_round_w(ctx, circuit, evaluation, 0, r_i)
+        assert np.array_equal(w.add_i.to_evaluations(), oadd) and np.array_equal(w.mul_i.to_evaluations(), omul), ks
+        eng = w.native_prover()
+        assert eng.c1() == ref["c_1"], ks
+        for j in range(2 * k_next):
+            assert eng.round_evals(ch[j - 1] if j else F.one, j) == [int(x) for x in ref["evals"][j]], (ks, j)
+        assert w.evaluate(ch) == o.w_evaluate(oadd, omul, ow, ow, np.array(ch, dtype=np.uint64)) == ref["final_eval"], ks
+        # the whole layer in one native call with scripted draws
+        it = iter(ch)
+        c1, evals, chn = gp.prove_w(ctx, w, pyref.SEED_R, draw=lambda _u, _j, _e: next(it))
+        assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]), ks
+        del eng, w
+    ctx.close()
