@@ -308,3 +308,29 @@ def test_multi_gkr_layer_matches_oracle(n_dev):
         assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]), ks
         del eng, w
     ctx.close()
+
+
+@pytest.mark.parametrize("n_dev", [2, 4])
+def test_multi_gkr_protocol_end_to_end(n_dev):
+    """the whole GKR message loop (gkr-protocol/src/lib.rs:38-218, :324-474, replayed through the host mirror exactly as
+    tests/test_gpu_gkr_protocol.py does on one device) with every table on ONE multi-device handle: wiring, the W prover of
+    every layer, restrict_poly, the verifier's evaluations - message by message equal to the oracle's restatement"""
+    import random
+    from test_gpu_gkr import random_circuit
+    from test_gpu_gkr_protocol import compare, run_protocol
+    from test_host_protocols import gkr_draw_count
+    pkg = load_package()
+    g = n_dev.bit_length() - 1
+    for p in (GOLD, 389):
+        ctx = multi_ctx(pkg, p, n_dev)
+        rng = random.Random(p % 977)
+        for ks in ([g, g + 1, g + 2, g + 1], [g + 1, g + 3, g + 2], [g, g, g]):
+            layers = random_circuit(rng, ks)
+            num_inputs = 1 << ks[-1]
+            inputs = [rng.randrange(p) for _ in range(num_inputs)]
+            draws = [rng.randrange(p) for _ in range(gkr_draw_count(layers, num_inputs))]
+            ref = pyref.gkr_transcript(layers, num_inputs, inputs, draws, p)
+            assert ref["check_input"]
+            rec, _ = run_protocol(pkg, ctx, layers, num_inputs, inputs, draws, False)
+            compare(rec, ref)
+        ctx.close()
