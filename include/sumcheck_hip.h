@@ -122,6 +122,8 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      sc_ctx_comm_peer_connect waits for every peer's hello (absorbs the start-up lag of a job)
  *   "dbg_delay_ms" / "dbg_skip_tag"   fault injection for tests: delay every sharded launch of this rank on the
  *                      host / make its next sharded launch skip an exchange tag (a rank out of step)
+ *   "dbg_fold_grab"    measurements: tiles per draw of fold_kernel's four-wave launches (0 = the default, 1; 4 = round 3's
+ *                      behaviour, profiles/r04_fold_small_grab_ab.txt)
  *   "time_kernels"     HIP-event timing of pass kernels (see sc_ctx_kernel_time)
  *   "nt_load_log" / "nt_store_log"  table log-size from which loads / stores are nontemporal */
 int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value);
@@ -229,7 +231,8 @@ int sc_table_evaluate(sc_ctx* ctx, const sc_table* t, const uint64_t* r, size_t 
                       uint64_t* out);
 /* The same at m points in ONE pass over the table: points = m rows of n words, out = m values.  Callers that evaluate one
  * table several times - restrict_poly's k + 1 points on a line (gkr-protocol/src/lib.rs:291-321), a verifier's oracle
- * queries - pay one read of the table, one launch and one hand-off instead of m (batches of 16 points per launch; up to 4
+ * queries - pay one read of the table, one launch and one hand-off instead of m (batches of 16 points per launch, 8 on a
+ * generic modulus; up to 4
  * points the pass stays memory-bound, beyond it is bound by the 2 m multiply-accumulates per 16 bytes).  Works on sharded
  * contexts and multi-device handles like sc_table_evaluate. */
 int sc_table_evaluate_many(sc_ctx* ctx, const sc_table* t, const uint64_t* points, size_t m, size_t n, int order, uint64_t* out);

@@ -256,6 +256,7 @@ evaluate_many_kernel(F f, const u64* __restrict__ T, int n, const u64* __restric
   __shared__ u64 L[M][kWave];
   __shared__ u64 H[M][3][16];              // half tables: [0] bits 0..3 of E's index, [1] bits 4..7, [2] unused / lane halves
   __shared__ u64 R[M][64];                 // the points
+  __shared__ u64 S[M][3][32];              // segment weights by 5-bit digit of the segment index: 2 products per chunk and point
   __shared__ u64 lds[kWaves * M];
   __shared__ int lds_flag;
   __shared__ unsigned lds_next;
@@ -292,6 +293,19 @@ evaluate_many_kernel(F f, const u64* __restrict__ T, int n, const u64* __restric
     const int j = i >> ebits, e = i & ((1 << ebits) - 1);
     E[j][e] = f.mul(H[j][0][e & ((1 << lo_bits) - 1)], H[j][1][e >> lo_bits]);
   }
+  // (the tb factors of a segment's weight, recomputed per chunk and point, were most of a small chunk's instructions)
+  for (int i = threadIdx.x; i < M * 96; i += kBlock) {
+    const int j = i / 96, lvl = (i % 96) >> 5, e = i & 31;
+    u64 w = f.one();
+    for (int q = 0; q < 5; ++q) {
+      const int bit = 5 * lvl + q;
+      if (bit < tb) {
+        const u64 rq = R[j][7 + ta + bit];
+        w = f.mul(w, ((e >> q) & 1) ? rq : f.sub(f.one(), rq));
+      }
+    }
+    S[j][lvl][e] = w;
+  }
   for (int i = threadIdx.x; i < M * kWave; i += kBlock) {
     const int j = i >> 6, l = i & 63;
     L[j][l] = f.mul(f.mul(H[j][2][l & 7], H[j][2][8 + (l >> 3)]), wx.w[j]);
@@ -316,7 +330,7 @@ evaluate_many_kernel(F f, const u64* __restrict__ T, int n, const u64* __restric
     typename F::Acc3 a[M];
 #pragma unroll
     for (int j = 0; j < M; ++j) f.acc3_zero(a[j]);
-    constexpr int B = 4;   // pieces in flight per lane
+    constexpr int B = (M == 16) ? 2 : 4;   // pieces in flight per lane (sixteen nine-register accumulators leave room for two)
     int i = 0;
     for (; i + B <= C; i += B) {   // fixed-count inner loops: see evaluate_kernel
       ull2 p[B];
@@ -343,8 +357,9 @@ evaluate_many_kernel(F f, const u64* __restrict__ T, int n, const u64* __restric
     }
 #pragma unroll
     for (int j = 0; j < M; ++j) {
-      u64 wB = f.one();   // segment weight, wave-uniform
-      for (int q = 0; q < tb; ++q) {
+      u64 wB = f.mul(S[j][0][seg & 31], S[j][1][(seg >> 5) & 31]);   // segment weight, wave-uniform
+      if (tb > 10) wB = f.mul(wB, S[j][2][(seg >> 10) & 31]);
+      for (int q = 15; q < tb; ++q) {   // (tables beyond 2^29 entries)
         const u64 rq = R[j][7 + ta + q];
         wB = f.mul(wB, ((seg >> q) & 1) ? rq : f.sub(f.one(), rq));
       }
