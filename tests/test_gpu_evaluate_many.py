@@ -168,6 +168,6 @@ def test_restrict_poly_is_one_pass_up_to_k17():
                     pt = o.to_mont([(bi + tt * (ci - bi)) % q for bi, ci in zip(b, c)])
                     val = sum(cf * pow(tt, d, q) for d, cf in enumerate(got)) % q
                     assert val == o.from_mont1(o.evaluate(tm, pt)), (q, k, tt)
-            if k == 13:
-                assert [(r["kind"], r["ks"]) for r in log] == [("evaluate", 14)], log
+            if k == 13:   # one launch of 14 points on Goldilocks; a generic modulus takes eight points per launch
+                assert [(r["kind"], r["ks"]) for r in log] == ([("evaluate", 14)] if q == GOLD else [("evaluate", 8), ("evaluate", 6)]), log
         ctx.close()
