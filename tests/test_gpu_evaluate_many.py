@@ -171,3 +171,40 @@ def test_restrict_poly_is_one_pass_up_to_k17():
             if k == 13:   # one launch of 14 points on Goldilocks; a generic modulus takes eight points per launch
                 assert [(r["kind"], r["ks"]) for r in log] == ([("evaluate", 14)] if q == GOLD else [("evaluate", 8), ("evaluate", 6)]), log
         ctx.close()
+
+
+def test_table_from_device_borrows_caller_memory():
+    """sc_table_from_device: a table over device memory the caller owns (here a torch tensor): zero-copy, never written, usable
+    by every table call and by the prover; misaligned / host pointers are refused"""
+    import torch
+    pkg = load_package()
+    o = oracle(GOLD)
+    ctx = pkg.Context(pkg.Field(GOLD))
+    n = 12
+    rng = np.random.default_rng(17)
+    ta, tb = rand_mont(o, rng, GOLD, (1 << n,)), rand_mont(o, rng, GOLD, (1 << n,))
+    da = torch.from_numpy(ta.view(np.int64)).cuda()
+    db = torch.from_numpy(tb.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    a = pkg.DenseMultilinearExtension.from_device(ctx, da.data_ptr(), n, keep=da)
+    b = pkg.DenseMultilinearExtension.from_device(ctx, db.data_ptr(), n, keep=db)
+    assert np.array_equal(a.to_evaluations(), ta)
+    pt = rand_mont(o, rng, GOLD, (n,))
+    assert a.evaluate(pt) == o.evaluate(ta, pt)
+    assert np.array_equal(a.fix_variables(pt[:3]).to_evaluations(), o.fix_variables(ta, pt[:3]))
+    from util import challenges
+    ch = challenges(o, n)
+    ref = o.prove(ta, tb, ch)
+    c1, evals, _ = pkg.matrix_multiplication.prove(ctx, pkg.matrix_multiplication.G(a, b), pyref.SEED_R)
+    assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+    torch.cuda.synchronize()
+    assert np.array_equal(da.cpu().numpy().view(np.uint64), ta), "the borrowed table was written"
+    del a, b                                   # dropping the handles leaves the tensors alone
+    assert np.array_equal(db.cpu().numpy().view(np.uint64), tb)
+    with pytest.raises(pkg.SumcheckHipError) as ei:
+        pkg.DenseMultilinearExtension.from_device(ctx, da.data_ptr() + 8, n - 1)       # 16-byte alignment
+    assert ei.value.code == 1
+    with pytest.raises(pkg.SumcheckHipError) as ei:
+        pkg.DenseMultilinearExtension.from_device(ctx, ta.ctypes.data, n)             # a host pointer
+    assert ei.value.code == 1
+    ctx.close()

@@ -334,3 +334,26 @@ def test_multi_gkr_protocol_end_to_end(n_dev):
             rec, _ = run_protocol(pkg, ctx, layers, num_inputs, inputs, draws, False)
             compare(rec, ref)
         ctx.close()
+
+
+def test_multi_more_provers_than_tail_slots():
+    """a handle has 64 pinned tail slots; the 65th prover alive at the same time takes pool memory for its last small outputs and
+    the host tail fetches them with a copy - same transcript"""
+    pkg = load_package()
+    o = oracle(GOLD)
+    ctx = multi_ctx(pkg, GOLD, 4)
+    n = 9
+    oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+    ch = challenges(o, n)
+    ref = o.prove(oa, ob, ch)
+    a, b = tables(pkg, ctx, n)
+    G = pkg.matrix_multiplication.G(a, b)
+    provers = [G.native_prover() for _ in range(70)]
+    for k in (0, 63, 64, 69):
+        for j in range(n):
+            assert provers[k].round_evals(int(ch[j - 1]) if j else 1, j) == [int(x) for x in ref["evals"][j]], (k, j)
+    del provers
+    # the slots came back: a fresh prover ends on its pinned slot again (no fetch launches in the log: six device passes at most)
+    c1, evals, _ = pkg.matrix_multiplication.prove(ctx, G, pyref.SEED_R)
+    assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+    ctx.close()

@@ -197,6 +197,66 @@ int main(int argc, char** argv) {
   time_fold(sc_table_device_ptr(ga), sc_table_device_ptr(gb), reps, &fu, &gu, &pm);
   printf("%-46s fold pass %7.1f us  first pass %7.1f us  proof %.4f ms\n", "hipMalloc again", fu, gu, pm);
   for (auto h : c.h) CK(hipMemRelease(h));
+  // more ways to obtain the two tables (round 4, after a box showed hipMalloc fast and every chunk mapping slow):
+  // fresh hipMalloc pairs made now, ONE hipMemCreate per table, ONE for both, and fine-grained / uncached allocations
+  auto fill_and_time = [&](const char* name, void* pa, void* pb) {
+    CK(hipMemcpy(pa, sc_table_device_ptr(ga), kTableBytes, hipMemcpyDeviceToDevice));
+    CK(hipMemcpy(pb, sc_table_device_ptr(gb), kTableBytes, hipMemcpyDeviceToDevice));
+    CK(hipDeviceSynchronize());
+    time_fold((const uint64_t*)pa, (const uint64_t*)pb, reps, &fu, &gu, &pm);
+    printf("%-46s fold pass %7.1f us  first pass %7.1f us  proof %.4f ms\n", name, fu, gu, pm);
+    fflush(stdout);
+  };
+  for (int r = 0; r < 3; ++r) {
+    void *pa = nullptr, *pb = nullptr;
+    CK(hipMalloc(&pa, kTableBytes));
+    CK(hipMalloc(&pb, kTableBytes));
+    fill_and_time(("fresh hipMalloc pair " + std::to_string(r)).c_str(), pa, pb);
+    SC(sc_ctx_synchronize(ctx));
+    CK(hipFree(pa));
+    CK(hipFree(pb));
+  }
+  {
+    void* pab = nullptr;
+    CK(hipMalloc(&pab, 2 * kTableBytes));
+    fill_and_time("one hipMalloc of 4 GiB: A | B", pab, (char*)pab + kTableBytes);
+    SC(sc_ctx_synchronize(ctx));
+    CK(hipFree(pab));
+  }
+  {
+    Chunks one = make_chunks(kTableBytes, 2);
+    map_range(va, one, {0});
+    map_range(vb, one, {1});
+    fill_and_time("hipMemCreate: ONE 2 GiB handle per table", va, vb);
+    SC(sc_ctx_synchronize(ctx));
+    unmap_range(va, kTableBytes, 1);
+    unmap_range(vb, kTableBytes, 1);
+    for (auto h : one.h) CK(hipMemRelease(h));
+  }
+  {
+    void *pa = nullptr, *pb = nullptr;
+    if (hipExtMallocWithFlags(&pa, kTableBytes, hipDeviceMallocFinegrained) == hipSuccess &&
+        hipExtMallocWithFlags(&pb, kTableBytes, hipDeviceMallocFinegrained) == hipSuccess) {
+      fill_and_time("hipExtMallocWithFlags(fine-grained)", pa, pb);
+      SC(sc_ctx_synchronize(ctx));
+    }
+    (void)hipGetLastError();
+    if (pa) (void)hipFree(pa);
+    if (pb) (void)hipFree(pb);
+  }
+  {
+    void *pa = nullptr, *pb = nullptr;
+    if (hipExtMallocWithFlags(&pa, kTableBytes, hipDeviceMallocUncached) == hipSuccess &&
+        hipExtMallocWithFlags(&pb, kTableBytes, hipDeviceMallocUncached) == hipSuccess) {
+      fill_and_time("hipExtMallocWithFlags(uncached)", pa, pb);
+      SC(sc_ctx_synchronize(ctx));
+    }
+    (void)hipGetLastError();
+    if (pa) (void)hipFree(pa);
+    if (pb) (void)hipFree(pb);
+  }
+  time_fold(sc_table_device_ptr(ga), sc_table_device_ptr(gb), reps, &fu, &gu, &pm);
+  printf("%-46s fold pass %7.1f us  first pass %7.1f us  proof %.4f ms\n", "the pool's tables, last", fu, gu, pm);
   sc_table_free(ctx, ga);
   sc_table_free(ctx, gb);
   sc_ctx_destroy(ctx);
