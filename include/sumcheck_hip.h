@@ -86,8 +86,9 @@ int sc_ctx_create(const sc_field* f, int device, sc_ctx** out);
  * <= 32 entries per table and device it was handed and serves the rounds of the device bits itself: a sharded proof is one
  * launch per device SHORTER than a single-device one.  Results are bit-identical to a one-device context.
  * Also served: sc_gkr_wiring, sc_gkr_prover_* / sc_gkr_prove (the dense W prover: every device streams its rows of c of add_i /
- * mul_i, the small product proofs run on the first device) and sc_gkr_w_evaluate.  Not served (SC_ERR_UNSUPPORTED):
- * sc_table_relabel, sc_table_from_device, the other sc_gkr_w_* calls, the sparse W prover, sc_tri_* (run those on an
+ * mul_i, the small product proofs run on the first device), sc_gkr_w_evaluate, and sc_tri_prover_* / sc_tri_prove /
+ * sc_tri_evaluate (every device squares its rows of the adjacency matrix).  Not served (SC_ERR_UNSUPPORTED):
+ * sc_table_relabel, sc_table_from_device, the other sc_gkr_w_* and sc_tri_* trait calls, the sparse W prover (run those on an
  * ordinary context), fix_variables across the device bits, and the sc_ctx_comm_* calls (the handle is its own communicator;
  * sc_ctx_comm_rank reports rank 0 of 1 - its tables are whole tables; option "n_devices" counts the devices).  sc_table_device_ptr returns NULL; sc_ctx_stream, sc_ctx_kernel_time and
  * sc_ctx_launch_log report the first device (one GPU's launches over its own shard). */

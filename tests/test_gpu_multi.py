@@ -357,3 +357,53 @@ def test_multi_more_provers_than_tail_slots():
     c1, evals, _ = pkg.matrix_multiplication.prove(ctx, G, pyref.SEED_R)
     assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
     ctx.close()
+
+
+@pytest.mark.parametrize("n_dev", [2, 8])
+def test_multi_triangle_prover_matches_oracle(n_dev):
+    """Prover<F, triangle_counting::G> behind one handle: every device squares its rows of the adjacency matrix (int8 matrix
+    cores from 64 rows per device up, the generic kernel below), the product sumchecks run on the first device - c_1 == 6 x
+    triangles, every round triple and the final G::evaluate == the oracle; 0/1 adjacency tables and field-valued ones"""
+    import random
+    from test_gpu_triangle import random_adj, triangle_count
+    pkg = load_package()
+    g = n_dev.bit_length() - 1
+    for p in (GOLD, 389):
+        ctx = multi_ctx(pkg, p, n_dev)
+        F = ctx.field
+        o = oracle(p)
+        gen = random.Random(5 + n_dev)
+        for k in sorted({max(g, 1), g + 1, 4, 5}):
+            n = 1 << k
+            m = random_adj(gen, n)
+            flat = sum(m, [])
+            G = pkg.triangle_counting.G.new_adj_matrix(ctx, 2 * k, flat)
+            oadj = o.to_mont([1 if b else 0 for b in flat])
+            ch = [F.from_int(gen.randrange(p)) for _ in range(3 * k)]
+            ref = o.tri_prove(oadj, k, ch)
+            eng = G.native_prover()
+            assert eng.c1() == ref["c_1"] and F.to_int(eng.c1()) == (6 * triangle_count(m)) % p, (p, k)
+            for j in range(3 * k):
+                assert eng.round_evals(ch[j - 1] if j else F.one, j) == [int(x) for x in ref["evals"][j]], (p, k, j)
+            assert G.evaluate(ch) == ref["final_eval"]
+            del eng
+        ctx.close()
+    # 512 vertices over the devices' matrix cores (64 rows each at 8 devices), whole proof in one native call, against
+    # the triangle count and the one-device transcript
+    k = 9
+    gen = np.random.default_rng(3)
+    upper = np.triu(gen.random((1 << k, 1 << k)) < 0.2, 1)
+    m = upper | upper.T
+    tri = int(np.trace(m.astype(np.int64) @ m.astype(np.int64) @ m.astype(np.int64))) // 6
+    one = pkg.Context(pkg.Field(GOLD))
+    F = one.field
+    ev = np.where(m.flatten(), np.uint64(F.one), np.uint64(0)).astype(np.uint64)
+    t1 = pkg.DenseMultilinearExtension.from_evaluations_vec(one, 2 * k, ev)
+    ref = pkg.triangle_counting.prove(one, pkg.triangle_counting.G(t1, t1, t1, k), pyref.SEED_R)
+    ctx = multi_ctx(pkg, GOLD, n_dev)
+    t = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2 * k, ev)
+    got = pkg.triangle_counting.prove(ctx, pkg.triangle_counting.G(t, t, t, k), pyref.SEED_R)
+    assert got[0] == ref[0] and F.to_int(got[0]) == (6 * tri) % F.p
+    assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
+    one.close()
+    ctx.close()
