@@ -186,3 +186,91 @@ def test_bench_self_launch_relays_exit_code_without_gpu():
     assert out.returncode != 0
     assert not [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert "needs a GPU" in out.stderr
+
+
+def model_local_prove(o, plan_proof, p, n, world, opts, pyref):
+    """The ONE-PROCESS form (sc_ctx_create_multi, transport "local"): the N shards live in one process, every planned launch runs
+    on every shard (the oracle in place of the kernels), the shards' grids are added in the process - no collective - and the
+    plan's last step is the HOST TAIL: the host folds each shard's pending entries and forms the cells of the device-bit rounds
+    from the N entries left per table, as engine/abi_prover.inc: host_tail does."""
+    from conftest import load_package
+    D = load_package().distributed
+    L = o.lib
+    add, sub, mul = (lambda x, y: L.sco_add(o.fp, x, y)), (lambda x, y: L.sco_sub(o.fp, x, y)), \
+        (lambda x, y: L.sco_mul(o.fp, x, y))
+    g = world.bit_length() - 1
+    shards = []
+    for rank in range(world):
+        start, length = D.shard_range(n, rank, world)
+        shards.append([o.generate_range(pyref.SEED_A, start, length), o.generate_range(pyref.SEED_B, start, length)])
+    ch = [o.challenge(pyref.SEED_R, j + 1) for j in range(n)]
+    steps = list(plan_proof(n, world, "local", **opts))
+    pending, cache, evals = [], None, []
+    for j in range(n):
+        if j:
+            pending.append(ch[j - 1])
+        covered = cache is not None and 0 <= j - cache[1] < cache[0] and len(pending) == j - cache[1]
+        if not covered:
+            step = steps.pop(0)
+            kf, ks = step["kf"], step["ks"]
+            assert kf == len(pending) and step["log_in"] == int(shards[0][0].size).bit_length() - 1, (step, len(pending))
+            if step["action"] == "host_tail":
+                assert world > 1 and ks == g and shards[0][0].size == 1 << kf and not steps
+                ta, tb = [], []
+                for a, b in shards:       # one entry per table and shard is left
+                    fa, fb = (o.fix_variables(a, pending), o.fix_variables(b, pending)) if kf else (a, b)
+                    ta.append(int(fa[0]))
+                    tb.append(int(fb[0]))
+                S = [int(x) for x in o.gridk_sums(np.array(ta, dtype=np.uint64), np.array(tb, dtype=np.uint64), g)]
+            else:
+                assert step["action"] in ("pass", "grid_pass") and step["sharded"] == (world > 1)
+                S = None
+                for sh in shards:
+                    if kf:
+                        sh[0], sh[1] = o.fix_variables(sh[0], pending), o.fix_variables(sh[1], pending)
+                    part = [int(x) for x in o.gridk_sums(sh[0], sh[1], ks)]
+                    S = part if S is None else [add(x, y) for x, y in zip(S, part)]
+            pending = []
+            cache = (ks, j, S)
+        ks, j0, S = cache
+        grid, cells = list(S), len(S)
+        for r in pending:
+            r2 = mul(r, r)
+            cells //= 3
+            grid = [add(add(grid[c], mul(r, sub(sub(grid[cells + c], grid[c]), grid[2 * cells + c]))), mul(r2, grid[2 * cells + c]))
+                    for c in range(cells)]
+        rest = cells // 3
+        h = []
+        for x in range(3):
+            t = 0
+            for c in range(rest):
+                digits, d = [], c
+                while d:
+                    digits.append(d % 3)
+                    d //= 3
+                if 2 not in digits:
+                    t = add(t, grid[x * rest + c])
+            h.append(t)
+        t = add(h[1], h[2])
+        evals.append([h[0], h[1], sub(add(t, t), h[0])])
+    assert not steps, steps
+    return evals, ch
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_local_plan_is_sufficient(world):
+    """the planner's schedule for ONE process over N devices - no gather, no rank pass, the host tail at the end - executed
+    with the oracle in place of the kernels reproduces the full-table oracle transcript (the engine itself:
+    tests/test_gpu_multi.py)"""
+    import pyref
+    from oracle import Oracle
+    pkg = load_package()
+    GOLD = 2**64 - 2**32 + 1
+    g = world.bit_length() - 1
+    for (p, n, opts) in [(GOLD, max(g, 1), {}), (GOLD, g + 1, {}), (GOLD, g + 4, {}), (GOLD, 10, {}), (GOLD, 14, {}), (389, 13, {}),
+                         (GOLD, 12, {"grid_max_vars": 3}), (GOLD, 11, {"vars_per_pass": 1}), (GOLD, 12, {"grid_pass": 0}),
+                         (5, 9, {"grid_sharded": 0}), (GOLD, 13, {"first_pass_vars": 2, "grid_log": 6})]:
+        o = Oracle(p)
+        evals, ch = model_local_prove(o, pkg.schedule.plan_proof, p, n, world, opts, pyref)
+        full = o.prove(o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n), np.array(ch, dtype=np.uint64))
+        assert full["status"] == 0 and evals == [[int(x) for x in row] for row in full["evals"]], (world, p, n, opts)
