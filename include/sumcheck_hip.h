@@ -321,9 +321,10 @@ int sc_prove(sc_ctx* ctx, const sc_table* a, const sc_table* b, sc_draw_fn draw,
  * every rank.  sc_gkr_wiring builds exactly those shards (every rank passes the whole gate list and keeps the gates
  * of its rows: no exchange), the prover (sc_gkr_prover_*) and sc_gkr_w_round_sums / _fix_variables / _evaluate work
  * on them (sums exchanged like a pass's; fix_variables while the variables fixed stay shard-local, i.e. all of b
- * and all but the top log2(world) of c).  sc_gkr_w_to_evaluations is single-rank only: the reference's output
- * order is b-major, so a sharded result would need an all-to-all nobody consumes (Prover::new only sums it:
- * sc_gkr_prover_c1 gives that). */
+ * and all but the top log2(world) of c).  sc_gkr_w_to_evaluations returns, like every table of a sharded context, this rank's
+ * contiguous shard of the result - whose order is b-major (the reference's), so the shard is a range of b and needs every
+ * rank's rows of c: add and mul are gathered for the duration of the call (Prover::new only sums the result:
+ * sc_gkr_prover_c1 gives that without it). */
 
 /* add_i(r_i,.,.) and mul_i(r_i,.,.) of Prover::start_round (gkr-protocol/src/lib.rs:388-416)
  * straight from the gate list of layer i (2^k_i gates: type 0 = add, 1 = mul; inputs index

@@ -141,7 +141,8 @@ def test_sharded_g_new_world8_config5_shape():
 @pytest.mark.parametrize("world", [2, 8])
 def test_sharded_wiring_and_generic_w_methods(world):
     """sc_gkr_wiring and sc_gkr_w_round_sums / _fix_variables / _evaluate on sharded contexts (every rank its rows of c)
-    against the oracle, and the dense prover on those shards; sc_gkr_w_to_evaluations says it is single-rank only"""
+    against the oracle, and the dense prover on those shards; sc_gkr_w_to_evaluations returns this rank's shard of the b-major
+    result (round 4: add / mul are gathered for the call)"""
     pkg = load_package()
     p = GOLD
     o = oracle(p)
@@ -176,9 +177,10 @@ def test_sharded_wiring_and_generic_w_methods(world):
                 cur = cur.fix_variables([ch[j - 1]])
                 got.append(cur.round_evals())
             final = w.evaluate(ch)
-            with pytest.raises(pkg.SumcheckHipError) as ei:
-                w.to_evaluations()
-            assert ei.value.code == 6
+            if k_next >= g:
+                full_ev = o.w_to_evaluations(oadd, omul, ow, ow)
+                cnt = full_ev.size // world
+                assert np.array_equal(w.to_evaluations(), full_ev[rank * cnt:(rank + 1) * cnt]), (ks, rank)
             eng = w.native_prover()
             eng_got = [eng.c1()] + [eng.round_evals(ch[j - 1] if j else F0.one, j) for j in range(2 * k_next)]
             del eng, cur, w

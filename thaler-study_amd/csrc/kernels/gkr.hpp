@@ -53,13 +53,14 @@ gkr_sums_kernel(F f, const u64* __restrict__ add, const u64* __restrict__ mul, c
 template <class F>
 __global__ void __launch_bounds__(kBlock)
 gkr_to_evaluations_kernel(F f, const u64* __restrict__ add, const u64* __restrict__ mul, const u64* __restrict__ w_b,
-                          int kb, const u64* __restrict__ w_c, int kc, u64* __restrict__ out) {
-  const size_t n = (size_t)1 << (kb + kc);
-  for (size_t o = (size_t)blockIdx.x * kBlock + threadIdx.x; o < n; o += (size_t)gridDim.x * kBlock) {
+                          int kb, const u64* __restrict__ w_c, int kc, size_t o_begin, size_t o_count, u64* __restrict__ out) {
+  // entries [o_begin, o_begin + o_count) of the b-major result (everything unsharded; a rank's shard of the OUTPUT otherwise)
+  for (size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x; i < o_count; i += (size_t)gridDim.x * kBlock) {
+    const size_t o = o_begin + i;
     const size_t b = o >> kc, c = o & (((size_t)1 << kc) - 1);
     const size_t bc = (c << kb) | b;
     const u64 wb = w_b[b], wc = w_c[c];
-    out[o] = f.add(f.mul(add[bc], f.add(wb, wc)), f.mul(mul[bc], f.mul(wb, wc)));
+    out[i] = f.add(f.mul(add[bc], f.add(wb, wc)), f.mul(mul[bc], f.mul(wb, wc)));
   }
 }
 
