@@ -88,8 +88,8 @@ int sc_ctx_create(const sc_field* f, int device, sc_ctx** out);
  * Also served: sc_gkr_wiring, sc_gkr_prover_* / sc_gkr_prove (the dense W prover: every device streams its rows of c of add_i /
  * mul_i, the small product proofs run on the first device), sc_gkr_w_evaluate, and sc_tri_prover_* / sc_tri_prove /
  * sc_tri_evaluate (every device squares its rows of the adjacency matrix).  Not served (SC_ERR_UNSUPPORTED):
- * sc_table_relabel, sc_table_from_device, the other sc_gkr_w_* and sc_tri_* trait calls, the sparse W prover (run those on an
- * ordinary context), fix_variables across the device bits, and the sc_ctx_comm_* calls (the handle is its own communicator;
+ * sc_table_relabel, sc_table_from_device, the other sc_gkr_w_* and sc_tri_* trait calls (run those on an ordinary context;
+ * sc_gkr_prover_create_sparse runs on the handle's first device), fix_variables across the device bits, and the sc_ctx_comm_* calls (the handle is its own communicator;
  * sc_ctx_comm_rank reports rank 0 of 1 - its tables are whole tables; option "n_devices" counts the devices).  sc_table_device_ptr returns NULL; sc_ctx_stream, sc_ctx_kernel_time and
  * sc_ctx_launch_log report the first device (one GPU's launches over its own shard). */
 int sc_ctx_create_multi(const sc_field* f, const int* devices, int n_devices, sc_ctx** out);

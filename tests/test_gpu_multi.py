@@ -298,9 +298,13 @@ def test_multi_gkr_layer_matches_oracle(n_dev):
         w = gp.start_round_w(ctx, circuit, evaluation, 0, r_i)
         assert np.array_equal(w.add_i.to_evaluations(), oadd) and np.array_equal(w.mul_i.to_evaluations(), omul), ks
         eng = w.native_prover()
-        assert eng.c1() == ref["c_1"], ks
+        seng = gp.SparseLayerProver(ctx, circuit, evaluation, 0, r_i)      # the gate-list prover: on the handle's first device
+        assert eng.c1() == ref["c_1"] == seng.c1(), ks
         for j in range(2 * k_next):
-            assert eng.round_evals(ch[j - 1] if j else F.one, j) == [int(x) for x in ref["evals"][j]], (ks, j)
+            e = [int(x) for x in ref["evals"][j]]
+            assert eng.round_evals(ch[j - 1] if j else F.one, j) == e, (ks, j)
+            assert seng.round_evals(ch[j - 1] if j else F.one, j) == e, (ks, j)
+        del seng
         assert w.evaluate(ch) == o.w_evaluate(oadd, omul, ow, ow, np.array(ch, dtype=np.uint64)) == ref["final_eval"], ks
         # the whole layer in one native call with scripted draws
         it = iter(ch)
