@@ -123,6 +123,8 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      sc_ctx_comm_peer_connect waits for every peer's hello (absorbs the start-up lag of a job)
  *   "dbg_delay_ms" / "dbg_skip_tag"   fault injection for tests: delay every sharded launch of this rank on the
  *                      host / make its next sharded launch skip an exchange tag (a rank out of step)
+ *   "pool_contiguous"  experiments: 1 = pool blocks of >= 1 MiB are asked for as physically contiguous VRAM
+ *                      (hipDeviceMallocContiguous; default 0; experiments/r04_vmm_placement.md, addendum 2)
  *   "dbg_fold_grab"    measurements: tiles per draw of fold_kernel's four-wave launches (0 = the default, 1; 4 = round 3's
  *                      behaviour, profiles/r04_fold_small_grab_ab.txt)
  *   "time_kernels"     HIP-event timing of pass kernels (see sc_ctx_kernel_time)

@@ -185,7 +185,8 @@ struct sc_ctx {
   // makes the next sharded launch skip a tag (a rank that is out of step with its peers)
   int dbg_delay_ms = 0;
   int dbg_skip_tag = 0;
-  int dbg_fold_grab = 0;   // measurements: tiles per draw of fold_kernel's four-wave launches (0 = 1, the default; 4 = round 3's behaviour)
+  int dbg_fold_grab = 0;
+  int pool_contiguous = 0;   // pool blocks of >= 1 MiB are asked for as PHYSICALLY contiguous VRAM (hipDeviceMallocContiguous)   // measurements: tiles per draw of fold_kernel's four-wave launches (0 = 1, the default; 4 = round 3's behaviour)
 
   // multi-device handle (sc_ctx_create_multi, engine/multi.inc).  The handle itself owns no device state: `subs` are ordinary
   // contexts, one per entry of devices[], shard d = rank d of world subs.size() on Transport::kLocal; `mrt` holds one
@@ -315,7 +316,12 @@ int pool_alloc(sc_ctx* ctx, size_t words, u64** out) {
     return SC_OK;
   }
   u64* p = nullptr;
-  hipError_t e = hipMalloc(&p, words * sizeof(u64));
+  hipError_t e = hipErrorOutOfMemory;
+  if (ctx->pool_contiguous && words * sizeof(u64) >= ((size_t)1 << 20)) {
+    e = hipExtMallocWithFlags((void**)&p, words * sizeof(u64), hipDeviceMallocContiguous);
+    if (e != hipSuccess) (void)hipGetLastError();   // no contiguous range of that size: an ordinary allocation below
+  }
+  if (e != hipSuccess) e = hipMalloc(&p, words * sizeof(u64));
   if (e != hipSuccess) {
     // release cached blocks and retry once
     for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
