@@ -411,3 +411,16 @@ def test_multi_triangle_prover_matches_oracle(n_dev):
     assert np.array_equal(got[1], ref[1]) and np.array_equal(got[2], ref[2])
     one.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("n,n_dev", [(18, 4), (12, 8), (3, 8), (22, 2)])
+def test_multi_handle_from_a_compiled_caller(n, n_dev):
+    """tests/cpp/test_multi_handle.cpp: the reference's prove / verify loop as a compiled program over the C ABI alone - one
+    handle over several devices, the verifier drawing r_j once, every check of sum-check-protocol/src/lib.rs:286-328 and the
+    final oracle evaluation - transcript equal to the one-device one"""
+    import subprocess
+    import __graft_entry__ as ge
+    exe = ge.build_cpp_multi_test()
+    out = subprocess.run([exe, str(n), str(n_dev)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "ALL OK" in out.stdout and out.stdout.count("verifier accepts") == 2, out.stdout
