@@ -113,3 +113,16 @@ def test_peer_transport_state_machine():
     b4 = pkg.DenseMultilinearExtension.generate(plain, pyref.SEED_B, 12)
     c1d, evalsd, _ = pkg.matrix_multiplication.prove(plain, pkg.matrix_multiplication.G(a4, b4), pyref.SEED_R)
     assert c1c == c1d and np.array_equal(evalsc, evalsd)
+
+
+def test_randomized_differential_run():
+    """tools/fuzz_diff.py for 20 s on a fixed seed: random primes (3 ... 2^64 - 59), sizes, schedules, handles of 1-8 entries, table and
+    challenge corner values; the product prover, the table calls, a GKR layer and a triangle proof against the oracle, bit for bit"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_diff.py"), "20", "7", "14"], capture_output=True, text=True,
+                         timeout=600, cwd=root)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    assert "0 mismatches" in out.stdout
