@@ -157,6 +157,8 @@ int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset);
 #define SC_KIND_MATSQ 8      /* triangle counting: square of the adjacency matrix */
 /* 9 was the resident prover kernel (removed in round 3: measured equal to launches) */
 #define SC_KIND_GRID_PASS 10 /* wgrid_pass_kernel: fold kf <= 5 variables of tables of <= 2^20 folded entries + the 3^ks cells of ks <= 5 rounds */
+#define SC_KIND_GRAM_PASS 11   /* gram_pass_kernel: the four-round first pass of a large proof on the int8 matrix cores (ks = 4) */
+#define SC_KIND_GRAM_FINISH 12 /* gram_finish_kernel: its partials -> the 81 cells in the mailbox */
 typedef struct sc_launch_record {
   int32_t kind;           /* SC_KIND_* */
   int32_t kf, ks;         /* variables folded / rounds served (meaning per kind above) */
@@ -284,8 +286,9 @@ int sc_prover_num_vars(const sc_prover* pr, size_t* out);
 #define SC_PLAN_RANK_PASS 2  /* rank_pass_kernel (peer transport): the rounds of the rank bits */
 #define SC_PLAN_GATHER 3     /* all-gather of the shards; the proof goes on replicated */
 #define SC_PLAN_HOST_TAIL 4  /* multi-device handle (transport 4): the host folds the shards' pending entries and serves the device-bit rounds; no launch */
+#define SC_PLAN_GRAM_PASS 5  /* gram_pass_kernel + gram_finish_kernel: rounds 1..4 of an unsharded proof on tables of >= 2^gram_log entries */
 typedef struct sc_plan_options {   /* the context options the schedule depends on (sc_ctx_set_option names) */
-  int32_t vars_per_pass, first_pass_vars, grid_pass, grid_log, grid_max_vars, grid_sharded, tail_log, use_mailbox;
+  int32_t vars_per_pass, first_pass_vars, grid_pass, grid_log, grid_max_vars, grid_sharded, tail_log, use_mailbox, gram_log;
 } sc_plan_options;
 typedef struct sc_plan_step {
   int32_t action, kf, ks, log_in, sharded;

@@ -54,6 +54,7 @@ pub struct sc_plan_options {
     pub grid_sharded: i32,
     pub tail_log: i32,
     pub use_mailbox: i32,
+    pub gram_log: i32,
 }
 /// One launch of a planned proof: `action` is one of the `SC_PLAN_*` values of the header.
 #[repr(C)]

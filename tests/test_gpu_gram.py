@@ -1,0 +1,136 @@
+"""The four-round first pass on the int8 matrix cores (kernels/gram.hpp: gram_pass_kernel + gram_finish_kernel) and the
+four-variable fold pass behind it (pass_kernel<4, 2>): transcripts bit for bit against the oracle for every kind of modulus
+(the kernel never sees p), adversarial byte patterns (the signed-byte correction), partial counts, the schedules that lead
+through pass_kernel<4, 2>, and the default schedule at the sizes where it is chosen by itself."""
+import numpy as np
+import pytest
+
+from conftest import load_package
+from util import GOLD, challenges, oracle, pid, pyref, verifier_identities
+
+pytestmark = pytest.mark.gpu
+
+P59 = 2**64 - 59
+
+
+def prove_vs_oracle(pkg, ctx, p, n, ha, hb, tag):
+    o = oracle(p)
+    a = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, ha)
+    b = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, hb)
+    g = pkg.matrix_multiplication.G(a, b)
+    c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+    ref = o.prove(ha, hb, ch)
+    assert ref["status"] == 0
+    assert c1 == ref["c_1"], tag
+    assert np.array_equal(evals, ref["evals"]), tag
+    assert g.evaluate([int(x) for x in ch]) == ref["final_eval"], tag
+    # round by round as well (Prover::round): the cache of the gram pass serves rounds 0..3
+    pr = g.native_prover()
+    assert pr.c1() == ref["c_1"]
+    for j in range(min(n, 7)):
+        assert pr.round_evals(int(ch[j - 1]) if j else ctx.field.one, j) == [int(x) for x in ref["evals"][j]], (tag, j)
+
+
+@pytest.mark.parametrize("p", [GOLD, P59, 389, 5, 2**61 - 1], ids=pid)
+@pytest.mark.parametrize("n,opts", [(14, {}), (15, {}), (17, {"max_blocks": 3}), (18, {"grid_log": 10}), (20, {"grid_log": 12}),
+                                    (20, {"max_blocks": 64}), (21, {"grid_log": 9, "max_blocks": 7})])
+def test_gram_first_pass_vs_oracle(p, n, opts):
+    """first_pass_vars = 4 asks for the matrix-core pass at any size; a small grid_log sends the pass behind it - four pending
+    challenges - to pass_kernel<4, 2> instead of wgrid_pass_kernel"""
+    pkg = load_package()
+    ctx = pkg.Context(pkg.Field(p))
+    ctx.set_option("first_pass_vars", 4)
+    for k, v in opts.items():
+        ctx.set_option(k, v)
+    plan = pkg.schedule.plan_proof(n, first_pass_vars=4, **{k: v for k, v in opts.items() if k != "max_blocks"})
+    assert plan[0]["action"] == "gram_pass" and plan[0]["ks"] == 4
+    if "grid_log" in opts:
+        assert plan[1] == {"action": "pass", "kf": 4, "ks": 2, "log_in": n, "sharded": False}
+    o = oracle(p)
+    ha, hb = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+    prove_vs_oracle(pkg, ctx, p, n, ha, hb, (p, n, opts))
+    ctx.close()
+
+
+@pytest.mark.parametrize("p", [GOLD, P59], ids=pid)
+@pytest.mark.parametrize("kind", ["ff", "zero_a", "x80", "x7f", "spike", "alternating"])
+def test_gram_byte_patterns(p, kind):
+    """the signed-byte correction at its corners: bytes 0xFF / 0x80 / 0x7F / 0x00 everywhere (entries reduced mod p first where
+    they have to be), one non-zero entry, and 0x00 / 0xFF alternating by entry"""
+    pkg = load_package()
+    n = 16
+    size = 1 << n
+    rng = np.random.default_rng(5)
+    if kind == "ff":
+        ha = np.full(size, p - 1, dtype=np.uint64)
+        hb = np.full(size, p - 1, dtype=np.uint64)
+    elif kind == "zero_a":
+        ha = np.zeros(size, dtype=np.uint64)
+        hb = rng.integers(0, 2**63, size=size, dtype=np.uint64) % np.uint64(p)
+    elif kind == "x80":
+        ha = np.full(size, 0x8080808080808080 % p, dtype=np.uint64)
+        hb = np.full(size, 0x8080808080808080 % p, dtype=np.uint64)
+    elif kind == "x7f":
+        ha = np.full(size, 0x7F7F7F7F7F7F7F7F, dtype=np.uint64)
+        hb = np.full(size, 0x7F7F7F7F7F7F7F7F, dtype=np.uint64)
+    elif kind == "spike":
+        ha = np.zeros(size, dtype=np.uint64)
+        hb = np.zeros(size, dtype=np.uint64)
+        ha[12345] = p - 2
+        hb[12345] = p - 3
+        hb[12344] = 77
+    else:
+        ha = np.where(np.arange(size) % 2 == 0, 0, p - 1).astype(np.uint64)
+        hb = np.where(np.arange(size) % 3 == 0, p - 1, 0).astype(np.uint64)
+    ctx = pkg.Context(pkg.Field(p))
+    ctx.set_option("first_pass_vars", 4)
+    ctx.set_option("grid_log", 8)
+    prove_vs_oracle(pkg, ctx, p, n, np.ascontiguousarray(ha), np.ascontiguousarray(hb), (p, kind))
+    ctx.close()
+
+
+def test_gram_is_the_default_from_2_26_and_agrees_with_the_three_round_schedule():
+    """n = 26: the default schedule opens with the gram pass; its transcript equals the one of the 27-cell first pass
+    (gram_log = 0) bit for bit, and the verifier's identities hold"""
+    pkg = load_package()
+    F = pkg.Field(GOLD)
+    n = 26
+    assert pkg.schedule.plan_proof(n)[0]["action"] == "gram_pass"
+    assert pkg.schedule.plan_proof(n, gram_log=0)[0] == {"action": "pass", "kf": 0, "ks": 3, "log_in": n, "sharded": False}
+    assert pkg.schedule.plan_proof(25)[0]["action"] == "pass"
+    out = []
+    for gram_log in (26, 0):
+        ctx = pkg.Context(F)
+        ctx.set_option("gram_log", gram_log)
+        a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
+        b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, n)
+        g = pkg.matrix_multiplication.G(a, b)
+        ctx.set_option("time_kernels", 1)
+        c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+        kinds = [r["kind"] for r in ctx.launch_log()]
+        assert ("gram_pass" in kinds and "gram_finish" in kinds) == (gram_log != 0), kinds
+        final = g.evaluate([int(x) for x in ch])
+        assert verifier_identities(F, c1, evals, ch, final) is None
+        out.append((c1, evals, ch, final))
+        del a, b, g
+        ctx.close()
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1]) and out[0][3] == out[1][3]
+
+
+def test_gram_on_a_one_device_handle_and_generic_field_n24():
+    """a handle over one device takes the plain schedule (gram pass included); the generic modulus at n = 24 against the oracle"""
+    pkg = load_package()
+    n = 24
+    o = oracle(P59)
+    ha, hb = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+    ref = o.prove(ha, hb, challenges(o, n))
+    for devices in (None, [0]):
+        ctx = pkg.Context(pkg.Field(P59), devices=devices) if devices else pkg.Context(pkg.Field(P59))
+        ctx.set_option("gram_log", 24)
+        a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
+        b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, n)
+        g = pkg.matrix_multiplication.G(a, b)
+        c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+        assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]), devices
+        del a, b, g
+        ctx.close()

@@ -43,7 +43,7 @@ __device__ __forceinline__ void st16(ull2* __restrict__ p, ull2 v) {
 // Fold weights of one pass: w[c] = eq((r0,..,r_{KF-1}), c) = prod_j (bit_j(c) ? r_j : 1 - r_j),
 // computed exactly on the host (Montgomery words).  KF = 1 uses w[1] = r0.
 struct FoldW {
-  u64 w[8];
+  u64 w[16];   // (KF <= 3 uses the first eight)
 };
 
 // Fold KF variables (LE) of a run of IN entries in registers; the first IN >> KF entries
@@ -218,6 +218,14 @@ __device__ __forceinline__ void wave_lds_fence() {
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
   __builtin_amdgcn_wave_barrier();
 }
+// LDS hand-off between the lanes of ONE wave: a wave's LDS operations execute in order, so all that is needed is
+// that the earlier ones have been issued and returned and that the compiler keeps the order.  (wave_lds_fence()
+// is a workgroup-scope fence: it would also wait for the wave's global stores - here the folded entries on
+// their way out, which nobody in this kernel waits for.)
+__device__ __forceinline__ void wave_lds_sync() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_wave_barrier();
+}
 // in: v[k] = piece 64k + lane of the wave tile; out: v[m] = piece NP*lane + m
 template <int NP>
 __device__ __forceinline__ void transpose_to_runs(ull2* __restrict__ lds, ull2 (&v)[NP], int lane) {
@@ -248,6 +256,7 @@ __device__ __forceinline__ void transpose_to_pieces(ull2* __restrict__ lds, ull2
 // the kernels by subject (each part reopens namespace sc; they build on each other in this order)
 #include "kernels/pass.hpp"
 #include "kernels/grid_pass.hpp"
+#include "kernels/gram.hpp"
 #include "kernels/mle.hpp"
 #include "kernels/gkr.hpp"
 #include "kernels/triangle.hpp"

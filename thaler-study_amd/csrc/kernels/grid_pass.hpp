@@ -53,14 +53,6 @@ struct WgOut {
   u64* limbs_dev;    // non-null: leave the cells as 2 x 3^KS split limbs here (device memory) and publish nothing
   PeerX px;          // world > 0: a sharded pass - the cells are exchanged with the peers before they are published
 };
-// LDS hand-off between the lanes of ONE wave: a wave's LDS operations execute in order, so all that is needed is
-// that the earlier ones have been issued and returned and that the compiler keeps the order.  (wave_lds_fence()
-// is a workgroup-scope fence: it would also wait for the wave's global stores - here the folded entries on
-// their way out, which nobody in this kernel waits for.)
-__device__ __forceinline__ void wave_lds_sync() {
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_wave_barrier();
-}
 // folded entry i of one table: sum_c w[c] * in[2^KF i + c], stored to the folded table
 template <class F, int KF>
 __device__ __forceinline__ u64 grid_fold1(const F& f, const u64* __restrict__ T, u64* __restrict__ T2, const GridW& gw, size_t i) {

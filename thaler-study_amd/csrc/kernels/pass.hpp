@@ -10,9 +10,9 @@ namespace sc {
 // fix_variables + to_univariate, sum-check-protocol/src/lib.rs:105-112).
 //
 // unit = one run of IN = 2^(KF+KS) input entries per table -> OUT = 2^KS output entries,
-// owned by one lane; a wave tile is 64 units.  KF in 0..3, KS in 1..3 (KS = 3, the 27-cell grid
-// of a three-round first pass, is only instantiated with KF = 0).  Sums leave through
-// finish_pass (PassOut).
+// owned by one lane; a wave tile is 64 units.  KF in 0..4, KS in 1..3 (KS = 3, the 27-cell grid
+// of a three-round first pass, is only instantiated with KF = 0; KF = 4, the pass behind the four-round first pass of
+// kernels/gram.hpp, only with KS = 2).  Sums leave through finish_pass (PassOut).
 // Where a pass leaves its sums.
 //  * grid of one block: that block publishes directly.
 //  * larger grids: every block stores its partial residues (sum-major rows), takes a ticket,
@@ -340,7 +340,7 @@ __device__ __forceinline__ u64 reduce_cells_lds(const F& f, const typename F::Ac
 // (their registers allow no more) and get ALL of a CU's waves into ONE block, so that the waves of a SIMD can share
 // their work through LDS (see the tile loop); the light ones keep 256 threads and several blocks per CU.
 __host__ __device__ constexpr int pass_block_threads(int kf, int ks) {
-  return (ks == 3 || (kf == 3 && ks == 2)) ? 512 : (kf == 2 && ks == 2) ? 768 : kBlock;
+  return (ks == 3 || (kf >= 3 && ks == 2)) ? 512 : (kf == 2 && ks == 2) ? 768 : kBlock;
 }
 
 // NT: bit 0 = nontemporal loads, bit 1 = nontemporal stores (see ld16 / st16)
@@ -354,7 +354,10 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   constexpr int BS = pass_block_threads(KF, KS), kWaves = BS / kWave;
   static_assert(BS == kBlock || NS >= 9, "reduce_cells (the KS = 1 passes) is written for 256 threads");
   // the tile transposes; after the loop the same bytes hold a chunk of every thread's accumulators (reduce_cells_lds)
-  constexpr int kTransposeSlots = (NP > 1 || NPO > 1) ? kWaves * kWave * NP : 1;
+  // KF = 4: a unit is 64 entries = 32 pieces per table - too many to stage at once; its four outputs (16 entries = 8 pieces
+  // each) are produced one after the other, 8 pieces per lane and table in flight (NPS)
+  constexpr int NPS = 8, NPL = (KF == 4) ? 2 * NPS : NP;   // pieces per lane the wave's LDS region is laid out for (KF = 4: both tables' sub-steps)
+  constexpr int kTransposeSlots = (NP > 1 || NPO > 1) ? kWaves * kWave * NPL : 1;
   constexpr int kChunkCells = reduce_chunk_cells<typename F::Acc, BS>();
   constexpr int kReduceSlots = (NS >= 9) ? (int)(((NS < kChunkCells ? NS : kChunkCells) * BS * sizeof(typename F::Acc) + sizeof(ull2) - 1) / sizeof(ull2)) : 1;
   __shared__ ull2 lds_t[kTransposeSlots > kReduceSlots ? kTransposeSlots : kReduceSlots];
@@ -362,7 +365,7 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   __shared__ int lds_flag;
   __shared__ unsigned lds_next;   // the block's tile counter
   const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-  ull2* const my_lds = lds_t + ((NP > 1 || NPO > 1) ? wave * kWave * NP : 0);
+  ull2* const my_lds = lds_t + ((NP > 1 || NPO > 1) ? wave * kWave * NPL : 0);
 
   typename F::Acc acc[NS];
 #pragma unroll
@@ -377,7 +380,8 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
 
   // inactive lanes carry zeros: they add nothing to the sums and store nothing.  Tables far
   // larger than the 256 MiB Infinity Cache are read once: stream them (nontemporal).
-  auto load_tile = [&](size_t tile, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
+  // (generic lambdas: their bodies are only instantiated where they are called - not for KF = 4, whose unit has no NP-piece form)
+  auto load_tile = [&](size_t tile, auto& pa, auto& pb) {
     const size_t q0 = tile * kWave * NP;
     if (q0 + (size_t)kWave * NP <= in_pieces) {  // full tile (wave-uniform): no per-piece test
 #pragma unroll
@@ -398,7 +402,7 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   };
   // KF = 3: a run is 2^(3+KS) entries; read it back from LDS one output (8 entries) at a time so
   // that only the staged pieces and OUT folded values are live, not the whole run twice.
-  auto stage_and_fold3 = [&](ull2 (&p)[NP], u64 (&t)[IN]) {
+  auto stage_and_fold3 = [&](auto& p, auto& t) {
     if constexpr (KF == 3) {  // (the body only instantiates for run lengths swz_slot supports)
 #pragma unroll
       for (int k = 0; k < NP; ++k) my_lds[swz_slot<NP>(64 * k + lane)] = p[k];
@@ -423,7 +427,7 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   // of the next tile at a time, while the other table is folded out of LDS, was measured and gave nothing: that pass is
   // not waiting for its own loads.)
   constexpr bool kPrefetch = (KS == 3);
-  auto process_tile = [&](size_t tile, size_t next, ull2 (&pa)[NP], ull2 (&pb)[NP]) {
+  auto process_tile = [&](size_t tile, size_t next, auto& pa, auto& pb) {
     u64 a[IN], b[IN];
     if constexpr (KF == 3) {
       stage_and_fold3(pa, a);
@@ -480,7 +484,101 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
   };
-  if constexpr (kPrefetch) {
+  if constexpr (KF == 4) {
+    static_assert(KF != 4 || KS == 2, "the four-variable fold is instantiated with KS = 2 only");
+    // A tile (64 units = 256 outputs per table) is folded in four sub-steps of 64 outputs: the wave loads 8 KiB of each
+    // table CONTIGUOUSLY (1 KiB per instruction, as everywhere), stores them to its LDS region, every lane reads its own
+    // eight pieces = sixteen entries back and folds them with ONE lazy sum of sixteen products - output 64 s + lane of the
+    // tile.  A last bounce through LDS hands lane l the quad 4 l .. 4 l + 3 that the two-round grid and the 16-byte
+    // output pieces want.
+    // Software pipeline: the moment a sub-step's registers have been written to LDS they are refilled with the next
+    // sub-step (of this tile or of the wave's next tile), so loads are in flight WHILE the wave multiplies.  (With one batch of loads per two sub-steps and nothing in flight during the arithmetic the pass
+    // ran at 5.5 TB/s: 8 waves x 32 KiB per CU take ~9.5 us to arrive and each wave then computed ~2 us with nothing
+    // requested.)  LDS ordering inside the wave by wave_lds_sync, NOT wave_lds_fence: the fence would wait for vmcnt(0),
+    // i.e. for the prefetched loads.
+    ull2* const reg_a = my_lds;
+    ull2* const reg_b = my_lds + kWave * NPS;
+    u64* const my_words = reinterpret_cast<u64*>(my_lds);
+    auto load_sub = [&](size_t tile, int o, ull2 (&pa)[NPS], ull2 (&pb)[NPS]) {
+      // (whole tiles only: the host sends this pass tables of >= 2^12 entries)
+      const size_t q0 = tile * kWave * NP + (size_t)o * NPS * kWave;
+#pragma unroll
+      for (int k = 0; k < NPS; ++k) {
+        const size_t q = q0 + (size_t)k * kWave + lane;
+        pa[k] = ld16<kNtLoad>(Ap + q);
+        pb[k] = ld16<kNtLoad>(Bp + q);
+      }
+    };
+    auto stash = [&](ull2* region, const ull2 (&p)[NPS]) {
+#pragma unroll
+      for (int k = 0; k < NPS; ++k) region[swz_slot<NPS>(64 * k + lane)] = p[k];
+    };
+    auto fold16 = [&](const ull2* region) -> u64 {
+      typename F::Acc3 s;
+      f.acc3_zero(s);
+#pragma unroll
+      for (int m = 0; m < NPS; ++m) {
+        const ull2 x = region[swz_slot<NPS>(NPS * lane + m)];
+        f.acc3_mac(s, x.x, fw.w[2 * m]);
+        f.acc3_mac(s, x.y, fw.w[2 * m + 1]);
+      }
+      return f.acc3_get(s);
+    };
+    ull2 pa[NPS], pb[NPS];
+    size_t tile = next_tile();
+    if (tile < n_tiles) load_sub(tile, 0, pa, pb);
+    while (tile < n_tiles) {
+      const size_t next = next_tile();
+      u64 va[OUT], vb[OUT], a[OUT], b[OUT];
+#pragma unroll
+      for (int o = 0; o < OUT; ++o) {
+        stash(reg_a, pa);
+        stash(reg_b, pb);
+        wave_lds_sync();
+        // the registers are free: the next sub-step (of this tile, or the first of the wave's next tile)
+        if (o + 1 < OUT) load_sub(tile, o + 1, pa, pb);
+        else if (next < n_tiles) load_sub(next, 0, pa, pb);
+        va[o] = fold16(reg_a);
+        vb[o] = fold16(reg_b);
+        wave_lds_sync();
+      }
+#pragma unroll
+      for (int o = 0; o < OUT; ++o) {
+        my_words[kWave * o + lane] = va[o];
+        my_words[kWave * OUT + kWave * o + lane] = vb[o];
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int i = 0; i < OUT; ++i) {
+        a[i] = my_words[OUT * lane + i];
+        b[i] = my_words[kWave * OUT + OUT * lane + i];
+      }
+      wave_lds_sync();
+      // outputs: lane l holds pieces 2 l, 2 l + 1 of the tile's 128 output pieces per table; store as pieces 64 k + lane
+      ull2 oa[NPO], ob[NPO];
+#pragma unroll
+      for (int m = 0; m < NPO; ++m) {
+        reg_a[swz_slot<NPO>(NPO * lane + m)] = ull2{a[2 * m], a[2 * m + 1]};
+        reg_b[swz_slot<NPO>(NPO * lane + m)] = ull2{b[2 * m], b[2 * m + 1]};
+      }
+      wave_lds_sync();
+#pragma unroll
+      for (int k = 0; k < NPO; ++k) {
+        oa[k] = reg_a[swz_slot<NPO>(64 * k + lane)];
+        ob[k] = reg_b[swz_slot<NPO>(64 * k + lane)];
+      }
+      wave_lds_sync();
+      const size_t o0 = tile * kWave * NPO;
+#pragma unroll
+      for (int k = 0; k < NPO; ++k) {
+        const size_t q = o0 + (size_t)k * kWave + lane;
+        st16<kNtStore>(A2p + q, oa[k]);
+        st16<kNtStore>(B2p + q, ob[k]);
+      }
+      accumulate_run<F, KS>(f, acc, a, b);
+      tile = next;
+    }
+  } else if constexpr (kPrefetch) {
     ull2 pa[NP], pb[NP];
     size_t tile = next_tile();
     if (tile < n_tiles) load_tile(tile, pa, pb);

@@ -127,6 +127,8 @@ struct sc_ctx {
   u64* d_wg_partials = nullptr;   // [kWgMaxBlocks][kGridChunk]
   u64* d_wg_groups = nullptr;     // [kWgMaxBlocks / 32][kGridChunk]
   unsigned* d_wg_tickets = nullptr;
+  u64* d_gram_totals = nullptr;   // gram_finish_kernel: kWords 64-bit totals + its ticket, all zero at rest (allocated on first use)
+  int gram_log = 26;              // first pass of an unsharded proof on tables of >= 2^gram_log entries: kernels/gram.hpp (0: never)
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
                       // cheaper than the ~25 us of collective latency of each further sharded pass
   // grid cap of the streaming kernels: three 256-thread blocks per CU (set in sc_ctx_create).
@@ -136,7 +138,7 @@ struct sc_ctx {
   int num_cus = 256;
   // blocks of each pass-kernel instantiation that fit on the chip at once ([generic|goldilocks][kf][ks],
   // 0 = not asked yet)
-  int resident_blocks[2][4][4] = {};
+  int resident_blocks[2][5][4] = {};
   int time_kernels = 0;
   int nt_load_log = 22;   // tables of >= 2^this entries are loaded nontemporal (measured: 21-25 equal, 27 and off worse)
   int nt_store_log = 25;  // outputs of >= 2^this entries are stored nontemporal

@@ -9,7 +9,7 @@ from . import _lib
 def plan_proof(num_vars, world=1, transport="none", **options):
     """list of dicts (action, kf, ks, log_in, sharded), in launch order; options: the sc_ctx_set_option names the
     schedule depends on (vars_per_pass, first_pass_vars, grid_pass, grid_log, grid_max_vars, grid_sharded, tail_log,
-    use_mailbox); unknown names raise"""
+    use_mailbox, gram_log); unknown names raise"""
     lib = _lib.load()
     opt = _lib.ScPlanOptions()
     lib.sc_plan_options_default(ctypes.byref(opt))
