@@ -17,6 +17,7 @@ OPTION_SETS = [
     {}, {"grid_pass": 0}, {"vars_per_pass": 1}, {"first_pass_vars": 1}, {"first_pass_vars": 2}, {"first_pass_vars": 3},
     {"grid_max_vars": 1}, {"grid_max_vars": 3}, {"grid_log": 3}, {"grid_log": 26}, {"grid_sharded": 0}, {"grid_sharded": 0, "tail_log": 4},
     {"grid_sharded": 0, "tail_log": 0, "grid_pass": 0}, {"use_mailbox": 0}, {"grid_max_vars": 4, "grid_log": 12, "first_pass_vars": 2},
+    {"gram_log": 0}, {"gram_log": 14}, {"first_pass_vars": 4}, {"first_pass_vars": 4, "grid_log": 10}, {"gram_log": 20, "grid_pass": 0},
 ]
 
 
@@ -43,8 +44,15 @@ def check(steps, n, world, transport, opts):
         elif s["action"] == "rank_pass":
             assert transport == "peer" and sharded and cur_log == kf and s["ks"] == g and 1 <= g <= 3 and kf <= 5
             cur_log, sharded = g, False
+        elif s["action"] == "gram_pass":
+            # the four-round first pass on the matrix cores: unsharded proofs only, first launch only, the default two-round schedule
+            # only, tables of >= 2^gram_log entries (first_pass_vars = 4: any size from 2^14)
+            assert s is steps[0] and kf == 0 and not sharded and s["ks"] == 4 and n >= 6 and cur_log >= 14
+            assert opts.get("vars_per_pass", 2) == 2 and opts.get("use_mailbox", 1) == 1 and opts.get("first_pass_vars", 0) in (0, 4)
+            assert opts.get("first_pass_vars", 0) == 4 or (opts.get("gram_log", 26) > 0 and cur_log >= opts.get("gram_log", 26))
         elif s["action"] == "pass":
-            assert kf <= 3 and 1 <= s["ks"] <= 3 and (s["ks"] < 3 or kf == 0) and cur_log >= kf + s["ks"]
+            assert (kf <= 3 or (kf == 4 and s["ks"] == 2 and steps[0]["action"] == "gram_pass")) and 1 <= s["ks"] <= 3
+            assert (s["ks"] < 3 or kf == 0) and cur_log >= kf + s["ks"]
             assert s["ks"] <= max(opts.get("vars_per_pass", 2), 1) or (kf == 0 and s["ks"] == 3)
             cur_log -= kf
         else:
@@ -71,9 +79,14 @@ def test_known_schedules(plan):
     def sig(steps):
         return [(s["action"], s["kf"], s["ks"], s["log_in"]) for s in steps]
 
-    # the headline: n = 28 on one GPU (bench.py config.schedule of every run)
-    assert sig(plan(28)) == [("pass", 0, 3, 28), ("pass", 3, 2, 28), ("pass", 2, 2, 25), ("pass", 2, 2, 23), ("grid_pass", 2, 5, 21),
-                             ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14), ("grid_pass", 5, 4, 9)]
+    # the headline: n = 28 on one GPU (bench.py config.schedule of every run): four rounds from the matrix-core pass, then seven
+    # launches where the 27-cell first pass (gram_log = 0: rounds 1 to 3) needs eight
+    assert sig(plan(28)) == [("gram_pass", 0, 4, 28), ("pass", 4, 2, 28), ("pass", 2, 2, 24), ("grid_pass", 2, 5, 22), ("grid_pass", 5, 5, 20),
+                             ("grid_pass", 5, 5, 15), ("grid_pass", 5, 5, 10)]
+    assert sig(plan(28, gram_log=0)) == [("pass", 0, 3, 28), ("pass", 3, 2, 28), ("pass", 2, 2, 25), ("pass", 2, 2, 23), ("grid_pass", 2, 5, 21),
+                                         ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14), ("grid_pass", 5, 4, 9)]
+    assert sig(plan(25))[0] == ("pass", 0, 3, 25) and sig(plan(26))[0] == ("gram_pass", 0, 4, 26)
+    assert sig(plan(20, first_pass_vars=4))[:2] == [("gram_pass", 0, 4, 20), ("grid_pass", 4, 4, 20)]
     # BASELINE config 4: n = 28 over 8 ranks, peer transport - seven launches, seven exchanges, no gather
     s8 = plan(28, 8, "peer")
     assert sig(s8) == [("pass", 0, 3, 25), ("pass", 3, 2, 25), ("grid_pass", 2, 5, 22), ("grid_pass", 5, 5, 20), ("grid_pass", 5, 5, 15),

@@ -324,7 +324,8 @@ gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, u
   auto total_of = [&](int w) -> long long {
     return (long long)__hip_atomic_load(totals + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   };
-  const u64 c256 = f.to_mont(f.mul(256, f.one()));   // (mul(z, R mod p) = z mod p for any 64-bit z)
+  // 2^160 * 2^-64 mod p for the bits of the integer beyond 2^160 (only the largest tables reach them)
+  const u64 c96 = f.mul(f.r_squared(), f.mul(f.r_squared(), 1ull << 32));
   for (int pair = tid; pair < X * X; pair += kBlock) {
     const int x = pair / X, y = pair % X;
     // T_ij = sum_rows u_i u'_j = G + 128 (Su_i + Su'_j) - 16384 rows  (>= 0, < 2^16 rows); all 80 loads in flight
@@ -338,31 +339,49 @@ gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, u
     for (int i = 0; i < 8; ++i)
 #pragma unroll
       for (int j = 0; j < 8; ++j) gg[8 * i + j] = total_of(gram_word<K1>(8 * x + i, 8 * y + j));
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      su_a[i] = 128 * su_a[i] - 16384 * (long long)rows;
+      su_b[i] = 128 * su_b[i];
+    }
     unsigned long long diag[15];
 #pragma unroll
     for (int s = 0; s < 15; ++s) diag[s] = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) diag[i + j] += (unsigned long long)(gg[8 * i + j] + 128 * (su_a[i] + su_b[j]) - 16384 * (long long)rows);
-    // sum_s diag[s] 2^(8s) mod p by Horner on plain residues (mul(v, mont(256)) = 256 v), then the Montgomery products'
-    // factor 2^-64: from_mont
-    u64 v = 0;
+      for (int j = 0; j < 8; ++j) diag[i + j] += (unsigned long long)(gg[8 * i + j] + su_a[i] + su_b[j]);   // < 8 * 2^16 * rows < 2^49
+    // the integer sum_s diag[s] 2^(8s) in three words (+ what passes 2^160), then ONE reduction: wide_get is
+    // (w2 2^128 + w1 2^64 + w0) 2^-64 mod p - the factor 2^-64 is the Montgomery products'
+    u64 w[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int s = 14; s >= 0; --s) v = f.add(f.mul(v, c256), f.mul(diag[s], f.one()));
-    M[pair] = f.from_mont(v);
+    for (int s = 0; s < 15; ++s) {
+      constexpr int kBits = 8;
+      const int wd = (kBits * s) / 64, bt = (kBits * s) % 64;
+      const u64 lo = diag[s] << bt, hi = bt ? diag[s] >> (64 - bt) : 0;
+      u64 t;
+      bool c = __builtin_add_overflow(w[wd], lo, &t);
+      w[wd] = t;
+      bool c2 = __builtin_add_overflow(w[wd + 1], hi, &t);
+      bool c3 = __builtin_add_overflow(t, (u64)(c ? 1 : 0), &t);
+      w[wd + 1] = t;
+      if (wd + 2 < 4) w[wd + 2] += (c2 ? 1 : 0) + (c3 ? 1 : 0);
+    }
+    // (word 3 stays zero: the sum is below 2^49 * 2^112 * 2; bits 160.. of word 2 go through c96)
+    u64 v = f.wide_get(w[0], w[1], (u32)w[2]);
+    if (w[2] >> 32) v = f.add(v, f.mul(w[2] >> 32, c96));
+    M[pair] = v;
   }
   __syncthreads();
   // M -> cells, one variable at a time: the pair (bit j of x, bit j of y) becomes the digit d_j in {0, 1, inf}:
   // d = 0 / 1 pins both bits; inf is (a1 - a0)(b1 - b0) = M11 - M10 - M01 + M00 in that variable.  Index of the working
   // array after j variables: ((x >> j) * (X >> j) + (y >> j)) * 3^j + digits, digits = sum_{i<j} d_i 3^(j-1-i) - after K1
-  // variables the cell index itself (variable 0 on the slowest axis).
+  // variables the cell index itself (variable 0 on the slowest axis).  (Unrolled: every division is by a constant.)
   u64* src = M;
   u64* dst = W;
-  int side = X, pow3 = 1;
-#pragma unroll 1
+#pragma unroll
   for (int j = 0; j < K1; ++j) {
-    const int half = side / 2, n_out = half * half * pow3 * 3;
+    const int side = X >> j, half = side / 2, pow3 = kPow3[j], n_out = half * half * pow3 * 3;
     for (int o = tid; o < n_out; o += kBlock) {
       const int d = o % 3, dig = (o / 3) % pow3, yx = o / (3 * pow3), yr = yx % half, xr = yx / half;
       auto at = [&](int bx, int by) { return src[((2 * xr + bx) * side + (2 * yr + by)) * pow3 + dig]; };
@@ -374,8 +393,6 @@ gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, u
     }
     __syncthreads();
     u64* t = src; src = dst; dst = t;
-    side = half;
-    pow3 *= 3;
   }
   if (tid < cells) __hip_atomic_store(mailbox + kMailboxWide + tid, src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   // the sequence word behind every wave's cell stores; then back to rest for the next launch (kernel-boundary ordering)

@@ -14,7 +14,10 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glob_ptr_t;
 
-constexpr int NS = 4;                    // stages
+#ifndef GRAM_NS
+#define GRAM_NS 4
+#endif
+constexpr int NS = GRAM_NS;              // stages (even)
 constexpr int kTabBytes = 8192;          // bytes per table and stage
 constexpr int kStageBytes = 2 * kTabBytes;
 constexpr int kThreads = 512;
@@ -54,7 +57,11 @@ __global__ void __launch_bounds__(kThreads) gram_kernel(const unsigned char* __r
   for (int u = 0; u < 2; ++u) {
     const int i = 2 * wave + u, tab = i >> 3, piece = i & 7;          // piece: 1 KiB of the table's 8 KiB
     const int row = piece * (1024 / G::RB) + lane / G::CPR, pos = lane % G::CPR;
+#ifdef GRAM_LINEAR
+    src_off[u] = (size_t)row * G::RB + 16 * pos;   // timing experiment: unswizzled source (results are wrong)
+#else
     src_off[u] = (size_t)row * G::RB + 16 * swz<K1>(row, pos);
+#endif
     dst_off[u] = (unsigned)(tab * kTabBytes + piece * 1024);         // wave-uniform; the hardware adds lane * 16
     tab_of[u] = tab ? B : A;
   }
@@ -82,6 +89,11 @@ __global__ void __launch_bounds__(kThreads) gram_kernel(const unsigned char* __r
 #pragma unroll
       for (int t = 0; t < 2; ++t) ba[(b * G::KSUB + ks) * 2 + t] = tr_addr(1, (G::RB / 4) * nq + 32 * b, ks, t);
   static_assert(G::NA == 8 && G::NBR == 4, "eight + four reads per stage");
+  unsigned aa2[G::NA], ba2[G::NBR];   // the stages beyond 64 KiB (the offset field of a DS instruction has 16 bits)
+#pragma unroll
+  for (int i = 0; i < G::NA; ++i) aa2[i] = aa[i] + 65536;
+#pragma unroll
+  for (int i = 0; i < G::NBR; ++i) ba2[i] = ba[i] + 65536;
 
   v16i acc[G::MB][G::NBK];
 #pragma unroll
@@ -97,14 +109,19 @@ __global__ void __launch_bounds__(kThreads) gram_kernel(const unsigned char* __r
   const unsigned long long t0 = __builtin_amdgcn_s_memtime(), w0 = __builtin_amdgcn_s_memrealtime();
 
   v2i r0[12], r1[12];
-#define READ12(R, OFF)                                                                                                              \
+#define READ12X(R, AA, BA, OFF)                                                                                                           \
   asm volatile(TR8(0, 12, 24) TR8(1, 13, 24) TR8(2, 14, 24) TR8(3, 15, 24) TR8(4, 16, 24) TR8(5, 17, 24) TR8(6, 18, 24) TR8(7, 19, 24)   \
                TR8(8, 20, 24) TR8(9, 21, 24) TR8(10, 22, 24) "ds_read_b64_tr_b8 %11, %23 offset:%24"                               \
                : "=&v"(R[0]), "=&v"(R[1]), "=&v"(R[2]), "=&v"(R[3]), "=&v"(R[4]), "=&v"(R[5]), "=&v"(R[6]), "=&v"(R[7]), "=&v"(R[8]),   \
                  "=&v"(R[9]), "=&v"(R[10]), "=&v"(R[11])                                                                           \
-               : "v"(aa[0]), "v"(aa[1]), "v"(aa[2]), "v"(aa[3]), "v"(aa[4]), "v"(aa[5]), "v"(aa[6]), "v"(aa[7]), "v"(ba[0]), "v"(ba[1]),   \
-                 "v"(ba[2]), "v"(ba[3]), "n"(OFF)                                                                                   \
+               : "v"(AA[0]), "v"(AA[1]), "v"(AA[2]), "v"(AA[3]), "v"(AA[4]), "v"(AA[5]), "v"(AA[6]), "v"(AA[7]), "v"(BA[0]), "v"(BA[1]),   \
+                 "v"(BA[2]), "v"(BA[3]), "n"(OFF)                                                                                   \
                : "memory")
+#define READ12(R, OFF)                                               \
+  do {                                                               \
+    if ((OFF) < 65536) READ12X(R, aa, ba, (OFF) % 65536);            \
+    else READ12X(R, aa2, ba2, (OFF) % 65536);                        \
+  } while (0)
 #define WAIT12(R)                                                                                                                   \
   asm volatile("s_waitcnt lgkmcnt(0)"                                                                                               \
                : "+v"(R[0]), "+v"(R[1]), "+v"(R[2]), "+v"(R[3]), "+v"(R[4]), "+v"(R[5]), "+v"(R[6]), "+v"(R[7]), "+v"(R[8]), "+v"(R[9]),   \
@@ -175,13 +192,22 @@ __global__ void __launch_bounds__(kThreads) gram_kernel(const unsigned char* __r
     WAIT12(r0);
     for (size_t s = 0; s < my_steps; s += NS) {
       const bool more = s + NS < my_steps;
-      TOP(s, 0);     READ12(r1, 1 * kStageBytes); compute(r0); WAIT12(r1);
-      TOP(s + 1, 1); READ12(r0, 2 * kStageBytes); compute(r1); WAIT12(r0);
-      TOP(s + 2, 2); READ12(r1, 3 * kStageBytes); compute(r0); WAIT12(r1);
-      TOP(s + 3, 3);
-      if (more) READ12(r0, 0);
-      compute(r1);
-      if (more) WAIT12(r0);
+#define PAIR(I)                                                                                       \
+      TOP(s + (I), (I));     READ12(r1, ((I) + 1) * kStageBytes); compute(r0); WAIT12(r1);            \
+      TOP(s + (I) + 1, (I) + 1);                                                                      \
+      if ((I) + 2 < NS) { READ12(r0, (((I) + 2) % NS) * kStageBytes); compute(r1); WAIT12(r0); }      \
+      else { if (more) READ12(r0, 0); compute(r1); if (more) WAIT12(r0); }
+      PAIR(0)
+#if GRAM_NS >= 4
+      PAIR(2)
+#endif
+#if GRAM_NS >= 6
+      PAIR(4)
+#endif
+#if GRAM_NS >= 8
+      PAIR(6)
+#endif
+#undef PAIR
     }
   }
   if (stamps && tid == 0) {
