@@ -89,17 +89,18 @@ def test_gram_byte_patterns(p, kind):
     ctx.close()
 
 
-def test_gram_is_the_default_from_2_26_and_agrees_with_the_three_round_schedule():
-    """n = 26: the default schedule opens with the gram pass; its transcript equals the one of the 27-cell first pass
-    (gram_log = 0) bit for bit, and the verifier's identities hold"""
+def test_gram_is_the_default_from_2_28_and_agrees_with_the_three_round_schedule():
+    """n = 28 (the headline size; below it the 27-cell first pass is as fast or faster, profiles/r04_gram_vs_27cell.txt): the default
+    schedule opens with the gram pass; its transcript equals the one of the 27-cell first pass (gram_log = 0) bit for bit, and the
+    verifier's identities hold"""
     pkg = load_package()
     F = pkg.Field(GOLD)
-    n = 26
+    n = 28
     assert pkg.schedule.plan_proof(n)[0]["action"] == "gram_pass"
     assert pkg.schedule.plan_proof(n, gram_log=0)[0] == {"action": "pass", "kf": 0, "ks": 3, "log_in": n, "sharded": False}
-    assert pkg.schedule.plan_proof(25)[0]["action"] == "pass"
+    assert pkg.schedule.plan_proof(27)[0]["action"] == "pass"
     out = []
-    for gram_log in (26, 0):
+    for gram_log in (28, 0):
         ctx = pkg.Context(F)
         ctx.set_option("gram_log", gram_log)
         a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)

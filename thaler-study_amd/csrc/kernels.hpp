@@ -212,16 +212,10 @@ __device__ __forceinline__ int swz_slot(int q) {
   const int l = q / NP;
   return (q & ~(NP - 1)) | ((q ^ (l >> SH)) & (NP - 1));
 }
-__device__ __forceinline__ void wave_lds_fence() {
-  // orders this wave's LDS writes before its later LDS reads (s_waitcnt lgkmcnt(0)) and
-  // stops the compiler from moving them across
-  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-  __builtin_amdgcn_wave_barrier();
-}
 // LDS hand-off between the lanes of ONE wave: a wave's LDS operations execute in order, so all that is needed is
-// that the earlier ones have been issued and returned and that the compiler keeps the order.  (wave_lds_fence()
-// is a workgroup-scope fence: it would also wait for the wave's global stores - here the folded entries on
-// their way out, which nobody in this kernel waits for.)
+// that the earlier ones have been issued and returned and that the compiler keeps the order.  (A workgroup-scope
+// fence - what the transposes used until round 4 - also waits for vmcnt(0): for the wave's global stores, the folded
+// entries on their way out, which nobody in these kernels waits for, and for any load issued ahead.)
 __device__ __forceinline__ void wave_lds_sync() {
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_wave_barrier();
@@ -232,10 +226,10 @@ __device__ __forceinline__ void transpose_to_runs(ull2* __restrict__ lds, ull2 (
   if constexpr (NP > 1) {
 #pragma unroll
     for (int k = 0; k < NP; ++k) lds[swz_slot<NP>(64 * k + lane)] = v[k];
-    wave_lds_fence();
+    wave_lds_sync();
 #pragma unroll
     for (int m = 0; m < NP; ++m) v[m] = lds[swz_slot<NP>(NP * lane + m)];
-    wave_lds_fence();
+    wave_lds_sync();
   }
 }
 // in: v[m] = piece NP*lane + m; out: v[k] = piece 64k + lane
@@ -244,10 +238,10 @@ __device__ __forceinline__ void transpose_to_pieces(ull2* __restrict__ lds, ull2
   if constexpr (NP > 1) {
 #pragma unroll
     for (int m = 0; m < NP; ++m) lds[swz_slot<NP>(NP * lane + m)] = v[m];
-    wave_lds_fence();
+    wave_lds_sync();
 #pragma unroll
     for (int k = 0; k < NP; ++k) v[k] = lds[swz_slot<NP>(64 * k + lane)];
-    wave_lds_fence();
+    wave_lds_sync();
   }
 }
 

@@ -100,7 +100,7 @@ typedef int gram_v16i __attribute__((ext_vector_type(16)));
 template <int K1>
 __global__ void __launch_bounds__(kGramThreads)
 gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, unsigned n_partials, unsigned steps_per_partial,
-                 int* __restrict__ partials) {
+                 int* __restrict__ partials, unsigned long long* __restrict__ totals) {
   typedef GramGeo<K1> G;
   constexpr int NS = kGramStages;
   extern __shared__ __attribute__((aligned(16))) unsigned char gram_lds[];
@@ -109,6 +109,8 @@ gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __res
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mh = wave >> 2, nq = wave & 3;
   const int h = lane >> 5, g2 = (lane >> 4) & 1, ll = lane & 15, q = ll >> 1, p = ll & 1;
+  // gram_finish_kernel's totals and its ticket (the word behind them) start from zero: cleared here, where it costs nothing
+  for (unsigned w = blockIdx.x * kGramThreads + tid; w < (unsigned)G::kWords + 1; w += gridDim.x * kGramThreads) totals[w] = 0;
   // DMA: 16 instructions of 1 KiB per stage, two per wave (i < 8: table a).  Lane L of an instruction lands at
   // row r0 + L / CPR, chunk position L % CPR, and fetches the chunk that belongs there.
   size_t src_off[2];
@@ -271,10 +273,10 @@ gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __res
 // The partials -> the 3^K1 cells of rounds 1..K1 in the host mailbox (the wide part, whole residues, then the sequence
 // word: exactly what an unsharded wgrid_pass_kernel<F, K1> with nothing to fold leaves - the host cannot tell them apart).
 //  1. every block adds a slice of the partials (grid = kWords / 256 word groups x `splits` partial groups) into `totals`
-//     (64-bit, agent-scope atomics; at rest all zero);
+//     (64-bit, agent-scope atomics; zeroed, with the ticket behind them, by gram_pass_kernel);
 //  2. the block that draws the last ticket turns G, the byte sums and the row count into M[x][y] = sum a (*) b mod p
 //     (thread = (x, y): 64 limb products -> 15 anti-diagonal sums -> Horner in 2^8), forms the cells as signed sums of M,
-//     publishes, and leaves totals and ticket at zero again.
+//     publishes.
 template <class F, int K1>
 __global__ void __launch_bounds__(kBlock)
 gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, unsigned long long rows, unsigned long long* __restrict__ totals,
@@ -395,12 +397,10 @@ gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, u
     u64* t = src; src = dst; dst = t;
   }
   if (tid < cells) __hip_atomic_store(mailbox + kMailboxWide + tid, src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  // the sequence word behind every wave's cell stores; then back to rest for the next launch (kernel-boundary ordering)
+  // the sequence word behind every wave's cell stores
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) __hip_atomic_store(mailbox + kMailboxSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  for (int w = tid; w < G::kWords; w += kBlock) __hip_atomic_store(totals + w, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace sc

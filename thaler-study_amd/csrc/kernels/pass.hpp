@@ -356,7 +356,7 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   // the tile transposes; after the loop the same bytes hold a chunk of every thread's accumulators (reduce_cells_lds)
   // KF = 4: a unit is 64 entries = 32 pieces per table - too many to stage at once; its four outputs (16 entries = 8 pieces
   // each) are produced one after the other, 8 pieces per lane and table in flight (NPS)
-  constexpr int NPS = 8, NPL = (KF == 4) ? 2 * NPS : NP;   // pieces per lane the wave's LDS region is laid out for (KF = 4: both tables' sub-steps)
+  constexpr int NPS = 8, NPL = (KF == 4) ? NPS + NPS / 2 : NP;   // pieces per lane the wave's LDS region is laid out for (KF = 4: a sub-step + the exchange area)
   constexpr int kTransposeSlots = (NP > 1 || NPO > 1) ? kWaves * kWave * NPL : 1;
   constexpr int kChunkCells = reduce_chunk_cells<typename F::Acc, BS>();
   constexpr int kReduceSlots = (NS >= 9) ? (int)(((NS < kChunkCells ? NS : kChunkCells) * BS * sizeof(typename F::Acc) + sizeof(ull2) - 1) / sizeof(ull2)) : 1;
@@ -406,7 +406,7 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     if constexpr (KF == 3) {  // (the body only instantiates for run lengths swz_slot supports)
 #pragma unroll
       for (int k = 0; k < NP; ++k) my_lds[swz_slot<NP>(64 * k + lane)] = p[k];
-      wave_lds_fence();
+      wave_lds_sync();
 #pragma unroll
       for (int o = 0; o < OUT; ++o) {
         u64 v[8];
@@ -418,7 +418,7 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
         fold_run<F, 3, 8>(f, v, fw);
         t[o] = v[0];
       }
-      wave_lds_fence();
+      wave_lds_sync();
     }
   };
   // The 27-cell grid runs at two waves per SIMD and is ALU-heavy: it cannot count on other
@@ -496,29 +496,31 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     // ran at 5.5 TB/s: 8 waves x 32 KiB per CU take ~9.5 us to arrive and each wave then computed ~2 us with nothing
     // requested.)  LDS ordering inside the wave by wave_lds_sync, NOT wave_lds_fence: the fence would wait for vmcnt(0),
     // i.e. for the prefetched loads.
-    ull2* const reg_a = my_lds;
-    ull2* const reg_b = my_lds + kWave * NPS;
-    u64* const my_words = reinterpret_cast<u64*>(my_lds);
-    auto load_sub = [&](size_t tile, int o, ull2 (&pa)[NPS], ull2 (&pb)[NPS]) {
+    // Which sub-step a wave is on decides which HBM channels it reads: a sub-step is 8 KiB of each table at tile * 32 KiB +
+    // o * 8 KiB, the tiles of a block's eight waves lie a multiple of 8 MiB apart (the same channels), and the waves of a
+    // block - and, through the memory system's back-pressure, the blocks of the grid - fall into step.  Taken in the same
+    // order everywhere, a quarter of the channels would serve the whole chip at any moment (with the multiplications removed
+    // - perfect lockstep - the pass took 1 530 us instead of 800).  So wave w walks the sub-steps in the order
+    // (i + w) mod 4 for table a and (i + w + 2) mod 4 for table b.
+    ull2* const reg = my_lds;                                   // 8 KiB: one table's sub-step
+    u64* const xchg = reinterpret_cast<u64*>(my_lds + kWave * NPS);   // 4 KiB: the tile's 256 + 256 outputs
+    const int rot = wave & 3;
+    auto load_sub = [&](const ull2* __restrict__ T, size_t tile, int o, ull2 (&p)[NPS]) {
       // (whole tiles only: the host sends this pass tables of >= 2^12 entries)
-      const size_t q0 = tile * kWave * NP + (size_t)o * NPS * kWave;
+      const ull2* src = T + tile * kWave * NP + (size_t)o * NPS * kWave + lane;
 #pragma unroll
-      for (int k = 0; k < NPS; ++k) {
-        const size_t q = q0 + (size_t)k * kWave + lane;
-        pa[k] = ld16<kNtLoad>(Ap + q);
-        pb[k] = ld16<kNtLoad>(Bp + q);
-      }
+      for (int k = 0; k < NPS; ++k) p[k] = ld16<kNtLoad>(src + k * kWave);
     };
-    auto stash = [&](ull2* region, const ull2 (&p)[NPS]) {
+    auto stash = [&](const ull2 (&p)[NPS]) {
 #pragma unroll
-      for (int k = 0; k < NPS; ++k) region[swz_slot<NPS>(64 * k + lane)] = p[k];
+      for (int k = 0; k < NPS; ++k) reg[swz_slot<NPS>(64 * k + lane)] = p[k];
     };
-    auto fold16 = [&](const ull2* region) -> u64 {
+    auto fold16 = [&]() -> u64 {
       typename F::Acc3 s;
       f.acc3_zero(s);
 #pragma unroll
       for (int m = 0; m < NPS; ++m) {
-        const ull2 x = region[swz_slot<NPS>(NPS * lane + m)];
+        const ull2 x = reg[swz_slot<NPS>(NPS * lane + m)];
         f.acc3_mac(s, x.x, fw.w[2 * m]);
         f.acc3_mac(s, x.y, fw.w[2 * m + 1]);
       }
@@ -526,46 +528,52 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     };
     ull2 pa[NPS], pb[NPS];
     size_t tile = next_tile();
-    if (tile < n_tiles) load_sub(tile, 0, pa, pb);
+    if (tile < n_tiles) {
+      load_sub(Ap, tile, rot, pa);
+      load_sub(Bp, tile, rot ^ 2, pb);
+    }
     while (tile < n_tiles) {
       const size_t next = next_tile();
-      u64 va[OUT], vb[OUT], a[OUT], b[OUT];
-#pragma unroll
-      for (int o = 0; o < OUT; ++o) {
-        stash(reg_a, pa);
-        stash(reg_b, pb);
-        wave_lds_sync();
-        // the registers are free: the next sub-step (of this tile, or the first of the wave's next tile)
-        if (o + 1 < OUT) load_sub(tile, o + 1, pa, pb);
-        else if (next < n_tiles) load_sub(next, 0, pa, pb);
-        va[o] = fold16(reg_a);
-        vb[o] = fold16(reg_b);
-        wave_lds_sync();
-      }
-#pragma unroll
-      for (int o = 0; o < OUT; ++o) {
-        my_words[kWave * o + lane] = va[o];
-        my_words[kWave * OUT + kWave * o + lane] = vb[o];
-      }
-      wave_lds_sync();
 #pragma unroll
       for (int i = 0; i < OUT; ++i) {
-        a[i] = my_words[OUT * lane + i];
-        b[i] = my_words[kWave * OUT + OUT * lane + i];
+        const int oa = (i + rot) & 3, ob = oa ^ 2, na = (i + 1 + rot) & 3;
+        // table a, then table b, through the same 8 KiB: the moment a table's registers are in LDS they are refilled with
+        // the wave's next sub-step (of this tile, or the first of its next tile), so loads are in flight while it multiplies
+        stash(pa);
+        wave_lds_sync();
+        if (i + 1 < OUT) load_sub(Ap, tile, na, pa);
+        else if (next < n_tiles) load_sub(Ap, next, na, pa);
+        const u64 xa = fold16();
+        wave_lds_sync();
+        stash(pb);
+        wave_lds_sync();
+        if (i + 1 < OUT) load_sub(Bp, tile, na ^ 2, pb);
+        else if (next < n_tiles) load_sub(Bp, next, na ^ 2, pb);
+        const u64 xb = fold16();
+        xchg[kWave * oa + lane] = xa;
+        xchg[kWave * OUT + kWave * ob + lane] = xb;
+        wave_lds_sync();
+      }
+      u64 a[OUT], b[OUT];
+#pragma unroll
+      for (int i = 0; i < OUT; ++i) {
+        a[i] = xchg[OUT * lane + i];
+        b[i] = xchg[kWave * OUT + OUT * lane + i];
       }
       wave_lds_sync();
+      ull2* const reg_a = reg;
       // outputs: lane l holds pieces 2 l, 2 l + 1 of the tile's 128 output pieces per table; store as pieces 64 k + lane
       ull2 oa[NPO], ob[NPO];
 #pragma unroll
       for (int m = 0; m < NPO; ++m) {
         reg_a[swz_slot<NPO>(NPO * lane + m)] = ull2{a[2 * m], a[2 * m + 1]};
-        reg_b[swz_slot<NPO>(NPO * lane + m)] = ull2{b[2 * m], b[2 * m + 1]};
+        reg_a[kWave * NPO + swz_slot<NPO>(NPO * lane + m)] = ull2{b[2 * m], b[2 * m + 1]};
       }
       wave_lds_sync();
 #pragma unroll
       for (int k = 0; k < NPO; ++k) {
         oa[k] = reg_a[swz_slot<NPO>(64 * k + lane)];
-        ob[k] = reg_b[swz_slot<NPO>(64 * k + lane)];
+        ob[k] = reg_a[kWave * NPO + swz_slot<NPO>(64 * k + lane)];
       }
       wave_lds_sync();
       const size_t o0 = tile * kWave * NPO;
