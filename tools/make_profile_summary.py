@@ -51,6 +51,12 @@ def is_hot(name):
 
 def describe(name):
     """(kind, kf, ks) of a hot kernel from its demangled name"""
+    m = re.search(r"gram_pass_kernel<(\d)>", name)
+    if m:
+        return "gram_pass", 0, int(m.group(1))
+    m = re.search(r"gram_finish_kernel<sc::\w+, (\d)>", name)
+    if m:
+        return "gram_finish", 0, int(m.group(1))
     if "wgrid_pass_kernel<" in name:
         return "grid_pass", -1, -1       # kf, ks from bench.py's schedule
     m = re.search(r"pass_kernel<sc::\w+, (\d), (\d)(?:, \d)?>", name)
@@ -66,7 +72,7 @@ def describe(name):
 
 
 if workload == "prover":   # a proof is passes only (the evaluate launches behind it are bench.py's parity gate)
-    HOT = ("pass_kernel<", "wgrid_pass_kernel<")
+    HOT = ("pass_kernel<", "wgrid_pass_kernel<", "gram_finish_kernel<")   # ("pass_kernel<" also matches gram_pass_kernel<)
 trace = [r for r in csv.DictReader(open(one(d_stats, "*_kernel_trace.csv"))) if is_hot(r["Kernel_Name"])]
 
 
@@ -75,7 +81,7 @@ def split_steps(rows):
     steps, cur = [], []
     for r in rows:
         kind, kf, ks = describe(r["Kernel_Name"])
-        start = (kind == "pass" and kf == 0) if workload == "prover" else (kind == "evaluate" and (not cur or describe(cur[-1]["Kernel_Name"])[0] != "evaluate"))
+        start = ((kind == "pass" and kf == 0) or kind == "gram_pass") if workload == "prover" else (kind == "evaluate" and (not cur or describe(cur[-1]["Kernel_Name"])[0] != "evaluate"))
         if start and cur:
             steps.append(cur)
             cur = []
@@ -111,6 +117,10 @@ def _bench_name(kind, kf, ks, log_in):
         return "sc::pass_kernel<GoldilocksMont,%d,%d> on 2^%d-entry tables" % (kf, ks, log_in)
     if kind == "grid_pass":
         return "sc::wgrid_pass_kernel<GoldilocksMont,ks> (kf=%d, ks=%d) on 2^%d-entry tables" % (kf, ks, log_in)
+    if kind == "gram_pass":
+        return "sc::gram_pass_kernel<%d> (rounds 1..%d from one read) on 2^%d-entry tables" % (ks, ks, log_in)
+    if kind == "gram_finish":
+        return "sc::gram_finish_kernel<GoldilocksMont,%d> (partials -> %d cells) behind the 2^%d-entry pass" % (ks, 3 ** ks, log_in)
     if kind == "evaluate":
         return "sc::evaluate_kernel<GoldilocksMont> on a 2^%d-entry table" % log_in
     if kind == "fold":
@@ -157,6 +167,9 @@ for i, r in enumerate(last):
         need = 8 * 2 ** n + (8 * 2 ** (n - k_fix) if k_fix else 0)
     pmc = fetch[i] * 2 * 1024 + write[i] * 1024
     name = bench_name(kind, kf, ks, log_in)
+    if kind in ("gram_pass", "gram_finish"):   # the partials between the two: from the launch log of the un-profiled run
+        rec = next((k for k in (bench or {}).get("roofline", {}).get("kernels", []) if k["kernel"] == name), None)
+        need = rec["bytes_per_launch"] if rec else (16 * 2 ** size if kind == "gram_pass" else 0)
     per_kernel.setdefault(name, []).append(pmc)
     lines.append("| %d | `%s` | 2^%d | %s | %.1f | %.4g | %.4g | %.2f | %.3f |" % (i, name, log_in, grid, t, need, pmc, need / t / 1e6, need / t / 1e6 / 8))
     tot_t += t
