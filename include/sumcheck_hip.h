@@ -99,8 +99,14 @@ const char* sc_last_error(const sc_ctx* ctx);
 /* Tunables (all have working defaults; they exist for measurements and tests):
  *   "vars_per_pass"    rounds served by one device pass: 1 | 2 (default 2)
  *   "first_pass_vars"  rounds served by the prover's first pass, which has nothing to fold:
- *                      1 | 2 | 3, default 0 = three for tables of >= 2^18 entries, two below
- *                      (never more than vars_per_pass allows)
+ *                      1 | 2 | 3 | 4, default 0 = four for unsharded tables of >= 2^"gram_log" entries (below), else three
+ *                      for tables of >= 2^18 entries, two below (never more than vars_per_pass allows).  4 = the
+ *                      matrix-core pass at any size from 2^14 entries (where it does not apply - sharded provers,
+ *                      smaller tables, "vars_per_pass" 1 - the same as 0)
+ *   "gram_log"         (default 28; 0 = never, else 14..40) an unsharded proof on tables of >= 2^gram_log entries opens
+ *                      with gram_pass_kernel: rounds 1..4 from ONE read, as exact integer limb products of the tables'
+ *                      bytes on the int8 matrix cores (the kernel does not depend on the modulus), + gram_finish_kernel;
+ *                      the pass behind it folds four variables (pass_kernel<4,2>).  DESIGN.md section 4
  *   "grid_pass"        the passes whose FOLDED tables have <= 2^"grid_log" (default 20) entries serve up to
  *                      "grid_max_vars" (default 5) rounds each and fold up to five pending challenges at once
  *                      (wgrid_pass_kernel); "grid_blocks" caps the launch (0 = what fits on the chip at once).

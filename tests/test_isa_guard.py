@@ -68,6 +68,23 @@ def test_first_pass_occupancy_and_no_scratch(isa):
         assert re.search(r"ScratchSize \[bytes/lane\]: 0\b", b), name
 
 
+def test_gram_pass_is_what_the_design_says(isa):
+    """kernels/gram.hpp: the first pass on the int8 matrix cores - four MFMAs and twelve transposed LDS reads per stage and
+    operand set, its tiles brought in by LDS-DMA, no scratch, registers for two waves per SIMD; the fold behind it keeps
+    its loads out of the way of its LDS traffic (no vmcnt(0) behind an LDS wait inside the tile loop)"""
+    text, usage = isa
+    u = kernel_usage(usage, "gram_pass_kernelILi4E")
+    assert u["ScratchSize [bytes/lane]"] == 0 and u["VGPRs Spill"] == 0 and u["VGPRs"] <= 168, u
+    m = re.search(r"^(_ZN2sc16gram_pass_kernelILi4E\S*):[^\n]*\n(.*?)\n\.Lfunc_end", text, flags=re.S | re.M)
+    assert m
+    body = m.group(2)
+    assert body.count("v_mfma_i32_32x32x32_i8") == 16, body.count("v_mfma_i32_32x32x32_i8")      # four stages x four
+    assert body.count("ds_read_b64_tr_b8") == 12 * 5, body.count("ds_read_b64_tr_b8")            # prologue + four stages
+    assert body.count("global_load_lds_dwordx4") >= 8 and "scratch_" not in body
+    u = kernel_usage(usage, "pass_kernel%sLi4ELi2ELi1E" % GOLD)
+    assert u["ScratchSize [bytes/lane]"] == 0 and u["VGPRs Spill"] == 0 and u["Occupancy [waves/SIMD]"] >= 2, u
+
+
 def test_streaming_variants_carry_nt_and_cached_variants_do_not(isa):
     text, _ = isa
     nt1 = kernel_body(text, "pass_kernel%sLi0ELi3ELi1E" % GOLD)
