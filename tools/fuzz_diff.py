@@ -81,7 +81,7 @@ def rand_elem(rng, F):
 
 def one_iteration(rng, nprng, max_n, stats):
     p = rand_prime(rng)
-    n = rng.randint(1, max_n)
+    n = rng.randint(1, max_n) if rng.random() < 0.7 else rng.randint(min(14, max_n), max_n)   # (the matrix-core first pass: from 2^14)
     F = pkg.Field(p)
     o = oracle(p)
     n_dev = rng.choice([0, 0, 0, 1, 2, 4, 8])
@@ -90,9 +90,10 @@ def one_iteration(rng, nprng, max_n, stats):
     ctx = pkg.Context(F, devices=[0] * n_dev) if n_dev else pkg.Context(F)
     opts = {}
     if rng.random() < 0.8:
-        opts = {"vars_per_pass": rng.choice([1, 2]), "first_pass_vars": rng.randint(0, 3), "grid_pass": rng.randint(0, 1),
+        opts = {"vars_per_pass": rng.choice([1, 2]), "first_pass_vars": rng.choice([0, 1, 2, 3, 4, 4]), "grid_pass": rng.randint(0, 1),
                 "grid_log": rng.choice([0, 3, 6, 9, 12, 16, 20]), "grid_max_vars": rng.randint(1, 5), "tail_log": rng.choice([0, 2, 5, 9, 14]),
-                "max_blocks": rng.choice([1, 2, 3, 7, 64, 256, 1024]), "grid_blocks": rng.choice([0, 0, 1, 2, 5, 64])}
+                "max_blocks": rng.choice([1, 2, 3, 7, 64, 256, 1024]), "grid_blocks": rng.choice([0, 0, 1, 2, 5, 64]),
+                "gram_log": rng.choice([0, 14, 15, 17, 28])}
         if not n_dev and rng.random() < 0.2:
             opts["use_mailbox"] = 0
         for k, v in opts.items():
@@ -151,6 +152,8 @@ def one_iteration(rng, nprng, max_n, stats):
             got.pop()
         assert got == want, (desc, "restrict_poly")
     stats["n_by_dev"][n_dev] = stats["n_by_dev"].get(n_dev, 0) + 1
+    if pkg.schedule.plan_proof(n, **{k: v for k, v in opts.items() if k not in ("max_blocks", "grid_blocks")})[0]["action"] == "gram_pass" and n_dev <= 1:
+        stats["gram"] = stats.get("gram", 0) + 1
     del a, b, g
     ctx.close()
 
@@ -268,9 +271,9 @@ def main():
     except BaseException:
         print("FAILED at iteration %d (seed %d): %s" % (it, seed, stats["last"]), flush=True)
         raise
-    print("fuzz_diff: %d iterations in %.0f s, seed %d, max_n %d, 0 mismatches; product-prover iterations by handle size (0 = plain context): %s; GKR layers %d, triangle graphs %d, refused as unsupported %d" % (
+    print("fuzz_diff: %d iterations in %.0f s, seed %d, max_n %d, 0 mismatches; product-prover iterations by handle size (0 = plain context): %s; GKR layers %d, triangle graphs %d, refused as unsupported %d; proofs that opened with the matrix-core pass: %d" % (
         it, time.time() - t0, seed, max_n, dict(sorted(stats["n_by_dev"].items())), stats.get("gkr", 0), stats.get("triangle", 0),
-        stats.get("unsupported", 0)), flush=True)
+        stats.get("unsupported", 0), stats.get("gram", 0)), flush=True)
 
 
 main()
