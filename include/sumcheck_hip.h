@@ -103,6 +103,9 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      for tables of >= 2^18 entries, two below (never more than vars_per_pass allows).  4 = the
  *                      matrix-core pass at any size from 2^14 entries (where it does not apply - sharded provers,
  *                      smaller tables, "vars_per_pass" 1 - the same as 0)
+ *   "pipe32"           (default 1) pass_kernel<3,2> on whole tiles of tables of >= 2^"pipe32_log" (default 20) entries runs in its
+ *                      pipelined form (sub-steps of 64 outputs, loads in flight while the wave multiplies, three waves per
+ *                      SIMD); 0 = the staged form everywhere.  Same results; for A/B measurements
  *   "gram_log"         (default 28; 0 = never, else 14..40) an unsharded proof on tables of >= 2^gram_log entries opens
  *                      with gram_pass_kernel: rounds 1..4 from ONE read, as exact integer limb products of the tables'
  *                      bytes on the int8 matrix cores (the kernel does not depend on the modulus), + gram_finish_kernel;

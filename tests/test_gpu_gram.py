@@ -135,3 +135,26 @@ def test_gram_on_a_one_device_handle_and_generic_field_n24():
         assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]), devices
         del a, b, g
         ctx.close()
+
+
+@pytest.mark.parametrize("p", [GOLD, P59, 389], ids=pid)
+@pytest.mark.parametrize("n", [13, 16, 20])
+def test_pipelined_three_variable_fold(p, n):
+    """pass_kernel<3,2> in its pipelined whole-tile form (option pipe32, default on from 2^20-entry tables; pipe32_log = 11 brings it
+    down to the smallest table it takes) against the staged form and the oracle"""
+    pkg = load_package()
+    o = oracle(p)
+    ha, hb = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+    ref = o.prove(ha, hb, challenges(o, n))
+    for pipe in (1, 0):
+        ctx = pkg.Context(pkg.Field(p))
+        for k, v in (("gram_log", 0), ("first_pass_vars", 3), ("grid_log", 7), ("pipe32", pipe), ("pipe32_log", 11)):
+            ctx.set_option(k, v)
+        plan = pkg.schedule.plan_proof(n, gram_log=0, first_pass_vars=3, grid_log=7)
+        assert plan[1] == {"action": "pass", "kf": 3, "ks": 2, "log_in": n, "sharded": False}
+        a = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, ha)
+        b = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, hb)
+        g = pkg.matrix_multiplication.G(a, b)
+        c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+        assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]), (p, n, pipe)
+        ctx.close()

@@ -339,24 +339,28 @@ __device__ __forceinline__ u64 reduce_cells_lds(const F& f, const typename F::Ac
 // Threads per block of pass_kernel<., KF, KS, .>.  The arithmetic-heavy instantiations hold two or three waves per SIMD
 // (their registers allow no more) and get ALL of a CU's waves into ONE block, so that the waves of a SIMD can share
 // their work through LDS (see the tile loop); the light ones keep 256 threads and several blocks per CU.
-__host__ __device__ constexpr int pass_block_threads(int kf, int ks) {
-  return (ks == 3 || (kf >= 3 && ks == 2)) ? 512 : (kf == 2 && ks == 2) ? 768 : kBlock;
+// (nt bit 2: the pipelined whole-tile form of the three-variable fold, see the tile loop)
+constexpr int kPipe32Threads = 768;
+__host__ __device__ constexpr int pass_block_threads(int kf, int ks, int nt = 0) {
+  return (kf == 3 && ks == 2 && (nt & 4)) ? kPipe32Threads : (ks == 3 || (kf >= 3 && ks == 2)) ? 512 : (kf == 2 && ks == 2) ? 768 : kBlock;
 }
 
 // NT: bit 0 = nontemporal loads, bit 1 = nontemporal stores (see ld16 / st16)
 template <class F, int KF, int KS, int NT>
-__global__ void __launch_bounds__(pass_block_threads(KF, KS))
+__global__ void __launch_bounds__(pass_block_threads(KF, KS, NT))
 pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
             u64* __restrict__ B2, FoldW fw, size_t n_units, PassOut out) {
   constexpr bool kNtLoad = (NT & 1) != 0, kNtStore = (NT & 2) != 0;
   constexpr int IN = 1 << (KF + KS), OUT = 1 << KS, NS = (KS == 1) ? 3 : (KS == 2) ? 9 : 27;
   constexpr int NP = IN / 2, NPO = OUT / 2;  // 16-byte pieces per lane, in and out
-  constexpr int BS = pass_block_threads(KF, KS), kWaves = BS / kWave;
+  constexpr int BS = pass_block_threads(KF, KS, NT), kWaves = BS / kWave;
+  constexpr bool kPipe = (KF == 4) || (KF == 3 && KS == 2 && (NT & 4) != 0);   // sub-step pipeline (whole tiles only)
   static_assert(BS == kBlock || NS >= 9, "reduce_cells (the KS = 1 passes) is written for 256 threads");
   // the tile transposes; after the loop the same bytes hold a chunk of every thread's accumulators (reduce_cells_lds)
   // KF = 4: a unit is 64 entries = 32 pieces per table - too many to stage at once; its four outputs (16 entries = 8 pieces
   // each) are produced one after the other, 8 pieces per lane and table in flight (NPS)
-  constexpr int NPS = 8, NPL = (KF == 4) ? NPS + NPS / 2 : NP;   // pieces per lane the wave's LDS region is laid out for (KF = 4: a sub-step + the exchange area)
+  constexpr int NPS = (1 << KF) / 2 > 0 ? (1 << KF) / 2 : 1;   // pieces of one output
+  constexpr int NPL = kPipe ? NPS + 4 : NP;   // pieces per lane the wave's LDS region is laid out for (pipelined: a sub-step + the 4-KiB exchange area)
   constexpr int kTransposeSlots = (NP > 1 || NPO > 1) ? kWaves * kWave * NPL : 1;
   constexpr int kChunkCells = reduce_chunk_cells<typename F::Acc, BS>();
   constexpr int kReduceSlots = (NS >= 9) ? (int)(((NS < kChunkCells ? NS : kChunkCells) * BS * sizeof(typename F::Acc) + sizeof(ull2) - 1) / sizeof(ull2)) : 1;
@@ -484,8 +488,8 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
   };
-  if constexpr (KF == 4) {
-    static_assert(KF != 4 || KS == 2, "the four-variable fold is instantiated with KS = 2 only");
+  if constexpr (kPipe) {
+    static_assert(KS == 2, "the pipelined folds are instantiated with KS = 2 only");
     // A tile (64 units = 256 outputs per table) is folded in four sub-steps of 64 outputs: the wave loads 8 KiB of each
     // table CONTIGUOUSLY (1 KiB per instruction, as everywhere), stores them to its LDS region, every lane reads its own
     // eight pieces = sixteen entries back and folds them with ONE lazy sum of sixteen products - output 64 s + lane of the
