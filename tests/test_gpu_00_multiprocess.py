@@ -113,8 +113,8 @@ def test_bench_eight_ranks_n28_on_one_device():
     assert c["num_vars"] == 28 and c["transport"] == "peer" and "verifier identities at n=28 ok" in c["parity_gate"]
     assert c["transports"]["peer"]["comm_nranks"] == 8
     sched = c["schedule"]
-    assert sched[0] == ["pass", 0, 3, 25] and sched[-1][0] == "grid_pass"       # 2^25-entry shards, five-round passes to the end
-    assert sum(s[2] for s in sched) == 28
+    assert sched[0] == ["gram_pass", 0, 4, 25] and sched[-1][0] == "grid_pass"  # 2^25-entry shards: the matrix-core first pass, five-round passes to the end
+    assert sum(s[2] for s in sched if s[0] != "gram_finish") == 28      # (gram_finish: the second launch of the first pass)
 
 
 @pytest.mark.gpu

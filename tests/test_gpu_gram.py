@@ -89,18 +89,18 @@ def test_gram_byte_patterns(p, kind):
     ctx.close()
 
 
-def test_gram_is_the_default_from_2_28_and_agrees_with_the_three_round_schedule():
-    """n = 28 (the headline size; below it the 27-cell first pass is as fast or faster, profiles/r04_gram_vs_27cell.txt): the default
-    schedule opens with the gram pass; its transcript equals the one of the 27-cell first pass (gram_log = 0) bit for bit, and the
-    verifier's identities hold"""
+def test_gram_is_the_default_from_2_24_and_agrees_with_the_three_round_schedule():
+    """n = 28: the default schedule (tables and shards of >= 2^24 entries, profiles/r04_gram_vs_27cell.txt) opens with the gram pass;
+    its transcript equals the one of the 27-cell first pass (gram_log = 0) bit for bit, and the verifier's identities hold"""
     pkg = load_package()
     F = pkg.Field(GOLD)
     n = 28
-    assert pkg.schedule.plan_proof(n)[0]["action"] == "gram_pass"
+    assert pkg.schedule.plan_proof(n)[0]["action"] == "gram_pass" and pkg.schedule.plan_proof(24)[0]["action"] == "gram_pass"
     assert pkg.schedule.plan_proof(n, gram_log=0)[0] == {"action": "pass", "kf": 0, "ks": 3, "log_in": n, "sharded": False}
-    assert pkg.schedule.plan_proof(27)[0]["action"] == "pass"
+    assert pkg.schedule.plan_proof(23)[0]["action"] == "pass"
+    assert [s["action"] for s in pkg.schedule.plan_proof(28, 8, "peer")][:2] == ["gram_pass", "pass"]      # 2^25-entry shards
     out = []
-    for gram_log in (28, 0):
+    for gram_log in (24, 0):
         ctx = pkg.Context(F)
         ctx.set_option("gram_log", gram_log)
         a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
@@ -158,3 +158,34 @@ def test_pipelined_three_variable_fold(p, n):
         c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
         assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]), (p, n, pipe)
         ctx.close()
+
+
+@pytest.mark.parametrize("world,transport", [(2, "host"), (4, "host"), (8, "host"), (2, "peer")])
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+def test_gram_pass_on_shards(p, world, transport):
+    """a sharded prover's shards take the matrix-core first pass too (its cells travel as a grid pass's cells do: summed by the
+    host callbacks, or exchanged inside gram_finish_kernel on the peer transport): every rank's transcript equals the oracle's"""
+    from test_gpu_sharded import run_virtual_ranks
+    pkg = load_package()
+    n = 14 + world.bit_length() - 1 + 3            # shards of 2^17 entries
+    o = oracle(p)
+    oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+    ref = o.prove(oa, ob, challenges(o, n))
+    plan = pkg.schedule.plan_proof(n, world, transport, first_pass_vars=4)
+    assert plan[0]["action"] == "gram_pass" and plan[0]["sharded"] and plan[0]["log_in"] == 17
+    results, _ = run_virtual_ranks(pkg, p, n, world, tail_log=5, vpp=4, transport=transport)
+    for rank, (c1, evals, ch, final, e0, s0) in enumerate(results):
+        assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]) and final == ref["final_eval"], (rank, world, transport)
+
+
+@pytest.mark.parametrize("n_dev", [2, 8])
+def test_gram_pass_on_a_multi_device_handle(n_dev):
+    pkg = load_package()
+    n = 19
+    o = oracle(P59)
+    ha, hb = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+    ctx = pkg.Context(pkg.Field(P59), devices=[0] * n_dev)
+    ctx.set_option("first_pass_vars", 4)
+    assert pkg.schedule.plan_proof(n, n_dev, "local", first_pass_vars=4)[0]["action"] == "gram_pass"
+    prove_vs_oracle(pkg, ctx, P59, n, ha, hb, ("handle", n_dev))
+    ctx.close()

@@ -125,8 +125,11 @@ def test_multi_n28_equals_one_device():
         assert c8 == c1 and np.array_equal(ev8, evals) and np.array_equal(ch8, ch), n_dev
         assert G.evaluate([int(x) for x in ch]) == final
         if n_dev == 8:
+            # (shard 0's launches: the matrix-core first pass and its finish, the four-variable fold, four five-round passes;
+            # the host serves the three device-bit rounds from the 16 entries per table and device it was handed)
             assert [(r["kind"], r["kf"], r["ks"], r["log_in"]) for r in log] == [
-                ("pass", 0, 3, 25), ("pass", 3, 2, 25), ("grid_pass", 2, 5, 22), ("grid_pass", 5, 5, 20), ("grid_pass", 5, 5, 15), ("grid_pass", 5, 5, 10)]
+                ("gram_pass", 0, 4, 25), ("gram_finish", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 5, 21), ("grid_pass", 5, 5, 19),
+                ("grid_pass", 5, 5, 14), ("grid_pass", 5, 4, 9)]
         del G, a, b
         ctx.close()
 

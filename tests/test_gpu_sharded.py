@@ -59,8 +59,8 @@ def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove", transport="
             ctx = pkg.Context(pkg.Field(p))
             ctx.set_option("tail_log", tail_log)
             ctx.set_option("vars_per_pass", min(vpp, 2))
-            ctx.set_option("first_pass_vars", 3 if vpp == 3 else min(vpp, 2))
-            ctx.set_option("grid_pass", 1 if vpp == 3 else 0)
+            ctx.set_option("first_pass_vars", vpp if vpp >= 3 else min(vpp, 2))    # (4: the matrix-core first pass on the shards)
+            ctx.set_option("grid_pass", 1 if vpp >= 3 else 0)
             if transport == "peer":
                 # in-kernel exchange through peer-mapped inboxes; threads of one process share the address space
                 ctx.set_option("peer_spin_ms", 20000)

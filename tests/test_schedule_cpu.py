@@ -37,7 +37,7 @@ def check(steps, n, world, transport, opts):
         assert s["kf"] == kf, (s, kf)
         if transport == "local" and world > 1:
             # the devices of one multi-device handle: never a gather or a rank pass; the host finishes the device bits
-            assert s["action"] in ("pass", "grid_pass", "host_tail")
+            assert s["action"] in ("pass", "grid_pass", "host_tail", "gram_pass")
         if s["action"] == "host_tail":
             assert transport == "local" and sharded and cur_log == kf and s["ks"] == g and kf <= 5 and s is steps[-1]
             cur_log, sharded = 0, False
@@ -45,11 +45,11 @@ def check(steps, n, world, transport, opts):
             assert transport == "peer" and sharded and cur_log == kf and s["ks"] == g and 1 <= g <= 3 and kf <= 5
             cur_log, sharded = g, False
         elif s["action"] == "gram_pass":
-            # the four-round first pass on the matrix cores: unsharded proofs only, first launch only, the default two-round schedule
-            # only, tables of >= 2^gram_log entries (first_pass_vars = 4: any size from 2^14)
-            assert s is steps[0] and kf == 0 and not sharded and s["ks"] == 4 and n >= 6 and cur_log >= 14
+            # the four-round first pass on the matrix cores: first launch only, the default two-round schedule only, tables or shards
+            # of >= 2^gram_log entries (first_pass_vars = 4: any size from 2^14), sharded provers where they take grid passes
+            assert s is steps[0] and kf == 0 and s["ks"] == 4 and cur_log >= 14 and (not sharded or opts.get("grid_sharded", 1) == 1)
             assert opts.get("vars_per_pass", 2) == 2 and opts.get("use_mailbox", 1) == 1 and opts.get("first_pass_vars", 0) in (0, 4)
-            assert opts.get("first_pass_vars", 0) == 4 or (opts.get("gram_log", 28) > 0 and cur_log >= opts.get("gram_log", 28))
+            assert opts.get("first_pass_vars", 0) == 4 or (opts.get("gram_log", 24) > 0 and cur_log >= opts.get("gram_log", 24))
         elif s["action"] == "pass":
             assert (kf <= 3 or (kf == 4 and s["ks"] == 2 and steps[0]["action"] == "gram_pass")) and 1 <= s["ks"] <= 3
             assert (s["ks"] < 3 or kf == 0) and cur_log >= kf + s["ks"]
@@ -85,20 +85,22 @@ def test_known_schedules(plan):
                              ("grid_pass", 5, 5, 15), ("grid_pass", 5, 5, 10)]
     assert sig(plan(28, gram_log=0)) == [("pass", 0, 3, 28), ("pass", 3, 2, 28), ("pass", 2, 2, 25), ("pass", 2, 2, 23), ("grid_pass", 2, 5, 21),
                                          ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14), ("grid_pass", 5, 4, 9)]
-    assert sig(plan(27))[0] == ("pass", 0, 3, 27) and sig(plan(29))[0] == ("gram_pass", 0, 4, 29)
+    assert sig(plan(23))[0] == ("pass", 0, 3, 23) and sig(plan(24))[0] == ("gram_pass", 0, 4, 24)
     assert sig(plan(20, first_pass_vars=4))[:2] == [("gram_pass", 0, 4, 20), ("grid_pass", 4, 4, 20)]
     # BASELINE config 4: n = 28 over 8 ranks, peer transport - seven launches, seven exchanges, no gather
     s8 = plan(28, 8, "peer")
-    assert sig(s8) == [("pass", 0, 3, 25), ("pass", 3, 2, 25), ("grid_pass", 2, 5, 22), ("grid_pass", 5, 5, 20), ("grid_pass", 5, 5, 15),
-                       ("grid_pass", 5, 5, 10), ("rank_pass", 5, 3, 5)]
+    assert sig(s8) == [("gram_pass", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 5, 21), ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14),
+                       ("grid_pass", 5, 4, 9), ("rank_pass", 4, 3, 4)]
     assert all(s["sharded"] for s in s8)
+    assert sig(plan(28, 8, "peer", gram_log=0)) == [("pass", 0, 3, 25), ("pass", 3, 2, 25), ("grid_pass", 2, 5, 22), ("grid_pass", 5, 5, 20),
+                                                    ("grid_pass", 5, 5, 15), ("grid_pass", 5, 5, 10), ("rank_pass", 5, 3, 5)]
     # the same over RCCL: the shard is gathered when it is down to its pending challenges, the rank bits are one more pass
     r8 = plan(28, 8, "rccl")
-    assert sig(r8)[:6] == sig(s8)[:6] and sig(r8)[6:] == [("gather", 0, 0, 5), ("grid_pass", 5, 3, 8)]
-    # ONE process over 8 devices (sc_ctx_create_multi): the same six launches per device, then the host folds the 32 entries
+    assert sig(r8)[:6] == sig(s8)[:6] and sig(r8)[6:] == [("gather", 0, 0, 4), ("grid_pass", 4, 3, 7)]
+    # ONE process over 8 devices (sc_ctx_create_multi): the same six launches per device, then the host folds the 16 entries
     # per table and device it was handed and serves the three device-bit rounds - no seventh launch, no gather
     l8 = plan(28, 8, "local")
-    assert sig(l8)[:6] == sig(s8)[:6] and sig(l8)[6:] == [("host_tail", 5, 3, 5)]
+    assert sig(l8)[:6] == sig(s8)[:6] and sig(l8)[6:] == [("host_tail", 4, 3, 4)]
     assert sig(plan(3, 8, "local")) == [("host_tail", 0, 3, 0)]      # one entry per device: the host serves every round
     assert sig(plan(28, 1, "local")) == sig(plan(28))                  # one device behind the handle: the plain schedule
     # two rounds per pass with a gather at 2^16-entry shards (grid_sharded 0): round 1's sharded schedule

@@ -97,7 +97,9 @@ typedef int gram_v16i __attribute__((ext_vector_type(16)));
 
 // A, B: the tables as bytes.  Step t (8 KiB of each table) belongs to partial t % n_partials; steps_per_partial is a
 // multiple of kGramStages and at most GramGeo::kMaxSteps.  partials: [n_partials][kWords] words.
-template <int K1>
+// NT: the DMA loads carry the nontemporal hint (tables far larger than the 256 MiB Infinity Cache are read once: with
+// allocating loads the same loop runs at 6.1 TB/s instead of 7.0, tools/gram/gram4_bench.hip -DGRAM_AUX=2)
+template <int K1, bool NT>
 __global__ void __launch_bounds__(kGramThreads)
 gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, unsigned n_partials, unsigned steps_per_partial,
                  int* __restrict__ partials, unsigned long long* __restrict__ totals) {
@@ -128,7 +130,7 @@ gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __res
 #pragma unroll
     for (int u = 0; u < 2; ++u)
       __builtin_amdgcn_global_load_lds((glob_ptr_t)(tab_of[u] + step * (size_t)kGramTabBytes + src_off[u]),
-                                       (lds_ptr_t)(gram_lds + stage_off + dst_off[u]), 16, 0, 0);
+                                       (lds_ptr_t)(gram_lds + stage_off + dst_off[u]), 16, 0, NT ? 2 : 0);
   };
   // transposed reads: lane 2q + p of a 16-lane group supplies row q, bytes 8p .. 8p + 7 of the group's 16 columns and
   // receives the eight rows of column (lane & 15) - operand register pair t covers rows 16 h + 8 t + (0..7) of the k-step
@@ -270,8 +272,9 @@ gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __res
 #undef SC_GRAM_WAIT12
 #undef SC_TR8
 
-// The partials -> the 3^K1 cells of rounds 1..K1 in the host mailbox (the wide part, whole residues, then the sequence
-// word: exactly what an unsharded wgrid_pass_kernel<F, K1> with nothing to fold leaves - the host cannot tell them apart).
+// The partials -> the 3^K1 cells of rounds 1..K1, handed on exactly as wgrid_pass_kernel<F, K1> hands its cells on
+// (publish_cells: the wide mailbox, the in-kernel exchange with the peers, or split limbs for a collective) - the host
+// cannot tell the two apart.
 //  1. every block adds a slice of the partials (grid = kWords / 256 word groups x `splits` partial groups) into `totals`
 //     (64-bit, agent-scope atomics; zeroed, with the ticket behind them, by gram_pass_kernel);
 //  2. the block that draws the last ticket turns G, the byte sums and the row count into M[x][y] = sum a (*) b mod p
@@ -280,7 +283,7 @@ gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __res
 template <class F, int K1>
 __global__ void __launch_bounds__(kBlock)
 gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, unsigned long long rows, unsigned long long* __restrict__ totals,
-                   unsigned* __restrict__ ticket, u64* __restrict__ mailbox, u64 seq) {
+                   unsigned* __restrict__ ticket, WgOut out) {
   typedef GramGeo<K1> G;
   constexpr int WB = G::kWords / kBlock, X = 1 << K1;
   static_assert(G::kWords % kBlock == 0, "whole word groups");
@@ -396,11 +399,7 @@ gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, u
     __syncthreads();
     u64* t = src; src = dst; dst = t;
   }
-  if (tid < cells) __hip_atomic_store(mailbox + kMailboxWide + tid, src[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  // the sequence word behind every wave's cell stores
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(mailbox + kMailboxSeq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  publish_cells<cells>(out, tid < cells ? src[tid] : 0);   // (unsharded: the wide mailbox; sharded: as a grid pass's cells)
 }
 
 }  // namespace sc

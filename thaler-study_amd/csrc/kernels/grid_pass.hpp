@@ -343,6 +343,29 @@ __device__ __forceinline__ void exchange_wide(const WgOut& o, u64 total) {
   }
 }
 
+// Where the cells of a pass leave the device (every thread of the block calls it; `total` = cell tid of this rank for
+// tid < CELLS): through the in-kernel exchange with the peers (sharded passes on the peer transport), as split limbs in
+// device memory for the collective that follows on the stream (RCCL), or as whole residues in the wide mailbox + the
+// sequence word (unsharded passes; sharded ones on a host transport or a multi-device handle - the host sums).
+template <int CELLS>
+__device__ __forceinline__ void publish_cells(const WgOut& out, u64 total) {
+  const int tid = threadIdx.x;
+  if (out.px.world > 0) {
+    exchange_wide<CELLS>(out, total);
+    return;
+  }
+  if (out.limbs_dev) {   // the stream's next operation (an all-reduce) reads them: kernel-boundary ordering
+    if (tid < CELLS) write_split(out.limbs_dev, tid, total);
+    return;
+  }
+  if (tid < CELLS) __hip_atomic_store(out.mailbox + kMailboxWide + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  // a workgroup barrier does not drain vmcnt: every storing wave waits for its own cell stores before the barrier, so
+  // that thread 0's release store of the sequence word cannot overtake a late cell of waves 1..3 (as exchange_wide does)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) __hip_atomic_store(out.mailbox + kMailboxSeq, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 template <class F, int KS, bool PF>
 __global__ void __launch_bounds__(kBlock)
 wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
@@ -413,20 +436,7 @@ wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
     // everything of this launch has been counted: leave the counters at zero for the next one
     if (tid <= n_groups) __hip_atomic_store(out.tickets + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (out.px.world > 0) {
-    exchange_wide<cells>(out, total);
-    return;
-  }
-  if (out.limbs_dev) {   // the stream's next operation (an all-reduce) reads them: kernel-boundary ordering
-    if (tid < cells) write_split(out.limbs_dev, tid, total);
-    return;
-  }
-  if (tid < cells) __hip_atomic_store(out.mailbox + kMailboxWide + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  // a workgroup barrier does not drain vmcnt: every storing wave waits for its own cell stores before the barrier, so
-  // that thread 0's release store of the sequence word cannot overtake a late cell of waves 1..3 (as exchange_wide does)
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (tid == 0) __hip_atomic_store(out.mailbox + kMailboxSeq, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  publish_cells<cells>(out, total);
 }
 
 // The last pass of a sharded prover on the peer transport: the shard is down to its 2^kf pending entries (kf <= 5),

@@ -14,6 +14,9 @@ typedef int v16i __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glob_ptr_t;
 
+#ifndef GRAM_AUX
+#define GRAM_AUX 0   // cache-policy bits of the LDS-DMA load (2: nontemporal)
+#endif
 #ifndef GRAM_NS
 #define GRAM_NS 4
 #endif
@@ -68,7 +71,7 @@ __global__ void __launch_bounds__(kThreads) gram_kernel(const unsigned char* __r
   auto issue = [&](size_t step, unsigned stage_off) {
 #pragma unroll
     for (int u = 0; u < 2; ++u)
-      __builtin_amdgcn_global_load_lds((glob_ptr_t)(tab_of[u] + step * (size_t)kTabBytes + src_off[u]), (lds_ptr_t)(lds + stage_off + dst_off[u]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glob_ptr_t)(tab_of[u] + step * (size_t)kTabBytes + src_off[u]), (lds_ptr_t)(lds + stage_off + dst_off[u]), 16, 0, GRAM_AUX);
   };
   // transposed reads: 32 columns from m0, rows 32 ks + 16 h + 8 t + q.  One address register per read; the stage is an immediate.
   auto tr_addr = [&](int tab, int m0, int ks, int t) -> unsigned {

@@ -5,7 +5,7 @@ from __graft_entry__ import load_package
 from util import pyref
 pkg = load_package()
 GOLD = pkg.GOLDILOCKS
-for n in (28, 27, 26):
+for n in [int(x) for x in sys.argv[1:]] or (28, 27, 26, 25):
     for gram_log in (14, 0):
         ctx = pkg.Context(pkg.Field(GOLD))
         ctx.set_option("gram_log", gram_log)
