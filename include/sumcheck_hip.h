@@ -99,14 +99,14 @@ const char* sc_last_error(const sc_ctx* ctx);
 /* Tunables (all have working defaults; they exist for measurements and tests):
  *   "vars_per_pass"    rounds served by one device pass: 1 | 2 (default 2)
  *   "first_pass_vars"  rounds served by the prover's first pass, which has nothing to fold:
- *                      1 | 2 | 3 | 4, default 0 = four for unsharded tables of >= 2^"gram_log" entries (below), else three
+ *                      1 | 2 | 3 | 4, default 0 = four for tables (shards) of >= 2^"gram_log" entries (below), else three
  *                      for tables of >= 2^18 entries, two below (never more than vars_per_pass allows).  4 = the
- *                      matrix-core pass at any size from 2^14 entries (where it does not apply - sharded provers,
- *                      smaller tables, "vars_per_pass" 1 - the same as 0)
+ *                      matrix-core pass at any size from 2^14 entries (where it does not apply - smaller tables,
+ *                      "vars_per_pass" 1, sharded provers with "grid_sharded" 0 - the same as 0)
  *   "pipe32"           (default 1) pass_kernel<3,2> on whole tiles of tables of >= 2^"pipe32_log" (default 20) entries runs in its
  *                      pipelined form (sub-steps of 64 outputs, loads in flight while the wave multiplies, three waves per
  *                      SIMD); 0 = the staged form everywhere.  Same results; for A/B measurements
- *   "gram_log"         (default 28; 0 = never, else 14..40) an unsharded proof on tables of >= 2^gram_log entries opens
+ *   "gram_log"         (default 21; 0 = never, else 14..40) a proof on tables (a sharded one: shards) of >= 2^gram_log entries opens
  *                      with gram_pass_kernel: rounds 1..4 from ONE read, as exact integer limb products of the tables'
  *                      bytes on the int8 matrix cores (the kernel does not depend on the modulus), + gram_finish_kernel;
  *                      the pass behind it folds four variables (pass_kernel<4,2>).  DESIGN.md section 4

@@ -89,18 +89,18 @@ def test_gram_byte_patterns(p, kind):
     ctx.close()
 
 
-def test_gram_is_the_default_from_2_24_and_agrees_with_the_three_round_schedule():
-    """n = 28: the default schedule (tables and shards of >= 2^24 entries, profiles/r04_gram_vs_27cell.txt) opens with the gram pass;
+def test_gram_is_the_default_from_2_21_and_agrees_with_the_three_round_schedule():
+    """n = 28: the default schedule (tables and shards of >= 2^21 entries, profiles/r04_gram_vs_27cell.txt) opens with the gram pass;
     its transcript equals the one of the 27-cell first pass (gram_log = 0) bit for bit, and the verifier's identities hold"""
     pkg = load_package()
     F = pkg.Field(GOLD)
     n = 28
-    assert pkg.schedule.plan_proof(n)[0]["action"] == "gram_pass" and pkg.schedule.plan_proof(24)[0]["action"] == "gram_pass"
+    assert pkg.schedule.plan_proof(n)[0]["action"] == "gram_pass" and pkg.schedule.plan_proof(21)[0]["action"] == "gram_pass"
     assert pkg.schedule.plan_proof(n, gram_log=0)[0] == {"action": "pass", "kf": 0, "ks": 3, "log_in": n, "sharded": False}
-    assert pkg.schedule.plan_proof(23)[0]["action"] == "pass"
+    assert pkg.schedule.plan_proof(20)[0]["action"] == "grid_pass"
     assert [s["action"] for s in pkg.schedule.plan_proof(28, 8, "peer")][:2] == ["gram_pass", "pass"]      # 2^25-entry shards
     out = []
-    for gram_log in (24, 0):
+    for gram_log in (21, 0):
         ctx = pkg.Context(F)
         ctx.set_option("gram_log", gram_log)
         a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)

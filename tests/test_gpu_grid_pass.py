@@ -44,7 +44,7 @@ def test_default_schedule_uses_grid_passes(pkg, p):
         if n <= 20:
             assert set(kinds) == {"grid_pass"}, (n, kinds)
             assert len(log) == (n + 4) // 5, (n, log)                        # five rounds per launch
-        assert sum(r["ks"] for r in log) == n, (n, log)                      # every round served exactly once
+        assert sum(r["ks"] for r in log if r["kind"] != "gram_finish") == n, (n, log)   # every round served exactly once (gram_finish: the first pass's second launch)
         assert all(r["kf"] <= 5 and 1 <= r["ks"] <= 5 for r in log)
     ctx.close()
 

@@ -49,7 +49,7 @@ def check(steps, n, world, transport, opts):
             # of >= 2^gram_log entries (first_pass_vars = 4: any size from 2^14), sharded provers where they take grid passes
             assert s is steps[0] and kf == 0 and s["ks"] == 4 and cur_log >= 14 and (not sharded or opts.get("grid_sharded", 1) == 1)
             assert opts.get("vars_per_pass", 2) == 2 and opts.get("use_mailbox", 1) == 1 and opts.get("first_pass_vars", 0) in (0, 4)
-            assert opts.get("first_pass_vars", 0) == 4 or (opts.get("gram_log", 24) > 0 and cur_log >= opts.get("gram_log", 24))
+            assert opts.get("first_pass_vars", 0) == 4 or (opts.get("gram_log", 21) > 0 and cur_log >= opts.get("gram_log", 21))
         elif s["action"] == "pass":
             assert (kf <= 3 or (kf == 4 and s["ks"] == 2 and steps[0]["action"] == "gram_pass")) and 1 <= s["ks"] <= 3
             assert (s["ks"] < 3 or kf == 0) and cur_log >= kf + s["ks"]
@@ -85,7 +85,7 @@ def test_known_schedules(plan):
                              ("grid_pass", 5, 5, 15), ("grid_pass", 5, 5, 10)]
     assert sig(plan(28, gram_log=0)) == [("pass", 0, 3, 28), ("pass", 3, 2, 28), ("pass", 2, 2, 25), ("pass", 2, 2, 23), ("grid_pass", 2, 5, 21),
                                          ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14), ("grid_pass", 5, 4, 9)]
-    assert sig(plan(23))[0] == ("pass", 0, 3, 23) and sig(plan(24))[0] == ("gram_pass", 0, 4, 24)
+    assert sig(plan(20))[0] == ("grid_pass", 0, 5, 20) and sig(plan(21))[0] == ("gram_pass", 0, 4, 21)
     assert sig(plan(20, first_pass_vars=4))[:2] == [("gram_pass", 0, 4, 20), ("grid_pass", 4, 4, 20)]
     # BASELINE config 4: n = 28 over 8 ranks, peer transport - seven launches, seven exchanges, no gather
     s8 = plan(28, 8, "peer")

@@ -62,14 +62,12 @@ __device__ __forceinline__ int gram_swz(int row, int chunk) {
   if constexpr (K1 == 5) return (((chunk >> 1) ^ (row & 7)) << 1) | (chunk & 1);
   else return (((chunk >> 1) ^ ((row >> 1) & 3)) << 1) | (chunk & 1);
 }
-// word of G[m][n] inside a partial (the accumulator order the waves store in); C/D layout of the 32x32 MFMA:
-// col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)   (cdna_hip_programming.md section 3)
+// word of G[m][n] inside a partial: pair-major - the 64 limb products of Gram entry (x, y) = (m / 8, n / 8) are contiguous
+// (256 bytes), so the block of gram_finish_kernel that owns the entry reads them as one line per partial.  (C/D layout of
+// the 32x32 MFMA, for the stores: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); cdna_hip_programming.md section 3)
 template <int K1>
 __host__ __device__ constexpr int gram_word(int m, int n) {
-  typedef GramGeo<K1> G;
-  const int mh = m / (G::RB / 2), mm = m % (G::RB / 2), a = mm / 32, r = mm % 32, hh = (r >> 2) & 1, reg = (r & 3) | ((r >> 3) << 2);
-  const int nq = n / (G::RB / 4), nn = n % (G::RB / 4), bb = nn / 32, lane = 32 * hh + (nn % 32);
-  return (((mh * 4 + nq) * (G::MB * G::NBK) + a * G::NBK + bb) * 16 + reg) * 64 + lane;
+  return (((m >> 3) << K1) + (n >> 3)) * 64 + (m & 7) * 8 + (n & 7);
 }
 
 typedef int gram_v2i __attribute__((ext_vector_type(2)));
@@ -102,7 +100,7 @@ typedef int gram_v16i __attribute__((ext_vector_type(16)));
 template <int K1, bool NT>
 __global__ void __launch_bounds__(kGramThreads)
 gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, unsigned n_partials, unsigned steps_per_partial,
-                 int* __restrict__ partials, unsigned long long* __restrict__ totals) {
+                 int* __restrict__ partials) {
   typedef GramGeo<K1> G;
   constexpr int NS = kGramStages;
   extern __shared__ __attribute__((aligned(16))) unsigned char gram_lds[];
@@ -111,8 +109,6 @@ gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __res
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int mh = wave >> 2, nq = wave & 3;
   const int h = lane >> 5, g2 = (lane >> 4) & 1, ll = lane & 15, q = ll >> 1, p = ll & 1;
-  // gram_finish_kernel's totals and its ticket (the word behind them) start from zero: cleared here, where it costs nothing
-  for (unsigned w = blockIdx.x * kGramThreads + tid; w < (unsigned)G::kWords + 1; w += gridDim.x * kGramThreads) totals[w] = 0;
   // DMA: 16 instructions of 1 KiB per stage, two per wave (i < 8: table a).  Lane L of an instruction lands at
   // row r0 + L / CPR, chunk position L % CPR, and fetches the chunk that belongs there.
   size_t src_off[2];
@@ -243,14 +239,17 @@ gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __res
       compute(r1);
       if (more) SC_GRAM_WAIT12(r0);
     }
-    // the partial, in accumulator order (gram_word), then the byte sums (the two k-halves of a column live in lanes l, l + 32)
+    // the partial, pair-major (gram_word), then the byte sums (the two k-halves of a column live in lanes l, l + 32)
     int* const out = partials + (size_t)part * G::kWords;
 #pragma unroll
     for (int a = 0; a < G::MB; ++a)
 #pragma unroll
       for (int b = 0; b < G::NBK; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) out[((wave * (G::MB * G::NBK) + a * G::NBK + b) * 16 + e) * 64 + lane] = acc[a][b][e];
+        for (int e = 0; e < 16; ++e) {
+          const int m = (G::RB / 2) * mh + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h, n = (G::RB / 4) * nq + 32 * b + (lane & 31);
+          out[gram_word<K1>(m, n)] = acc[a][b][e];
+        }
     if (nq == 0) {
 #pragma unroll
       for (int a = 0; a < G::MB; ++a) {
@@ -274,48 +273,101 @@ gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __res
 
 // The partials -> the 3^K1 cells of rounds 1..K1, handed on exactly as wgrid_pass_kernel<F, K1> hands its cells on
 // (publish_cells: the wide mailbox, the in-kernel exchange with the peers, or split limbs for a collective) - the host
-// cannot tell the two apart.
-//  1. every block adds a slice of the partials (grid = kWords / 256 word groups x `splits` partial groups) into `totals`
-//     (64-bit, agent-scope atomics; zeroed, with the ticket behind them, by gram_pass_kernel);
-//  2. the block that draws the last ticket turns G, the byte sums and the row count into M[x][y] = sum a (*) b mod p
-//     (thread = (x, y): 64 limb products -> 15 anti-diagonal sums -> Horner in 2^8), forms the cells as signed sums of M,
-//     publishes.
+// cannot tell the two apart.  One block per Gram entry (x, y):
+//  1. it adds its 64 limb products and its 16 byte sums over all partials (64-bit; one 256-byte line per partial),
+//     forms T_ij = sum_rows u_i u'_j = G + 128 (Su_i + Su'_j) - 16384 rows, the fifteen anti-diagonal sums, their weighted
+//     sum sum_s D_s 2^(8s) as a 162-bit integer and ONE reduction (wide_get, which also supplies the factor 2^-64 of the
+//     Montgomery products): M[x][y] = sum a (*) b mod p, stored for the last block;
+//  2. the block that draws the last ticket turns M into the cells, one variable at a time (256 -> 192 -> 144 -> 108 -> 81
+//     words at K1 = 4), and hands them on.  The ticket rests at zero.
 template <class F, int K1>
 __global__ void __launch_bounds__(kBlock)
-gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, unsigned long long rows, unsigned long long* __restrict__ totals,
+gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, unsigned long long rows, u64* __restrict__ m_out,
                    unsigned* __restrict__ ticket, WgOut out) {
   typedef GramGeo<K1> G;
-  constexpr int WB = G::kWords / kBlock, X = 1 << K1;
-  static_assert(G::kWords % kBlock == 0, "whole word groups");
+  constexpr int X = 1 << K1;
   constexpr int kPow3[6] = {1, 3, 9, 27, 81, 243};
   constexpr int cells = kPow3[K1];
+  static_assert(kBlock == 256, "four slices of 64 words / sixteen slices of 16 sums");
+  __shared__ long long red[4][64], sred[16][16];
+  __shared__ unsigned long long diag[15];
   __shared__ u64 M[X * X], W[X * X];
   __shared__ int last_flag;
   const int tid = threadIdx.x;
-  const unsigned wg = blockIdx.x % WB, split = blockIdx.x / WB, n_splits = gridDim.x / WB;
-  const int word = (int)wg * kBlock + tid;
+  const int pair = blockIdx.x, x = pair / X, y = pair % X;
   {
-    const bool is_sum = word >= G::RB * G::RB;   // the byte sums are unsigned words
+    // the entry's 64 limb products: thread = (word, slice of the partials)
+    const int w = tid & 63, slice = tid >> 6;
+    const int* src = partials + pair * 64 + w;
     long long s = 0;
-    const int* src = partials + word;
-    unsigned v = split;
-    for (; v + 15 * n_splits < n_partials; v += 16 * n_splits) {   // sixteen loads in flight
-      int x[16];
+    unsigned v = slice;
+    for (; v + 15 * 4 < n_partials; v += 16 * 4) {   // sixteen loads in flight
+      int t[16];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) x[u] = src[(size_t)(v + u * n_splits) * G::kWords];
+      for (int u = 0; u < 16; ++u) t[u] = src[(size_t)(v + u * 4) * G::kWords];
 #pragma unroll
-      for (int u = 0; u < 16; ++u) s += is_sum ? (long long)(unsigned)x[u] : (long long)x[u];
+      for (int u = 0; u < 16; ++u) s += (long long)t[u];
     }
-    for (; v < n_partials; v += n_splits) {
-      const int x = src[(size_t)v * G::kWords];
-      s += is_sum ? (long long)(unsigned)x : (long long)x;
-    }
-    __hip_atomic_fetch_add(totals + word, (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (; v < n_partials; v += 4) s += (long long)src[(size_t)v * G::kWords];
+    red[slice][w] = s;
   }
-  // hand-off as in finish_pass (Guideline 16): every wave drains its atomics, barrier, one ticket per block
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  {
+    // its byte sums (unsigned words): thread = (sum, slice)
+    const int k = tid & 15, slice = tid >> 4;
+    const int* src = partials + G::RB * G::RB + (k < 8 ? 8 * x + k : G::RB + 8 * y + (k - 8));
+    long long s = 0;
+    unsigned v = slice;
+    for (; v + 7 * 16 < n_partials; v += 8 * 16) {
+      int t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(v + u * 16) * G::kWords];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += (long long)(unsigned)t[u];
+    }
+    for (; v < n_partials; v += 16) s += (long long)(unsigned)src[(size_t)v * G::kWords];
+    sred[slice][k] = s;
+  }
+  __syncthreads();
+  if (tid < 64) red[0][tid] += red[1][tid] + red[2][tid] + red[3][tid];
+  else if (tid < 80) {
+    const int k = tid - 64;
+    long long t = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sred[q][k];
+    sred[0][k] = (k < 8) ? 128 * t - 16384 * (long long)rows : 128 * t;
+  }
+  __syncthreads();
+  if (tid < 15) {
+    // T_ij >= 0, < 2^16 rows; a diagonal < 8 * 2^16 * rows < 2^49
+    unsigned long long d = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int j = tid - i;
+      if (j >= 0 && j < 8) d += (unsigned long long)(red[0][8 * i + j] + sred[0][i] + sred[0][8 + j]);
+    }
+    diag[tid] = d;
+  }
   __syncthreads();
   if (tid == 0) {
+    u64 w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int s = 0; s < 15; ++s) {
+      const int wd = (8 * s) / 64, bt = (8 * s) % 64;
+      const u64 lo = diag[s] << bt, hi = bt ? diag[s] >> (64 - bt) : 0;
+      u64 t;
+      const bool c = __builtin_add_overflow(w[wd], lo, &t);
+      w[wd] = t;
+      const bool c2 = __builtin_add_overflow(w[wd + 1], hi, &t);
+      const bool c3 = __builtin_add_overflow(t, (u64)(c ? 1 : 0), &t);
+      w[wd + 1] = t;
+      if (wd + 2 < 4) w[wd + 2] += (c2 ? 1 : 0) + (c3 ? 1 : 0);
+    }
+    // (word 3 stays zero: the sum is below 2^162; what passes 2^160 goes through 2^160 * 2^-64 mod p)
+    u64 v = f.wide_get(w[0], w[1], (u32)w[2]);
+    if (w[2] >> 32) v = f.add(v, f.mul(w[2] >> 32, f.mul(f.r_squared(), f.mul(f.r_squared(), 1ull << 32))));
+    // hand-off as in finish_pass (Guideline 16, R1): write-through store, drain, ticket; the last block acquires
+    __hip_atomic_store(m_out + pair, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (t == gridDim.x - 1) ? 1 : 0;
     if (last) {
@@ -326,57 +378,8 @@ gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, u
   }
   __syncthreads();
   if (!last_flag) return;
-  auto total_of = [&](int w) -> long long {
-    return (long long)__hip_atomic_load(totals + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-  // 2^160 * 2^-64 mod p for the bits of the integer beyond 2^160 (only the largest tables reach them)
-  const u64 c96 = f.mul(f.r_squared(), f.mul(f.r_squared(), 1ull << 32));
-  for (int pair = tid; pair < X * X; pair += kBlock) {
-    const int x = pair / X, y = pair % X;
-    // T_ij = sum_rows u_i u'_j = G + 128 (Su_i + Su'_j) - 16384 rows  (>= 0, < 2^16 rows); all 80 loads in flight
-    long long su_a[8], su_b[8], gg[64];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      su_a[i] = total_of(G::RB * G::RB + 8 * x + i);
-      su_b[i] = total_of(G::RB * G::RB + G::RB + 8 * y + i);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) gg[8 * i + j] = total_of(gram_word<K1>(8 * x + i, 8 * y + j));
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      su_a[i] = 128 * su_a[i] - 16384 * (long long)rows;
-      su_b[i] = 128 * su_b[i];
-    }
-    unsigned long long diag[15];
-#pragma unroll
-    for (int s = 0; s < 15; ++s) diag[s] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) diag[i + j] += (unsigned long long)(gg[8 * i + j] + su_a[i] + su_b[j]);   // < 8 * 2^16 * rows < 2^49
-    // the integer sum_s diag[s] 2^(8s) in three words (+ what passes 2^160), then ONE reduction: wide_get is
-    // (w2 2^128 + w1 2^64 + w0) 2^-64 mod p - the factor 2^-64 is the Montgomery products'
-    u64 w[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < 15; ++s) {
-      constexpr int kBits = 8;
-      const int wd = (kBits * s) / 64, bt = (kBits * s) % 64;
-      const u64 lo = diag[s] << bt, hi = bt ? diag[s] >> (64 - bt) : 0;
-      u64 t;
-      bool c = __builtin_add_overflow(w[wd], lo, &t);
-      w[wd] = t;
-      bool c2 = __builtin_add_overflow(w[wd + 1], hi, &t);
-      bool c3 = __builtin_add_overflow(t, (u64)(c ? 1 : 0), &t);
-      w[wd + 1] = t;
-      if (wd + 2 < 4) w[wd + 2] += (c2 ? 1 : 0) + (c3 ? 1 : 0);
-    }
-    // (word 3 stays zero: the sum is below 2^49 * 2^112 * 2; bits 160.. of word 2 go through c96)
-    u64 v = f.wide_get(w[0], w[1], (u32)w[2]);
-    if (w[2] >> 32) v = f.add(v, f.mul(w[2] >> 32, c96));
-    M[pair] = v;
-  }
+  for (int i = tid; i < X * X; i += kBlock) M[i] = __hip_atomic_load(m_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every block has drawn: back to rest
   __syncthreads();
   // M -> cells, one variable at a time: the pair (bit j of x, bit j of y) becomes the digit d_j in {0, 1, inf}:
   // d = 0 / 1 pins both bits; inf is (a1 - a0)(b1 - b0) = M11 - M10 - M01 + M00 in that variable.  Index of the working

@@ -127,9 +127,9 @@ struct sc_ctx {
   u64* d_wg_partials = nullptr;   // [kWgMaxBlocks][kGridChunk]
   u64* d_wg_groups = nullptr;     // [kWgMaxBlocks / 32][kGridChunk]
   unsigned* d_wg_tickets = nullptr;
-  u64* d_gram_totals = nullptr;   // gram_finish_kernel: kWords 64-bit totals + its ticket, all zero at rest (allocated on first use)
+  u64* d_gram_totals = nullptr;   // gram_finish_kernel: the 256 Gram entries mod p + its ticket (zero at rest); allocated on first use
   int pipe32 = 1, pipe32_log = 20, pipe32_blocks = 0;   // pass_kernel<3,2>: the pipelined whole-tile form on tables of >= 2^pipe32_log entries
-  int gram_log = 24;              // first pass of an unsharded proof on tables of >= 2^gram_log entries: kernels/gram.hpp (0: never)
+  int gram_log = 21;              // first pass of an unsharded proof on tables of >= 2^gram_log entries: kernels/gram.hpp (0: never)
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
                       // cheaper than the ~25 us of collective latency of each further sharded pass
   // grid cap of the streaming kernels: three 256-thread blocks per CU (set in sc_ctx_create).
