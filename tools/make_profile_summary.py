@@ -51,7 +51,7 @@ def is_hot(name):
 
 def describe(name):
     """(kind, kf, ks) of a hot kernel from its demangled name"""
-    m = re.search(r"gram_pass_kernel<(\d)>", name)
+    m = re.search(r"gram_pass_kernel<(\d)(?:, \w+)?>", name)
     if m:
         return "gram_pass", 0, int(m.group(1))
     m = re.search(r"gram_finish_kernel<sc::\w+, (\d)>", name)
