@@ -103,6 +103,8 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      for tables of >= 2^18 entries, two below (never more than vars_per_pass allows).  4 = the
  *                      matrix-core pass at any size from 2^14 entries (where it does not apply - smaller tables,
  *                      "vars_per_pass" 1, sharded provers with "grid_sharded" 0 - the same as 0)
+ *   "fold_dma"         (default 1) pass_kernel<4,2>, the fold behind the matrix-core first pass, brings its sub-steps in by LDS-DMA
+ *                      (Goldilocks; 0 and every other modulus: through registers).  Same results; for A/B measurements
  *   "pipe32"           (default 1) pass_kernel<3,2> on whole tiles of tables of >= 2^"pipe32_log" (default 20) entries runs in its
  *                      pipelined form (sub-steps of 64 outputs, loads in flight while the wave multiplies, three waves per
  *                      SIMD); 0 = the staged form everywhere.  Same results; for A/B measurements

@@ -189,3 +189,22 @@ def test_gram_pass_on_a_multi_device_handle(n_dev):
     assert pkg.schedule.plan_proof(n, n_dev, "local", first_pass_vars=4)[0]["action"] == "gram_pass"
     prove_vs_oracle(pkg, ctx, P59, n, ha, hb, ("handle", n_dev))
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [14, 17, 20])
+def test_four_variable_fold_in_both_forms(n):
+    """pass_kernel<4,2>: the LDS-DMA form (option fold_dma, default on for Goldilocks) and the register-staged pipelined form
+    against the oracle"""
+    pkg = load_package()
+    o = oracle(GOLD)
+    ha, hb = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+    ref = o.prove(ha, hb, challenges(o, n))
+    for dma in (1, 0):
+        ctx = pkg.Context(pkg.Field(GOLD))
+        for k, v in (("first_pass_vars", 4), ("grid_log", 8), ("fold_dma", dma), ("max_blocks", 256 if dma else 5)):
+            ctx.set_option(k, v)
+        a = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, ha)
+        b = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, hb)
+        c1, evals, ch = pkg.matrix_multiplication.prove(ctx, pkg.matrix_multiplication.G(a, b), pyref.SEED_R)
+        assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]), (n, dma)
+        ctx.close()

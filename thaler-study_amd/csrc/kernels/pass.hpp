@@ -355,12 +355,13 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   constexpr int NP = IN / 2, NPO = OUT / 2;  // 16-byte pieces per lane, in and out
   constexpr int BS = pass_block_threads(KF, KS, NT), kWaves = BS / kWave;
   constexpr bool kPipe = (KF == 4) || (KF == 3 && KS == 2 && (NT & 4) != 0);   // sub-step pipeline (whole tiles only)
+  constexpr bool kDma = (KF == 4) && (NT & 8) != 0;   // ... with its sub-steps brought in by LDS-DMA (no staging registers)
   static_assert(BS == kBlock || NS >= 9, "reduce_cells (the KS = 1 passes) is written for 256 threads");
   // the tile transposes; after the loop the same bytes hold a chunk of every thread's accumulators (reduce_cells_lds)
   // KF = 4: a unit is 64 entries = 32 pieces per table - too many to stage at once; its four outputs (16 entries = 8 pieces
   // each) are produced one after the other, 8 pieces per lane and table in flight (NPS)
   constexpr int NPS = (1 << KF) / 2 > 0 ? (1 << KF) / 2 : 1;   // pieces of one output
-  constexpr int NPL = kPipe ? NPS + 4 : NP;   // pieces per lane the wave's LDS region is laid out for (pipelined: a sub-step + the 4-KiB exchange area)
+  constexpr int NPL = kDma ? 2 * NPS + 2 : kPipe ? NPS + 4 : NP;   // pieces per lane the wave's LDS region is laid out for (pipelined: a sub-step + the 4-KiB exchange area; DMA: two stages + a 2-KiB exchange area)
   constexpr int kTransposeSlots = (NP > 1 || NPO > 1) ? kWaves * kWave * NPL : 1;
   constexpr int kChunkCells = reduce_chunk_cells<typename F::Acc, BS>();
   constexpr int kReduceSlots = (NS >= 9) ? (int)(((NS < kChunkCells ? NS : kChunkCells) * BS * sizeof(typename F::Acc) + sizeof(ull2) - 1) / sizeof(ull2)) : 1;
@@ -488,7 +489,139 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
   };
-  if constexpr (kPipe) {
+  if constexpr (kDma) {
+    // The four-variable fold with its sub-steps brought in by LDS-DMA: no staging registers, the next stage always in
+    // flight.  A stage = one table's sub-step (8 KiB, 64 outputs); a wave owns two stages (table a's and table b's) and a
+    // 2-KiB exchange area; stage j of a tile (j = 0..7: a, b, a, b, ...) is refilled with stage j + 2 the moment its
+    // sixteen entries per lane are in registers.  The destination of an LDS-DMA load is lane-linear, so the swizzle of
+    // transpose_to_runs is applied to the SOURCE piece (swz_slot is an involution inside aligned groups of NPS pieces).
+    // Every LDS access of the loop is inline assembly: behind an LDS-DMA load the compiler orders LDS accesses it cannot
+    // disambiguate with s_waitcnt vmcnt(0), i.e. behind the prefetch.  vmcnt is counted by hand: loads, stores and DMA
+    // complete in issue order, and when stage j is read the only younger operations allowed to be outstanding are the
+    // eight DMA instructions of stage j + 1.
+    static_assert(KS == 2 && NPS == 8, "written for the four-variable fold");
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    typedef const __attribute__((address_space(1))) void* glob_ptr_t;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    ull2* const slot0 = my_lds;                          // table a's stage
+    ull2* const slot1 = my_lds + kWave * NPS;            // table b's
+    const unsigned xbase = (unsigned)(size_t)(lds_ptr_t)(my_lds + 2 * kWave * NPS);   // 2 KiB: exchange / output transposes, one table at a time
+    const int rot = wave & 3;
+    // (swz_slot<8>(64 k + lane) = 64 k + (lane ^ ((4 k + lane / 16) & 7)): two lane offsets, for even and odd k;
+    //  swz_slot<8>(8 lane + m) = 8 lane + (m ^ ((lane / 2) & 7)): one base and one XOR mask - registers are what this kernel is short of)
+    const int src_even = lane ^ ((lane >> 4) & 7), src_odd = lane ^ (((lane >> 4) + 4) & 7);
+    const unsigned rd_base = (unsigned)(size_t)(lds_ptr_t)slot0 + 16u * (unsigned)(NPS * lane), rd_mask = (unsigned)((lane >> 1) & 7);
+    auto issue = [&](const ull2* __restrict__ T, size_t tile, int o, int slot) {
+      const ull2* src = T + tile * kWave * NP + (size_t)o * NPS * kWave;
+      ull2* const dst = slot ? slot1 : slot0;
+#pragma unroll
+      for (int k = 0; k < NPS; ++k)
+        __builtin_amdgcn_global_load_lds((glob_ptr_t)(src + kWave * k + ((k & 1) ? src_odd : src_even)), (lds_ptr_t)(dst + kWave * k), 16, 0,
+                                         kNtLoad ? 2 : 0);
+    };
+    // one stage -> the lane's output: its eight pieces in two batches of four reads (sixteen registers live, not thirty-two)
+#define SC_DMA_READ4(X, R0, OFF)                                                                                      \
+  asm volatile("ds_read_b128 %0, %4 offset:%8\n\tds_read_b128 %1, %5 offset:%8\n\tds_read_b128 %2, %6 offset:%8\n\t" \
+               "ds_read_b128 %3, %7 offset:%8\n\ts_waitcnt lgkmcnt(0)"                                                 \
+               : "=&v"(X[0]), "=&v"(X[1]), "=&v"(X[2]), "=&v"(X[3])                                                  \
+               : "v"(rd_base + 16u * ((unsigned)(R0) ^ rd_mask)), "v"(rd_base + 16u * ((unsigned)(R0 + 1) ^ rd_mask)),  \
+                 "v"(rd_base + 16u * ((unsigned)(R0 + 2) ^ rd_mask)), "v"(rd_base + 16u * ((unsigned)(R0 + 3) ^ rd_mask)), "n"(OFF) \
+               : "memory")
+    auto mac4 = [&](typename F::Acc3& s, const u32x4 (&x)[4], int m0) {
+#pragma unroll
+      for (int m = 0; m < 4; ++m) {
+        f.acc3_mac(s, ((u64)x[m].y << 32) | x[m].x, fw.w[2 * (m0 + m)]);
+        f.acc3_mac(s, ((u64)x[m].w << 32) | x[m].z, fw.w[2 * (m0 + m) + 1]);
+      }
+    };
+    // the exchange area, in assembly as well (wave-private; LDS operations of a wave execute in order)
+    auto x_write64 = [&](unsigned byte_off, u64 v) {
+      const u32x2 w = {(unsigned)v, (unsigned)(v >> 32)};
+      asm volatile("ds_write_b64 %0, %1" ::"v"(xbase + byte_off), "v"(w) : "memory");
+    };
+    auto x_write128 = [&](unsigned byte_off, u64 lo, u64 hi) {
+      const u32x4 w = {(unsigned)lo, (unsigned)(lo >> 32), (unsigned)hi, (unsigned)(hi >> 32)};
+      asm volatile("ds_write_b128 %0, %1" ::"v"(xbase + byte_off), "v"(w) : "memory");
+    };
+    auto x_read128 = [&](unsigned byte_off) -> u32x4 {
+      u32x4 r;
+      asm volatile("s_waitcnt lgkmcnt(0)\n\tds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=&v"(r) : "v"(xbase + byte_off) : "memory");
+      return r;
+    };
+    size_t tile = next_tile();
+    if (tile < n_tiles) {
+      issue(Ap, tile, rot, 0);
+      issue(Bp, tile, rot ^ 2, 1);
+    }
+    while (tile < n_tiles) {
+      const size_t next = next_tile();
+      u64 va[OUT], vb[OUT];
+#pragma unroll
+      for (int i = 0; i < OUT; ++i) {
+        const int na = (i + 1 + rot) & 3;
+        u32x4 x[4], y[4];
+        typename F::Acc3 s;
+        // table a: stage 2 i (slot 0); behind it in the queue: stage 2 i + 1
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        SC_DMA_READ4(x, 0, 0);
+        SC_DMA_READ4(y, 4, 0);
+        if (i + 1 < OUT) issue(Ap, tile, na, 0);
+        else if (next < n_tiles) issue(Ap, next, na, 0);
+        f.acc3_zero(s);
+        mac4(s, x, 0);
+        mac4(s, y, 4);
+        va[i] = f.acc3_get(s);
+        // table b: stage 2 i + 1 (slot 1); behind it: stage 2 i + 2 - unless this was the wave's last tile
+        if (i + 1 < OUT || next < n_tiles) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        SC_DMA_READ4(x, 0, NPS * kWave * 16);
+        SC_DMA_READ4(y, 4, NPS * kWave * 16);
+        if (i + 1 < OUT) issue(Bp, tile, na ^ 2, 1);
+        else if (next < n_tiles) issue(Bp, next, na ^ 2, 1);
+        f.acc3_zero(s);
+        mac4(s, x, 0);
+        mac4(s, y, 4);
+        vb[i] = f.acc3_get(s);
+      }
+#undef SC_DMA_READ4
+      // outputs 64 o + lane -> quads 4 l .. 4 l + 3 per lane, one table at a time through the 2-KiB area; then the quad as
+      // two 16-byte pieces 2 l, 2 l + 1 -> pieces 64 k + lane for the stores
+      u64 a[OUT], b[OUT];
+      ull2 oa[NPO], ob[NPO];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+#pragma unroll
+        for (int i = 0; i < OUT; ++i) {
+          const int o = t ? (((i + rot) & 3) ^ 2) : ((i + rot) & 3);
+          x_write64((unsigned)(kWave * o + lane) * 8u, t ? vb[i] : va[i]);
+        }
+        const u32x4 q0 = x_read128((unsigned)(OUT * lane) * 8u), q1 = x_read128((unsigned)(OUT * lane + 2) * 8u);
+        u64* const q = t ? b : a;
+        q[0] = ((u64)q0.y << 32) | q0.x; q[1] = ((u64)q0.w << 32) | q0.z;
+        q[2] = ((u64)q1.y << 32) | q1.x; q[3] = ((u64)q1.w << 32) | q1.z;
+#pragma unroll
+        for (int m = 0; m < NPO; ++m) x_write128((unsigned)swz_slot<NPO>(NPO * lane + m) * 16u, q[2 * m], q[2 * m + 1]);
+#pragma unroll
+        for (int k = 0; k < NPO; ++k) {
+          const u32x4 r = x_read128((unsigned)swz_slot<NPO>(64 * k + lane) * 16u);
+          ull2& dstp = t ? ob[k] : oa[k];
+          dstp.x = ((u64)r.y << 32) | r.x;
+          dstp.y = ((u64)r.w << 32) | r.z;
+        }
+      }
+      const size_t o0 = tile * kWave * NPO;
+#pragma unroll
+      for (int k = 0; k < NPO; ++k) {
+        const size_t q = o0 + (size_t)k * kWave + lane;
+        st16<kNtStore>(A2p + q, oa[k]);
+        st16<kNtStore>(B2p + q, ob[k]);
+      }
+      accumulate_run<F, KS>(f, acc, a, b);
+      tile = next;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else if constexpr (kPipe) {
     static_assert(KS == 2, "the pipelined folds are instantiated with KS = 2 only");
     // A tile (64 units = 256 outputs per table) is folded in four sub-steps of 64 outputs: the wave loads 8 KiB of each
     // table CONTIGUOUSLY (1 KiB per instruction, as everywhere), stores them to its LDS region, every lane reads its own

@@ -28,6 +28,7 @@
 #include <new>
 #include <string>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/sumcheck_hip.h"
@@ -128,6 +129,7 @@ struct sc_ctx {
   u64* d_wg_groups = nullptr;     // [kWgMaxBlocks / 32][kGridChunk]
   unsigned* d_wg_tickets = nullptr;
   u64* d_gram_totals = nullptr;   // gram_finish_kernel: the 256 Gram entries mod p + its ticket (zero at rest); allocated on first use
+  int fold_dma = 1;       // pass_kernel<4,2>: the LDS-DMA form (kernels/pass.hpp; Goldilocks)
   int pipe32 = 1, pipe32_log = 20, pipe32_blocks = 0;   // pass_kernel<3,2>: the pipelined whole-tile form on tables of >= 2^pipe32_log entries
   int gram_log = 21;              // first pass of an unsharded proof on tables of >= 2^gram_log entries: kernels/gram.hpp (0: never)
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
