@@ -59,7 +59,7 @@ def describe(name):
         return "gram_finish", 0, int(m.group(1))
     if "wgrid_pass_kernel<" in name:
         return "grid_pass", -1, -1       # kf, ks from bench.py's schedule
-    m = re.search(r"pass_kernel<sc::\w+, (\d), (\d)(?:, \d)?>", name)
+    m = re.search(r"pass_kernel<sc::\w+, (\d), (\d)(?:, \d+)?>", name)
     if m:
         return "pass", int(m.group(1)), int(m.group(2))
     m = re.search(r"fold_kernel<sc::\w+, (\d)", name)
