@@ -489,6 +489,20 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
     if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
     return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
   };
+  // Output stores of a folding pass and the L2: the folded entries leave the CUs as a trickle of 1-KiB stores, stay in the
+  // (write-back) L2 until something evicts them line by line, and reach HBM as a trickle too - which costs the READ stream far
+  // more than their bytes (the four-variable fold on 2^28-entry tables: 624-656 us without its stores, 772-822 with them:
+  // 6 % of the bytes, +150 us; nontemporal stores change nothing).  Written back in bulk they cost less: one wave per XCD
+  // (the first eight blocks: workgroups are dealt to the XCDs round-robin) asks its L2 to write its dirty lines back after
+  // every tile it finishes (~1 MB per request at n = 28): 777-784 us where the pass took 820-822 on the same box; every two
+  // tiles 795-801, every four 806-813, four waves per XCD 802-809 (profiles/r04_fold_writeback.txt).  A hint, not a fence:
+  // nothing waits for it.  The pipelined forms only (tiles of 32-64 KiB per table): in the staged two-variable fold, whose
+  // tiles are 8 KiB, a request per tile made the pass on 2^24-entry tables 3 us slower.
+  auto bulk_writeback = [&]() {
+    if constexpr (KF > 0) {
+      if (wave == 0 && blockIdx.x < 8) asm volatile("buffer_wbl2 sc1" ::: "memory");
+    }
+  };
   if constexpr (kDma) {
     // The four-variable fold with its sub-steps brought in by LDS-DMA: no staging registers, the next stage always in
     // flight.  A stage = one table's sub-step (8 KiB, 64 outputs); a wave owns two stages (table a's and table b's) and a
@@ -618,6 +632,7 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
         st16<kNtStore>(B2p + q, ob[k]);
       }
       accumulate_run<F, KS>(f, acc, a, b);
+      bulk_writeback();
       tile = next;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -721,6 +736,7 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
         st16<kNtStore>(B2p + q, ob[k]);
       }
       accumulate_run<F, KS>(f, acc, a, b);
+      bulk_writeback();
       tile = next;
     }
   } else if constexpr (kPrefetch) {
