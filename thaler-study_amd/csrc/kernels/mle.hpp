@@ -55,6 +55,8 @@ fold_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, FoldW fw, size
       ull2 o = {v[0], v[1]};
       T2p[qo] = o;
     }
+    // (bulk write-back of the L2, one wave per XCD: kernels/pass.hpp, bulk_writeback)
+    if (grab > 1 && tile + 1 == run + (size_t)grab && wave == 0 && blockIdx.x < 8) asm volatile("buffer_wbl2 sc1" ::: "memory");
   }
 }
 // LE, scalar tail: outputs that do not fill a 16-byte piece (n_out == 1).
