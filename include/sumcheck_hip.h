@@ -82,9 +82,9 @@ int sc_ctx_create(const sc_field* f, int device, sc_ctx** out);
  * log2(n_devices) index bits = d) lives on devices[d]; sc_table_evaluate, sc_prod2_*, sc_prover_* and sc_prove work on the
  * whole table.  In one process the exchange step of a pass needs no collective: every device's kernel leaves its own sums
  * in its own pinned mailbox and the calling thread adds them (split limbs / residues mod p) before it answers the round;
- * launches go out from one thread per device.  When the shards are down to their pending challenges the host folds the
- * <= 32 entries per table and device it was handed and serves the rounds of the device bits itself: a sharded proof is one
- * launch per device SHORTER than a single-device one.  Results are bit-identical to a one-device context.
+ * launches go out from one thread per device.  When a pass leaves <= 2^host_tail_log entries per table and device it writes
+ * them to pinned host memory and the host finishes the proof (option "host_tail_log"): every launcher thread folds its
+ * device's pending challenges, the calling thread serves the remaining rounds.  Results are bit-identical to a one-device context.
  * Also served: sc_gkr_wiring, sc_gkr_prover_* / sc_gkr_prove (the dense W prover: every device streams its rows of c of add_i /
  * mul_i, the small product proofs run on the first device), sc_gkr_w_evaluate, and sc_tri_prover_* / sc_tri_prove /
  * sc_tri_evaluate (every device squares its rows of the adjacency matrix).  Not served (SC_ERR_UNSUPPORTED):
@@ -110,8 +110,18 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      SIMD); 0 = the staged form everywhere.  Same results; for A/B measurements
  *   "gram_log"         (default 21; 0 = never, else 14..40) a proof on tables (a sharded one: shards) of >= 2^gram_log entries opens
  *                      with gram_pass_kernel: rounds 1..4 from ONE read, as exact integer limb products of the tables'
- *                      bytes on the int8 matrix cores (the kernel does not depend on the modulus), + gram_finish_kernel;
- *                      the pass behind it folds four variables (pass_kernel<4,2>).  DESIGN.md section 4
+ *                      bytes on the int8 matrix cores; every block reduces its accumulators to the 81 cells mod p and the
+ *                      block that finishes last adds them (ONE launch since round 5); the pass behind it folds four
+ *                      variables (pass_kernel<4,2>).  DESIGN.md section 4
+ *   "host_tail_log"    (default 10; 0..10) the host finishes the proof: a pass whose folded tables have <= 2^host_tail_log
+ *                      entries (per device on a multi-device handle) writes them to pinned host memory instead of the
+ *                      pool, and every later round is served by the host from them - fold the pending challenges
+ *                      (<= 2^11 multiply-adds), then one sub-microsecond round at a time - with NO further launch: the
+ *                      last launch (or two) of every proof and every shard, ~13 us each, disappears.  Not a CPU path
+ *                      for the hot loop: what the host touches is what is left when 2^-18 of the work remains.  Applies
+ *                      to unsharded provers (incl. a sharded one after its gather) and to multi-device handles; five-round
+ *                      passes (and any pass with <= 32 outputs) hand over, 0 = off (a multi-device handle then hands
+ *                      over once a shard holds <= 32 entries, as in round 4)
  *   "grid_pass"        the passes whose FOLDED tables have <= 2^"grid_log" (default 20) entries serve up to
  *                      "grid_max_vars" (default 5) rounds each and fold up to five pending challenges at once
  *                      (wgrid_pass_kernel); "grid_blocks" caps the launch (0 = what fits on the chip at once).
@@ -169,7 +179,7 @@ int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset);
 /* 9 was the resident prover kernel (removed in round 3: measured equal to launches) */
 #define SC_KIND_GRID_PASS 10 /* wgrid_pass_kernel: fold kf <= 5 variables of tables of <= 2^20 folded entries + the 3^ks cells of ks <= 5 rounds */
 #define SC_KIND_GRAM_PASS 11   /* gram_pass_kernel: the four-round first pass of a large proof on the int8 matrix cores (ks = 4) */
-#define SC_KIND_GRAM_FINISH 12 /* gram_finish_kernel: its partials -> the 81 cells in the mailbox */
+/* 12 was gram_finish_kernel (rounds 4: a second launch behind the gram pass; folded into gram_pass_kernel in round 5) */
 typedef struct sc_launch_record {
   int32_t kind;           /* SC_KIND_* */
   int32_t kf, ks;         /* variables folded / rounds served (meaning per kind above) */
@@ -296,15 +306,25 @@ int sc_prover_num_vars(const sc_prover* pr, size_t* out);
 #define SC_PLAN_GRID_PASS 1  /* wgrid_pass_kernel: up to five rounds */
 #define SC_PLAN_RANK_PASS 2  /* rank_pass_kernel (peer transport): the rounds of the rank bits */
 #define SC_PLAN_GATHER 3     /* all-gather of the shards; the proof goes on replicated */
-#define SC_PLAN_HOST_TAIL 4  /* multi-device handle (transport 4): the host folds the shards' pending entries and serves the device-bit rounds; no launch */
-#define SC_PLAN_GRAM_PASS 5  /* gram_pass_kernel + gram_finish_kernel: rounds 1..4 of an unsharded proof on tables of >= 2^gram_log entries */
+#define SC_PLAN_HOST_TAIL 4  /* the host finishes: it folds the kf pending challenges of the <= 2^host_tail_log-entry tables the pass before
+                              * wrote to pinned host memory (log_in = log2 entries per table and device) and serves every remaining
+                              * round (ks) itself; no launch.  Always the last step */
+#define SC_PLAN_GRAM_PASS 5  /* gram_pass_kernel: rounds 1..4 of a proof on tables (shards) of >= 2^gram_log entries */
+/* ABI version of this header: bumped whenever a struct below grows or an enum is extended.  sc_abi_version()
+ * returns the library's; a caller built against another major version must not pass structs.  Version 5 = round 5. */
+#define SC_ABI_VERSION 5
+int sc_abi_version(void);
 typedef struct sc_plan_options {   /* the context options the schedule depends on (sc_ctx_set_option names) */
+  uint32_t struct_size;            /* sizeof(sc_plan_options) as the CALLER compiled it: set by sc_plan_options_default from its argument;
+                                    * the library reads and writes no field beyond it (fields a caller's struct lacks take their defaults) */
   int32_t vars_per_pass, first_pass_vars, grid_pass, grid_log, grid_max_vars, grid_sharded, tail_log, use_mailbox, gram_log;
+  int32_t host_tail_log;           /* since version 5 */
 } sc_plan_options;
 typedef struct sc_plan_step {
   int32_t action, kf, ks, log_in, sharded;
 } sc_plan_step;
-void sc_plan_options_default(sc_plan_options* o);
+/* struct_size = sizeof(sc_plan_options) at the call site */
+void sc_plan_options_default(sc_plan_options* o, size_t struct_size);
 int sc_plan_proof(const sc_plan_options* opt, size_t num_vars, int world, int transport, sc_plan_step* out, size_t cap,
                   size_t* n_out);
 

@@ -42,10 +42,14 @@ pub struct sc_ctx {
 pub struct sc_table {
     _private: [u8; 0],
 }
-/// The context options the schedule depends on (`sc_plan_proof`).
+/// `SC_ABI_VERSION` of the header these declarations were written against; `sc_abi_version()` is the library's.
+pub const SC_ABI_VERSION: c_int = 5;
+/// The context options the schedule depends on (`sc_plan_proof`).  `struct_size` is set by
+/// `sc_plan_options_default(&mut o, size_of::<sc_plan_options>())`; the library touches nothing beyond it.
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct sc_plan_options {
+    pub struct_size: u32,
     pub vars_per_pass: i32,
     pub first_pass_vars: i32,
     pub grid_pass: i32,
@@ -55,6 +59,7 @@ pub struct sc_plan_options {
     pub tail_log: i32,
     pub use_mailbox: i32,
     pub gram_log: i32,
+    pub host_tail_log: i32,
 }
 /// One launch of a planned proof: `action` is one of the `SC_PLAN_*` values of the header.
 #[repr(C)]
@@ -195,7 +200,8 @@ extern "C" {
         out: *mut u64,
     ) -> c_int;
 
-    pub fn sc_plan_options_default(o: *mut sc_plan_options);
+    pub fn sc_abi_version() -> c_int;
+    pub fn sc_plan_options_default(o: *mut sc_plan_options, struct_size: usize);
     pub fn sc_plan_proof(
         opt: *const sc_plan_options,
         num_vars: usize,

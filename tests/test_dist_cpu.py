@@ -18,6 +18,21 @@ from conftest import ROOT, load_package
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
+HOST_TABLES = [None]
+
+
+def host_round(o, shards, pending, sub, add):
+    """engine/abi_prover.inc: host_tail + host_round - every shard folds the challenges it has not folded yet, the folded shards
+    in device order are the whole tables, and the round is H(0), H(1), H(inf) over their pairs"""
+    parts = [((o.fix_variables(a, pending), o.fix_variables(b, pending)) if pending else (a, b)) for a, b in shards]
+    a = np.concatenate([x for x, _ in parts])
+    b = np.concatenate([y for _, y in parts])
+    HOST_TABLES[0] = (a, b)
+    h = [int(x) for x in o.gridk_sums(a, b, 1)]
+    t = add(h[1], h[2])
+    return [h[0], h[1], sub(add(t, t), h[0])]          # H(2) = 2H(1) - H(0) + 2H(inf)
+
+
 def model_sharded_prove(o, D, plan_proof, p, n, rank, world, opts, allreduce, allgather, pyref):
     """The sharded prover with the oracle in place of the kernels, driven by the ENGINE'S OWN PLANNER: the launches come
     from sc_plan_proof (the function prover_pass calls at every pass, thaler-study_amd/csrc/engine/abi_prover.inc: plan_pass),
@@ -29,6 +44,7 @@ def model_sharded_prove(o, D, plan_proof, p, n, rank, world, opts, allreduce, al
     ch = [o.challenge(pyref.SEED_R, j + 1) for j in range(n)]
     steps = list(plan_proof(n, world, "host", **opts))
     sharded, pending, cache = True, [], None
+    host = False          # the plan's last step, SC_PLAN_HOST_TAIL: the host serves every remaining round from the (whole) tables
     evals = []
     n_allreduce = n_gather = 0
     L = o.lib
@@ -38,7 +54,7 @@ def model_sharded_prove(o, D, plan_proof, p, n, rank, world, opts, allreduce, al
         if j:
             pending.append(ch[j - 1])
         covered = cache is not None and 0 <= j - cache[1] < cache[0] and len(pending) == j - cache[1]
-        if not covered:
+        if not covered and not host:
             step = steps.pop(0)
             if step["action"] == "gather":
                 assert sharded and step["log_in"] == int(a.size).bit_length() - 1
@@ -47,6 +63,17 @@ def model_sharded_prove(o, D, plan_proof, p, n, rank, world, opts, allreduce, al
                 sharded = False
                 n_gather += 1
                 step = steps.pop(0)
+            if step["action"] == "host_tail":
+                # (only a whole prover hands over on a host transport: after the gather) engine/abi_prover.inc: host_tail
+                assert not sharded and not steps and step["kf"] == len(pending) and step["ks"] == n - j, (step, j)
+                assert step["log_in"] == int(a.size).bit_length() - 1 <= 10
+                host = True
+        if host:
+            evals.append(host_round(o, [[a, b]], pending, sub, add))
+            a, b = HOST_TABLES[0]
+            pending = []
+            continue
+        if not covered:
             assert step["action"] in ("pass", "grid_pass"), step      # (rank passes exist on the peer transport only)
             kf, ks = step["kf"], step["ks"]
             assert kf == len(pending) and step["log_in"] == int(a.size).bit_length() - 1 and step["sharded"] == sharded, (step, len(pending), a.size)
@@ -191,8 +218,8 @@ def test_bench_self_launch_relays_exit_code_without_gpu():
 def model_local_prove(o, plan_proof, p, n, world, opts, pyref):
     """The ONE-PROCESS form (sc_ctx_create_multi, transport "local"): the N shards live in one process, every planned launch runs
     on every shard (the oracle in place of the kernels), the shards' grids are added in the process - no collective - and the
-    plan's last step is the HOST TAIL: the host folds each shard's pending entries and forms the cells of the device-bit rounds
-    from the N entries left per table, as engine/abi_prover.inc: host_tail does."""
+    plan's last step is the HOST TAIL: every shard folds its pending challenges, the folded shards are the whole tables and the
+    host serves every remaining round from them, as engine/abi_prover.inc: host_tail / host_round do."""
     from conftest import load_package
     D = load_package().distributed
     L = o.lib
@@ -206,22 +233,20 @@ def model_local_prove(o, plan_proof, p, n, world, opts, pyref):
     ch = [o.challenge(pyref.SEED_R, j + 1) for j in range(n)]
     steps = list(plan_proof(n, world, "local", **opts))
     pending, cache, evals = [], None, []
+    host = False
     for j in range(n):
         if j:
             pending.append(ch[j - 1])
         covered = cache is not None and 0 <= j - cache[1] < cache[0] and len(pending) == j - cache[1]
-        if not covered:
+        if not covered and not host:
             step = steps.pop(0)
             kf, ks = step["kf"], step["ks"]
             assert kf == len(pending) and step["log_in"] == int(shards[0][0].size).bit_length() - 1, (step, len(pending))
             if step["action"] == "host_tail":
-                assert world > 1 and ks == g and shards[0][0].size == 1 << kf and not steps
-                ta, tb = [], []
-                for a, b in shards:       # one entry per table and shard is left
-                    fa, fb = (o.fix_variables(a, pending), o.fix_variables(b, pending)) if kf else (a, b)
-                    ta.append(int(fa[0]))
-                    tb.append(int(fb[0]))
-                S = [int(x) for x in o.gridk_sums(np.array(ta, dtype=np.uint64), np.array(tb, dtype=np.uint64), g)]
+                # every shard is down to <= 2^host_tail_log entries (<= 32 with the option off): the host takes over for good
+                limit = max(opts.get("host_tail_log", 10), 5) if world > 1 else opts.get("host_tail_log", 10)
+                assert ks == n - j and not steps and (step["log_in"] <= limit or step["log_in"] == kf), (step, j)
+                host = True
             else:
                 assert step["action"] in ("pass", "grid_pass") and step["sharded"] == (world > 1)
                 S = None
@@ -230,8 +255,13 @@ def model_local_prove(o, plan_proof, p, n, world, opts, pyref):
                         sh[0], sh[1] = o.fix_variables(sh[0], pending), o.fix_variables(sh[1], pending)
                     part = [int(x) for x in o.gridk_sums(sh[0], sh[1], ks)]
                     S = part if S is None else [add(x, y) for x, y in zip(S, part)]
+                pending = []
+                cache = (ks, j, S)
+        if host:
+            evals.append(host_round(o, shards, pending, sub, add))
+            shards = [list(HOST_TABLES[0])]
             pending = []
-            cache = (ks, j, S)
+            continue
         ks, j0, S = cache
         grid, cells = list(S), len(S)
         for r in pending:

@@ -37,6 +37,15 @@ def test_default_schedule_uses_grid_passes(pkg, p):
     ctx = pkg.Context(pkg.Field(p))
     o = oracle(p)
     for n in list(range(1, 19)) + [20, 21, 22]:
+        # the default: the launches are the plan's, the host serves what the last launch leaves (option "host_tail_log")
+        ctx.set_option("host_tail_log", 10)
+        log = prove_and_check(pkg, ctx, o, n)
+        plan = pkg.schedule.plan_proof(n)
+        assert [(r["kind"], r["kf"], r["ks"]) for r in log] == [(s["action"], s["kf"], s["ks"]) for s in plan if s["action"] != "host_tail"], (n, log)
+        assert sum(r["ks"] for r in log) == n - (plan[-1]["ks"] if plan[-1]["action"] == "host_tail" else 0)
+        assert (plan[-1]["action"] == "host_tail") == (n > 10), (n, plan)
+        # the device alone (round 4's schedule)
+        ctx.set_option("host_tail_log", 0)
         log = prove_and_check(pkg, ctx, o, n)
         kinds = [r["kind"] for r in log]
         # tables of <= 2^20 entries are proved by grid passes alone; larger ones end with them
@@ -44,7 +53,7 @@ def test_default_schedule_uses_grid_passes(pkg, p):
         if n <= 20:
             assert set(kinds) == {"grid_pass"}, (n, kinds)
             assert len(log) == (n + 4) // 5, (n, log)                        # five rounds per launch
-        assert sum(r["ks"] for r in log if r["kind"] != "gram_finish") == n, (n, log)   # every round served exactly once (gram_finish: the first pass's second launch)
+        assert sum(r["ks"] for r in log) == n, (n, log)   # every round served exactly once
         assert all(r["kf"] <= 5 and 1 <= r["ks"] <= 5 for r in log)
     ctx.close()
 
@@ -54,6 +63,9 @@ def test_default_schedule_uses_grid_passes(pkg, p):
     {"grid_log": 3}, {"grid_log": 8}, {"grid_log": 14, "grid_max_vars": 4}, {"grid_log": 26},
     {"grid_blocks": 1}, {"grid_blocks": 3}, {"grid_blocks": 33}, {"grid_blocks": 70, "grid_max_vars": 3},
     {"grid_pass": 0}, {"grid_pass": 0, "first_pass_vars": 2},
+    # the device alone down to the last round (host_tail_log 0), and host tails from other sizes
+    {"host_tail_log": 0}, {"host_tail_log": 0, "grid_max_vars": 3}, {"host_tail_log": 0, "grid_blocks": 3}, {"host_tail_log": 0, "grid_pass": 0},
+    {"host_tail_log": 6}, {"host_tail_log": 2, "grid_max_vars": 2}, {"host_tail_log": 10, "grid_blocks": 2},
 ], ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()))
 def test_every_grid_schedule_matches_the_oracle(pkg, opts):
     for p in (GOLD, 1572869):

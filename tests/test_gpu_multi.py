@@ -71,11 +71,12 @@ def test_multi_transcripts_match_oracle(p, n_dev):
 
 
 @pytest.mark.parametrize("opts", [{"vars_per_pass": 1}, {"grid_pass": 0}, {"grid_sharded": 0}, {"first_pass_vars": 2}, {"grid_max_vars": 3},
-                                  {"grid_log": 6}, {"first_pass_vars": 1, "grid_max_vars": 2}, {"vars_per_pass": 1, "grid_pass": 0}],
+                                  {"grid_log": 6}, {"first_pass_vars": 1, "grid_max_vars": 2}, {"vars_per_pass": 1, "grid_pass": 0},
+                                  {"host_tail_log": 0}, {"host_tail_log": 0, "grid_pass": 0}, {"host_tail_log": 7}, {"host_tail_log": 3, "grid_max_vars": 2}],
                          ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()))
 def test_multi_every_schedule_matches_oracle(opts):
-    """the option mixes: passes that end on the pinned tail buffer at every size, shards that go on from it (ping-pong of its
-    two halves), host tails that fold 1..5 pending challenges - and the launches of device 0 are the plan's"""
+    """the option mixes: passes that end on the pinned tail buffer at every size (2^0 .. 2^10 entries per device), host tails that
+    fold 0..5 pending challenges on the launcher threads and serve g .. g + 10 rounds - and the launches of device 0 are the plan's"""
     pkg = load_package()
     o = oracle(GOLD)
     for n_dev in (2, 8):
@@ -94,7 +95,7 @@ def test_multi_every_schedule_matches_oracle(opts):
             ctx.set_option("time_kernels", 0)
             assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"]), (n, n_dev, opts)
             plan = pkg.schedule.plan_proof(n, n_dev, "local", **opts)
-            assert plan[-1]["action"] == "host_tail" and plan[-1]["ks"] == g
+            assert plan[-1]["action"] == "host_tail" and plan[-1]["ks"] >= g and sum(s["ks"] for s in plan) == n
             assert log == [(s["action"], s["kf"], s["ks"], s["log_in"]) for s in plan[:-1]], (n, n_dev, opts)
         ctx.close()
 
@@ -125,11 +126,11 @@ def test_multi_n28_equals_one_device():
         assert c8 == c1 and np.array_equal(ev8, evals) and np.array_equal(ch8, ch), n_dev
         assert G.evaluate([int(x) for x in ch]) == final
         if n_dev == 8:
-            # (shard 0's launches: the matrix-core first pass and its finish, the four-variable fold, four five-round passes;
-            # the host serves the three device-bit rounds from the 16 entries per table and device it was handed)
+            # (shard 0's launches: the matrix-core first pass, the four-variable fold, three five-round passes; the launcher threads
+            # fold the five pending challenges of the 2^9 entries per table and device the last one hands over, the host serves
+            # the seven rounds that are left: FIVE launches per device - round 4: seven)
             assert [(r["kind"], r["kf"], r["ks"], r["log_in"]) for r in log] == [
-                ("gram_pass", 0, 4, 25), ("gram_finish", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 5, 21), ("grid_pass", 5, 5, 19),
-                ("grid_pass", 5, 5, 14), ("grid_pass", 5, 4, 9)]
+                ("gram_pass", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 5, 21), ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14)]
         del G, a, b
         ctx.close()
 
@@ -344,8 +345,9 @@ def test_multi_gkr_protocol_end_to_end(n_dev):
 
 
 def test_multi_more_provers_than_tail_slots():
-    """a handle has 64 pinned tail slots; the 65th prover alive at the same time takes pool memory for its last small outputs and
-    the host tail fetches them with a copy - same transcript"""
+    """a handle has 16 pinned tail slots (half of every shard's 32; the other half serves provers created on a shard itself); the
+    17th prover alive at the same time never hands over: it stays on the devices until its shards hold only their pending
+    challenges, and the host tail fetches those from pool memory with a copy - same transcript"""
     pkg = load_package()
     o = oracle(GOLD)
     ctx = multi_ctx(pkg, GOLD, 4)
@@ -356,7 +358,7 @@ def test_multi_more_provers_than_tail_slots():
     a, b = tables(pkg, ctx, n)
     G = pkg.matrix_multiplication.G(a, b)
     provers = [G.native_prover() for _ in range(70)]
-    for k in (0, 63, 64, 69):
+    for k in (0, 15, 16, 17, 69):
         for j in range(n):
             assert provers[k].round_evals(int(ch[j - 1]) if j else 1, j) == [int(x) for x in ref["evals"][j]], (k, j)
     del provers

@@ -18,6 +18,7 @@ OPTION_SETS = [
     {"grid_max_vars": 1}, {"grid_max_vars": 3}, {"grid_log": 3}, {"grid_log": 26}, {"grid_sharded": 0}, {"grid_sharded": 0, "tail_log": 4},
     {"grid_sharded": 0, "tail_log": 0, "grid_pass": 0}, {"use_mailbox": 0}, {"grid_max_vars": 4, "grid_log": 12, "first_pass_vars": 2},
     {"gram_log": 0}, {"gram_log": 14}, {"first_pass_vars": 4}, {"first_pass_vars": 4, "grid_log": 10}, {"gram_log": 20, "grid_pass": 0},
+    {"host_tail_log": 0}, {"host_tail_log": 3}, {"host_tail_log": 7, "grid_max_vars": 2}, {"host_tail_log": 0, "grid_pass": 0},
 ]
 
 
@@ -27,6 +28,8 @@ def check(steps, n, world, transport, opts):
     assert served == n, (served, n)
     cur_log, kf, sharded = n - g, 0, transport != "none" and not (transport == "local" and world == 1)
     gmax = opts.get("grid_max_vars", 5)
+    htl = opts.get("host_tail_log", 10)
+    prev = None
     for s in steps:
         assert s["log_in"] == cur_log and s["sharded"] == (sharded if s["action"] != "gather" else True), (s, cur_log, sharded)
         if s["action"] == "gather":
@@ -39,7 +42,17 @@ def check(steps, n, world, transport, opts):
             # the devices of one multi-device handle: never a gather or a rank pass; the host finishes the device bits
             assert s["action"] in ("pass", "grid_pass", "host_tail", "gram_pass")
         if s["action"] == "host_tail":
-            assert transport == "local" and sharded and cur_log == kf and s["ks"] == g and kf <= 5 and s is steps[-1]
+            # the host finishes: always the last step, it serves every round that is left; only a whole prover or the shards of a
+            # multi-device handle hand over (the shards of the other transports live in other processes), and only tables the
+            # option admits - written by a five-round pass, or <= 32 entries of any pass - or, on a handle, shards that hold
+            # nothing but their pending challenges (wherever those are)
+            local = transport == "local" and sharded
+            assert s is steps[-1] and s["ks"] == n - sum(x["ks"] for x in steps[:-1]) and kf <= 5
+            assert opts.get("use_mailbox", 1) == 1 or (local and cur_log == kf)
+            assert not sharded or local
+            limit = min(max(htl, 5) if local else htl, 10)
+            handed = prev is not None and prev["kf"] > 0 and cur_log <= limit and (prev["action"] == "grid_pass" or cur_log <= 5)
+            assert handed or (local and cur_log == kf), (s, prev, limit)
             cur_log, sharded = 0, False
         elif s["action"] == "rank_pass":
             assert transport == "peer" and sharded and cur_log == kf and s["ks"] == g and 1 <= g <= 3 and kf <= 5
@@ -60,7 +73,14 @@ def check(steps, n, world, transport, opts):
             assert cur_log - kf <= opts.get("grid_log", 20) and opts.get("grid_pass", 1) == 1 and opts.get("use_mailbox", 1) == 1
             assert not sharded or opts.get("grid_sharded", 1) == 1
             cur_log -= kf
+        if s["action"] in ("pass", "grid_pass") and s is not steps[-1] and s["kf"] > 0 and opts.get("use_mailbox", 1) == 1:
+            # a pass that COULD hand over (rule above) does: the next step is the host tail
+            local = transport == "local" and sharded
+            limit = min(max(htl, 5) if local else htl, 10)
+            if (not sharded or local) and cur_log <= limit and (s["action"] == "grid_pass" or cur_log <= 5):
+                assert steps[steps.index(s) + 1]["action"] == "host_tail", (s, steps)
         kf = s["ks"]
+        prev = s
     # whatever is left after the last launch are the variables its cached grid serves
     assert cur_log >= 0
 
@@ -81,10 +101,16 @@ def test_known_schedules(plan):
 
     # the headline: n = 28 on one GPU (bench.py config.schedule of every run): four rounds from the matrix-core pass, then seven
     # launches where the 27-cell first pass (gram_log = 0: rounds 1 to 3) needs eight
+    # (round 5: one launch for the matrix-core pass, and the host finishes from the 2^10-entry tables the sixth launch leaves:
+    # SIX launches)
     assert sig(plan(28)) == [("gram_pass", 0, 4, 28), ("pass", 4, 2, 28), ("pass", 2, 2, 24), ("grid_pass", 2, 5, 22), ("grid_pass", 5, 5, 20),
-                             ("grid_pass", 5, 5, 15), ("grid_pass", 5, 5, 10)]
+                             ("grid_pass", 5, 5, 15), ("host_tail", 5, 5, 10)]
+    assert sig(plan(28, host_tail_log=0)) == sig(plan(28))[:6] + [("grid_pass", 5, 5, 10)]
     assert sig(plan(28, gram_log=0)) == [("pass", 0, 3, 28), ("pass", 3, 2, 28), ("pass", 2, 2, 25), ("pass", 2, 2, 23), ("grid_pass", 2, 5, 21),
-                                         ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14), ("grid_pass", 5, 4, 9)]
+                                         ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14), ("host_tail", 5, 4, 9)]
+    # the shard of an 8-GPU run as a proof of its own: five launches (round 4: seven)
+    assert sig(plan(25)) == [("gram_pass", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 5, 21), ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14),
+                             ("host_tail", 5, 4, 9)]
     assert sig(plan(20))[0] == ("grid_pass", 0, 5, 20) and sig(plan(21))[0] == ("gram_pass", 0, 4, 21)
     assert sig(plan(20, first_pass_vars=4))[:2] == [("gram_pass", 0, 4, 20), ("grid_pass", 4, 4, 20)]
     # BASELINE config 4: n = 28 over 8 ranks, peer transport - seven launches, seven exchanges, no gather
@@ -92,32 +118,65 @@ def test_known_schedules(plan):
     assert sig(s8) == [("gram_pass", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 5, 21), ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14),
                        ("grid_pass", 5, 4, 9), ("rank_pass", 4, 3, 4)]
     assert all(s["sharded"] for s in s8)
+    assert sig(plan(28, 8, "peer", host_tail_log=0)) == sig(s8)     # (the shards of a peer / RCCL / host plane never hand over)
     assert sig(plan(28, 8, "peer", gram_log=0)) == [("pass", 0, 3, 25), ("pass", 3, 2, 25), ("grid_pass", 2, 5, 22), ("grid_pass", 5, 5, 20),
                                                     ("grid_pass", 5, 5, 15), ("grid_pass", 5, 5, 10), ("rank_pass", 5, 3, 5)]
     # the same over RCCL: the shard is gathered when it is down to its pending challenges, the rank bits are one more pass
     r8 = plan(28, 8, "rccl")
     assert sig(r8)[:6] == sig(s8)[:6] and sig(r8)[6:] == [("gather", 0, 0, 4), ("grid_pass", 4, 3, 7)]
-    # ONE process over 8 devices (sc_ctx_create_multi): the same six launches per device, then the host folds the 16 entries
-    # per table and device it was handed and serves the three device-bit rounds - no seventh launch, no gather
+    # ONE process over 8 devices (sc_ctx_create_multi): FIVE launches per device, then every launcher thread folds the five pending
+    # challenges of the 2^9 entries per table its device handed over and the host serves the seven rounds that are left - no gather
     l8 = plan(28, 8, "local")
-    assert sig(l8)[:6] == sig(s8)[:6] and sig(l8)[6:] == [("host_tail", 4, 3, 4)]
+    assert sig(l8)[:5] == sig(s8)[:5] and sig(l8)[5:] == [("host_tail", 5, 7, 9)]
+    # (option off: round 4's schedule - a sixth launch, the host takes the 16 entries per table and device it leaves)
+    l8o = plan(28, 8, "local", host_tail_log=0)
+    assert sig(l8o)[:6] == sig(s8)[:6] and sig(l8o)[6:] == [("host_tail", 4, 3, 4)]
     assert sig(plan(3, 8, "local")) == [("host_tail", 0, 3, 0)]      # one entry per device: the host serves every round
     assert sig(plan(28, 1, "local")) == sig(plan(28))                  # one device behind the handle: the plain schedule
     # two rounds per pass with a gather at 2^16-entry shards (grid_sharded 0): round 1's sharded schedule
     t8 = plan(28, 8, "rccl", grid_sharded=0)
     assert [s["action"] for s in t8].count("gather") == 1 and t8[[s["action"] for s in t8].index("gather")]["log_in"] == 16
     # small proofs are grid passes alone, five rounds per launch
-    assert sig(plan(12)) == [("grid_pass", 0, 4, 12), ("grid_pass", 4, 4, 12), ("grid_pass", 4, 4, 8)]
-    assert len(plan(20)) == 4 and len(plan(5)) == 1
+    assert sig(plan(12)) == [("grid_pass", 0, 4, 12), ("grid_pass", 4, 4, 12), ("host_tail", 4, 4, 8)]
+    assert sig(plan(12, host_tail_log=0)) == [("grid_pass", 0, 4, 12), ("grid_pass", 4, 4, 12), ("grid_pass", 4, 4, 8)]
+    assert len(plan(20)) == 4 and len(plan(5)) == 1 and sig(plan(10)) == [("grid_pass", 0, 5, 10), ("grid_pass", 5, 5, 10)]
 
 
 def test_plan_argument_checks(plan):
     pkg = load_package()
     for bad in [dict(num_vars=2, world=8, transport="peer"), dict(num_vars=10, world=3, transport="peer"),
                 dict(num_vars=10, world=2, transport="none"), dict(num_vars=10, world=1, transport="none", grid_max_vars=6),
-                dict(num_vars=10, world=1, transport="none", vars_per_pass=3)]:
+                dict(num_vars=10, world=1, transport="none", vars_per_pass=3), dict(num_vars=10, world=1, transport="none", host_tail_log=11)]:
         with pytest.raises(pkg.SumcheckHipError) as ei:
             plan(**bad)
         assert ei.value.code == 1
     with pytest.raises(KeyError):
         plan(10, no_such_option=1)
+
+
+def test_plan_options_struct_is_versioned():
+    """sc_plan_options carries the size the CALLER compiled; the library writes and reads nothing beyond it, fields a
+    caller's (older, shorter) struct lacks take their defaults, and an uninitialised struct is refused"""
+    import ctypes
+    pkg = load_package()
+    lib, L = pkg._lib.load(), pkg._lib
+    assert lib.sc_abi_version() == L.ABI_VERSION == 5
+    full = L.ScPlanOptions()
+    lib.sc_plan_options_default(ctypes.byref(full), ctypes.sizeof(full))
+    assert full.struct_size == ctypes.sizeof(full) == 44 and full.host_tail_log == 10 and full.gram_log == 21
+
+    class Old(ctypes.Structure):      # a caller built before host_tail_log existed, with a guard word behind its struct
+        _fields_ = [("struct_size", ctypes.c_uint32)] + [(k, ctypes.c_int32) for k in (
+            "vars_per_pass", "first_pass_vars", "grid_pass", "grid_log", "grid_max_vars", "grid_sharded", "tail_log", "use_mailbox", "gram_log")] + \
+            [("guard", ctypes.c_int32)]
+    old = Old()
+    old.guard = 0x5A5A5A5A
+    lib.sc_plan_options_default(ctypes.cast(ctypes.byref(old), ctypes.POINTER(L.ScPlanOptions)), 40)
+    assert old.struct_size == 40 and old.guard == 0x5A5A5A5A and old.gram_log == 21
+    old.guard = 0          # (would read as host_tail_log = 0 if the library looked past struct_size)
+    steps = (L.ScPlanStep * 64)()
+    n = ctypes.c_size_t()
+    assert lib.sc_plan_proof(ctypes.cast(ctypes.byref(old), ctypes.POINTER(L.ScPlanOptions)), 28, 1, 0, steps, 64, ctypes.byref(n)) == 0
+    assert L.PLAN_ACTIONS[steps[n.value - 1].action] == "host_tail"          # the default, not the guard word
+    blank = L.ScPlanOptions()
+    assert lib.sc_plan_proof(ctypes.byref(blank), 28, 1, 0, steps, 64, ctypes.byref(n)) == 1      # SC_ERR_ARG: never initialised

@@ -27,9 +27,13 @@ class ScField(ctypes.Structure):
     _fields_ = [("p", u64), ("p_inv_neg", u64), ("r_mod_p", u64), ("r2_mod_p", u64)]
 
 
+ABI_VERSION = 5   # SC_ABI_VERSION of include/sumcheck_hip.h as this binding was written
+
+
 class ScPlanOptions(ctypes.Structure):
-    _fields_ = [(k, ctypes.c_int32) for k in ("vars_per_pass", "first_pass_vars", "grid_pass", "grid_log", "grid_max_vars", "grid_sharded",
-                                             "tail_log", "use_mailbox", "gram_log")]
+    _fields_ = [("struct_size", ctypes.c_uint32)] + [
+        (k, ctypes.c_int32) for k in ("vars_per_pass", "first_pass_vars", "grid_pass", "grid_log", "grid_max_vars", "grid_sharded",
+                                      "tail_log", "use_mailbox", "gram_log", "host_tail_log")]
 
 
 class ScPlanStep(ctypes.Structure):
@@ -45,7 +49,7 @@ class ScLaunchRecord(ctypes.Structure):
                 ("bytes_read", u64), ("bytes_written", u64), ("ms", ctypes.c_double)]
 
 
-KIND_NAMES = {0: "pass", 2: "evaluate", 3: "fold", 4: "fix_low", 5: "fold_be", 6: "coldot", 7: "gkr", 8: "matsq", 10: "grid_pass", 11: "gram_pass", 12: "gram_finish"}
+KIND_NAMES = {0: "pass", 2: "evaluate", 3: "fold", 4: "fix_low", 5: "fold_be", 6: "coldot", 7: "gkr", 8: "matsq", 10: "grid_pass", 11: "gram_pass"}
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, voidp, u64p, size_t)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, voidp, u64p, u64p, size_t)
@@ -92,7 +96,8 @@ SIGNATURES = {
     "sc_prod2_round_sums": (ctypes.c_int, [voidp, voidp, voidp, u64p]),
     "sc_prod2_fold_and_sums": (ctypes.c_int, [voidp, voidp, voidp, u64p, ctypes.POINTER(voidp), ctypes.POINTER(voidp), u64p]),
     "sc_prod2_evaluate": (ctypes.c_int, [voidp, voidp, voidp, u64p, size_t, u64p]),
-    "sc_plan_options_default": (None, [ctypes.POINTER(ScPlanOptions)]),
+    "sc_abi_version": (ctypes.c_int, []),
+    "sc_plan_options_default": (None, [ctypes.POINTER(ScPlanOptions), size_t]),
     "sc_plan_proof": (ctypes.c_int, [ctypes.POINTER(ScPlanOptions), size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ScPlanStep), size_t,
                                      ctypes.POINTER(size_t)]),
     "sc_prover_create": (ctypes.c_int, [voidp, voidp, voidp, ctypes.POINTER(voidp)]),
@@ -166,6 +171,10 @@ def load():
     except Exception:
         pass
     lib = ctypes.CDLL(LIB_PATH)
+    lib.sc_abi_version.restype = ctypes.c_int
+    if lib.sc_abi_version() != ABI_VERSION:
+        raise ImportError("%s speaks ABI version %d, this binding %d: rebuild (`make -C thaler-study_amd/csrc`)"
+                          % (LIB_PATH, lib.sc_abi_version(), ABI_VERSION))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

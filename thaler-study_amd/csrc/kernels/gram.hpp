@@ -1,5 +1,5 @@
 // Part of kernels.hpp (included there, in order): the FOUR-round first pass of a large proof on the int8 matrix cores
-// (gram_pass_kernel, gram_finish_kernel).
+// (gram_pass_kernel: the Gram matrix of the tables' bytes AND, since round 5, its reduction to the 81 cells - one launch).
 #pragma once
 
 namespace sc {
@@ -18,9 +18,9 @@ namespace sc {
 // exactly as they lie in HBM:
 //     G[8x+i][8y+j] = sum_rows byte_i(a[.. + x]) * byte_j(b[.. + y])         (exact integers)
 //     sum_rows a b  = sum_{i,j} 2^(8(i+j)) G[8x+i][8y+j]                      (an integer of <= 64+64+n bits)
-// and a Montgomery product a (*) b = a b 2^-64 mod p summed over the rows is that integer times 2^-64 mod p.  The kernel
-// never sees p: the SAME code serves every modulus, and the 27-cell first pass's ~560 VALU instructions per 8 entries per
-// table pair (86 % VALU-busy at 0.80 of the HBM peak) become ~45 per 1024 entries.  K = 4: 128 x 128 byte columns,
+// and a Montgomery product a (*) b = a b 2^-64 mod p summed over the rows is that integer times 2^-64 mod p.  The loop
+// never sees p (the modulus enters in the epilogue, once per block and partial), and the 27-cell first pass's ~560 VALU
+// instructions per 8 entries per table pair (86 % VALU-busy at 0.80 of the HBM peak) become ~45 per 1024 entries.  K = 4: 128 x 128 byte columns,
 // 128 MACs per byte read; measured (tools/gram/gram4_bench.hip) the pass then runs at the rate the DMA skeleton alone
 // reaches (6.2 TB/s), at K = 5 (256 MACs per byte) the chip lowers its clock under the matrix cores' load
 // (1.57 GHz instead of 2.1) and the pass is 11 % slower than at K = 4 - and the fold pass behind a four-round pass
@@ -31,7 +31,8 @@ namespace sc {
 // with the unsigned column sums sum u taken by v_sad_u8 on the operands the wave holds anyway.
 // int32 accumulators: |s s'| <= 2^14, so one accumulator takes 2^16 rows; a launch cuts the rows into `n_partials`
 // interleaved slices of at most that many (step t belongs to partial t % n_partials) and a block walks the partials
-// blockIdx, blockIdx + gridDim, ...; gram_finish_kernel adds the partials as 64-bit integers.
+// blockIdx, blockIdx + gridDim, ...; behind each partial the block reduces its accumulators to the 256 Gram entries mod p
+// (gram_reduce_partial) and adds them to the entries of its earlier partials.
 //
 // Data path: global_load_lds_dwordx4 (1 KiB per wave instruction, no staging registers) into a ring of kGramStages
 // stages of 8 KiB per table; ds_read_b64_tr_b8 hands a lane the eight ROWS of one byte column (the contraction index
@@ -52,7 +53,6 @@ struct GramGeo {
   static constexpr int KSUB = ROWS / 32;         // MFMA k-steps per stage
   static constexpr int MB = RB / 64, NBK = RB / 128;   // 32-column blocks per wave along the rows / columns of G
   static constexpr int CPR = RB / 16;            // 16-byte chunks per row
-  static constexpr int kWords = RB * RB + 2 * RB;   // words per partial: G in accumulator order, then the byte sums of a and b
   static constexpr int kEntriesPerStep = kGramTabBytes / 8;
   static constexpr int kMaxSteps = kGramMaxRows / ROWS;   // steps per partial at most
 };
@@ -62,14 +62,6 @@ __device__ __forceinline__ int gram_swz(int row, int chunk) {
   if constexpr (K1 == 5) return (((chunk >> 1) ^ (row & 7)) << 1) | (chunk & 1);
   else return (((chunk >> 1) ^ ((row >> 1) & 3)) << 1) | (chunk & 1);
 }
-// word of G[m][n] inside a partial: pair-major - the 64 limb products of Gram entry (x, y) = (m / 8, n / 8) are contiguous
-// (256 bytes), so the block of gram_finish_kernel that owns the entry reads them as one line per partial.  (C/D layout of
-// the 32x32 MFMA, for the stores: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5); cdna_hip_programming.md section 3)
-template <int K1>
-__host__ __device__ constexpr int gram_word(int m, int n) {
-  return (((m >> 3) << K1) + (n >> 3)) * 64 + (m & 7) * 8 + (n & 7);
-}
-
 typedef int gram_v2i __attribute__((ext_vector_type(2)));
 typedef int gram_v4i __attribute__((ext_vector_type(4)));
 typedef int gram_v16i __attribute__((ext_vector_type(16)));
@@ -93,14 +85,25 @@ typedef int gram_v16i __attribute__((ext_vector_type(16)));
                :                                                                                                                    \
                : "memory")
 
+// Words per block of the hand-off rows (>= 3^4 cells)
+constexpr int kGramRowWords = 128;
+
 // A, B: the tables as bytes.  Step t (8 KiB of each table) belongs to partial t % n_partials; steps_per_partial is a
-// multiple of kGramStages and at most GramGeo::kMaxSteps.  partials: [n_partials][kWords] words.
+// multiple of kGramStages and at most GramGeo::kMaxSteps.
 // NT: the DMA loads carry the nontemporal hint (tables far larger than the 256 MiB Infinity Cache are read once: with
 // allocating loads the same loop runs at 6.1 TB/s instead of 7.0, tools/gram/gram4_bench.hip -DGRAM_AUX=2)
-template <int K1, bool NT>
+//
+// Round 5: ONE launch.  Until then the blocks stored their int32 accumulators (66 KiB per partial, 17 MB per launch) and a
+// second kernel of 256 blocks added them: 12-14 us + a kernel boundary on every proof and every shard.  Now each block
+// reduces what it holds (gram_reduce_partial: accumulators -> the 256 Gram entries mod p, ~2 us on the block's own LDS),
+// turns the entries into the 3^K1 cells (linear: gram_entries_to_cells), stores 81 words, draws a ticket, and the block
+// that draws the last one adds the rows and hands the cells on exactly as wgrid_pass_kernel<F, K1> does (publish_cells:
+// the wide mailbox, the in-kernel exchange with the peers, or split limbs for a collective).  rows: [gridDim][kGramRowWords]
+// words; *ticket rests at zero.
+template <class F, int K1, bool NT>
 __global__ void __launch_bounds__(kGramThreads)
-gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, unsigned n_partials, unsigned steps_per_partial,
-                 int* __restrict__ partials) {
+gram_pass_kernel(F f, const unsigned char* __restrict__ A, const unsigned char* __restrict__ B, unsigned n_partials, unsigned steps_per_partial,
+                 u64* __restrict__ rows, unsigned* __restrict__ ticket, WgOut out) {
   typedef GramGeo<K1> G;
   constexpr int NS = kGramStages;
   extern __shared__ __attribute__((aligned(16))) unsigned char gram_lds[];
@@ -209,6 +212,7 @@ gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __res
     __builtin_amdgcn_s_barrier();                                                                     \
     if ((S) + NS < my_steps) issue(first + ((S) + NS) * stride, (STAGE) * kGramStageBytes);           \
   } while (0)
+  u64 m_acc = 0;   // thread e < 256: Gram entry e = 16 x + y of this block's partials, mod p
   for (unsigned part = blockIdx.x; part < n_partials; part += gridDim.x) {
     const size_t first = part;
 #pragma unroll
@@ -239,158 +243,99 @@ gram_pass_kernel(const unsigned char* __restrict__ A, const unsigned char* __res
       compute(r1);
       if (more) SC_GRAM_WAIT12(r0);
     }
-    // the partial, pair-major (gram_word), then the byte sums (the two k-halves of a column live in lanes l, l + 32)
-    int* const out = partials + (size_t)part * G::kWords;
-#pragma unroll
-    for (int a = 0; a < G::MB; ++a)
-#pragma unroll
-      for (int b = 0; b < G::NBK; ++b)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int m = (G::RB / 2) * mh + 32 * a + (e & 3) + 8 * (e >> 2) + 4 * h, n = (G::RB / 4) * nq + 32 * b + (lane & 31);
-          out[gram_word<K1>(m, n)] = acc[a][b][e];
-        }
+    // ---- this partial's accumulators -> the 256 Gram entries mod p, added to the block's running entries ----
+    // C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5) (cdna_hip_programming.md
+    // section 3): register e of block a holds G[m][n], m = 64 mh + 32 a + 8 (e >> 2) + (e & 3) + 4 h, n = 32 nq + (lane & 31),
+    // i.e. Gram entry (x, y) = (m / 8, n / 8), limb product (i, j) = (m % 8, n % 8) = ((e & 3) + 4 h, lane & 7).
+    //   T_ij = sum_rows u_i u'_j = G + 128 (Su_i + Su'_j) - 16384 rows   (>= 0, < 2^32: a partial has <= 2^16 rows)
+    //   entry = sum_ij 2^(8(i+j)) T_ij  (< 2^153)  ->  ONE reduction (wide_get, which also supplies the 2^-64 of the Montgomery products)
+    static_assert(K1 == 4, "the epilogue's thread mapping is written for 128 x 128 byte columns");
+    long long* const ca = reinterpret_cast<long long*>(gram_lds + 32768);        // [RB]: 128 Su_i - 16384 rows
+    long long* const cb = ca + G::RB;                                            // [RB]: 128 Su'_j
+    u64* const vbuf = reinterpret_cast<u64*>(gram_lds);                          // [256 entries][16 = (h, j)], rotated by the entry
+    __syncthreads();   // every wave has its last operands in registers: the stages are free
+    const long long rows_part = (long long)my_steps * G::ROWS;
     if (nq == 0) {
 #pragma unroll
       for (int a = 0; a < G::MB; ++a) {
-        const unsigned t = su_a[a] + (unsigned)__shfl_xor((int)su_a[a], 32, 64);
-        if (h == 0) out[G::RB * G::RB + (G::RB / 2) * mh + 32 * a + (lane & 31)] = (int)t;
+        const unsigned t = su_a[a] + (unsigned)__shfl_xor((int)su_a[a], 32, 64);   // (the two k-halves of a column live in lanes l, l + 32)
+        if (h == 0) ca[(G::RB / 2) * mh + 32 * a + (lane & 31)] = 128ll * (long long)t - 16384ll * rows_part;
       }
     }
     if (mh == 0) {
 #pragma unroll
       for (int b = 0; b < G::NBK; ++b) {
         const unsigned t = su_b[b] + (unsigned)__shfl_xor((int)su_b[b], 32, 64);
-        if (h == 0) out[G::RB * G::RB + G::RB + (G::RB / 4) * nq + 32 * b + (lane & 31)] = (int)t;
+        if (h == 0) cb[(G::RB / 4) * nq + 32 * b + (lane & 31)] = 128ll * (long long)t;
       }
+    }
+    __syncthreads();
+    {
+      const int n = (G::RB / 4) * nq + (lane & 31), y = n >> 3, jj = n & 7;
+      const long long cbv = cb[n];
+#pragma unroll
+      for (int a = 0; a < G::MB; ++a)
+#pragma unroll
+        for (int xq = 0; xq < 4; ++xq) {
+          const int m0 = (G::RB / 2) * mh + 32 * a + 8 * xq + 4 * h;
+          u64 v = 0;
+#pragma unroll
+          for (int il = 0; il < 4; ++il) v += (u64)((long long)acc[a][0][4 * xq + il] + ca[m0 + il] + cbv) << (8 * il);   // < 2^57
+          const int e = (m0 >> 3) * 16 + y;
+          vbuf[e * 16 + ((8 * h + jj + e) & 15)] = v;
+        }
+    }
+    __syncthreads();
+    if (tid < 256) {
+      // sum_k v_k 2^(32 h + 8 j), k = 8 h + j: three words
+      u64 w0 = 0, w1 = 0, w2 = 0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        const u64 v = vbuf[tid * 16 + ((k + tid) & 15)];
+        const int sh = 32 * (k >> 3) + 8 * (k & 7);
+        if (sh < 64) {
+          const u64 lo = v << sh, hi = sh ? v >> (64 - sh) : 0;
+          u64 t;
+          const bool c = __builtin_add_overflow(w0, lo, &t);
+          w0 = t;
+          const bool c2 = __builtin_add_overflow(w1, hi, &t);
+          const bool c3 = __builtin_add_overflow(t, (u64)(c ? 1 : 0), &t);
+          w1 = t;
+          w2 += (c2 ? 1 : 0) + (c3 ? 1 : 0);
+        } else {
+          const int s2 = sh - 64;
+          const u64 lo = v << s2, hi = s2 ? v >> (64 - s2) : 0;
+          u64 t;
+          const bool c = __builtin_add_overflow(w1, lo, &t);
+          w1 = t;
+          w2 += hi + (c ? 1 : 0);
+        }
+      }
+      m_acc = f.add(m_acc, f.wide_get(w0, w1, (u32)w2));   // (w2 < 2^25)
     }
   }
 #undef SC_GRAM_TOP
-}
-#undef SC_GRAM_READ12
-#undef SC_GRAM_WAIT12
-#undef SC_TR8
-
-// The partials -> the 3^K1 cells of rounds 1..K1, handed on exactly as wgrid_pass_kernel<F, K1> hands its cells on
-// (publish_cells: the wide mailbox, the in-kernel exchange with the peers, or split limbs for a collective) - the host
-// cannot tell the two apart.  One block per Gram entry (x, y):
-//  1. it adds its 64 limb products and its 16 byte sums over all partials (64-bit; one 256-byte line per partial),
-//     forms T_ij = sum_rows u_i u'_j = G + 128 (Su_i + Su'_j) - 16384 rows, the fifteen anti-diagonal sums, their weighted
-//     sum sum_s D_s 2^(8s) as a 162-bit integer and ONE reduction (wide_get, which also supplies the factor 2^-64 of the
-//     Montgomery products): M[x][y] = sum a (*) b mod p, stored for the last block;
-//  2. the block that draws the last ticket turns M into the cells, one variable at a time (256 -> 192 -> 144 -> 108 -> 81
-//     words at K1 = 4), and hands them on.  The ticket rests at zero.
-template <class F, int K1>
-__global__ void __launch_bounds__(kBlock)
-gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, unsigned long long rows, u64* __restrict__ m_out,
-                   unsigned* __restrict__ ticket, WgOut out) {
-  typedef GramGeo<K1> G;
-  constexpr int X = 1 << K1;
-  constexpr int kPow3[6] = {1, 3, 9, 27, 81, 243};
-  constexpr int cells = kPow3[K1];
-  static_assert(kBlock == 256, "four slices of 64 words / sixteen slices of 16 sums");
-  __shared__ long long red[4][64], sred[16][16];
-  __shared__ unsigned long long diag[15];
-  __shared__ u64 M[X * X], W[X * X];
-  __shared__ int last_flag;
-  const int tid = threadIdx.x;
-  const int pair = blockIdx.x, x = pair / X, y = pair % X;
-  {
-    // the entry's 64 limb products: thread = (word, slice of the partials)
-    const int w = tid & 63, slice = tid >> 6;
-    const int* src = partials + pair * 64 + w;
-    long long s = 0;
-    unsigned v = slice;
-    for (; v + 15 * 4 < n_partials; v += 16 * 4) {   // sixteen loads in flight
-      int t[16];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) t[u] = src[(size_t)(v + u * 4) * G::kWords];
-#pragma unroll
-      for (int u = 0; u < 16; ++u) s += (long long)t[u];
-    }
-    for (; v < n_partials; v += 4) s += (long long)src[(size_t)v * G::kWords];
-    red[slice][w] = s;
-  }
-  {
-    // its byte sums (unsigned words): thread = (sum, slice)
-    const int k = tid & 15, slice = tid >> 4;
-    const int* src = partials + G::RB * G::RB + (k < 8 ? 8 * x + k : G::RB + 8 * y + (k - 8));
-    long long s = 0;
-    unsigned v = slice;
-    for (; v + 7 * 16 < n_partials; v += 8 * 16) {
-      int t[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(v + u * 16) * G::kWords];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) s += (long long)(unsigned)t[u];
-    }
-    for (; v < n_partials; v += 16) s += (long long)(unsigned)src[(size_t)v * G::kWords];
-    sred[slice][k] = s;
-  }
-  __syncthreads();
-  if (tid < 64) red[0][tid] += red[1][tid] + red[2][tid] + red[3][tid];
-  else if (tid < 80) {
-    const int k = tid - 64;
-    long long t = 0;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) t += sred[q][k];
-    sred[0][k] = (k < 8) ? 128 * t - 16384 * (long long)rows : 128 * t;
-  }
-  __syncthreads();
-  if (tid < 15) {
-    // T_ij >= 0, < 2^16 rows; a diagonal < 8 * 2^16 * rows < 2^49
-    unsigned long long d = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int j = tid - i;
-      if (j >= 0 && j < 8) d += (unsigned long long)(red[0][8 * i + j] + sred[0][i] + sred[0][8 + j]);
-    }
-    diag[tid] = d;
-  }
-  __syncthreads();
-  if (tid == 0) {
-    u64 w[4] = {0, 0, 0, 0};
-#pragma unroll
-    for (int s = 0; s < 15; ++s) {
-      const int wd = (8 * s) / 64, bt = (8 * s) % 64;
-      const u64 lo = diag[s] << bt, hi = bt ? diag[s] >> (64 - bt) : 0;
-      u64 t;
-      const bool c = __builtin_add_overflow(w[wd], lo, &t);
-      w[wd] = t;
-      const bool c2 = __builtin_add_overflow(w[wd + 1], hi, &t);
-      const bool c3 = __builtin_add_overflow(t, (u64)(c ? 1 : 0), &t);
-      w[wd + 1] = t;
-      if (wd + 2 < 4) w[wd + 2] += (c2 ? 1 : 0) + (c3 ? 1 : 0);
-    }
-    // (word 3 stays zero: the sum is below 2^162; what passes 2^160 goes through 2^160 * 2^-64 mod p)
-    u64 v = f.wide_get(w[0], w[1], (u32)w[2]);
-    if (w[2] >> 32) v = f.add(v, f.mul(w[2] >> 32, f.mul(f.r_squared(), f.mul(f.r_squared(), 1ull << 32))));
-    // hand-off as in finish_pass (Guideline 16, R1): write-through store, drain, ticket; the last block acquires
-    __hip_atomic_store(m_out + pair, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (t == gridDim.x - 1) ? 1 : 0;
-    if (last) {
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    last_flag = last;
-  }
-  __syncthreads();
-  if (!last_flag) return;
-  for (int i = tid; i < X * X; i += kBlock) M[i] = __hip_atomic_load(m_out + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every block has drawn: back to rest
-  __syncthreads();
+  // ---- the block's entries -> its cells -> the hand-off ----
   // M -> cells, one variable at a time: the pair (bit j of x, bit j of y) becomes the digit d_j in {0, 1, inf}:
   // d = 0 / 1 pins both bits; inf is (a1 - a0)(b1 - b0) = M11 - M10 - M01 + M00 in that variable.  Index of the working
   // array after j variables: ((x >> j) * (X >> j) + (y >> j)) * 3^j + digits, digits = sum_{i<j} d_i 3^(j-1-i) - after K1
   // variables the cell index itself (variable 0 on the slowest axis).  (Unrolled: every division is by a constant.)
-  u64* src = M;
-  u64* dst = W;
+  // Linear in M, so it commutes with the sum over the blocks: done per block, the rows that cross the chip are 81 words.
+  constexpr int X = 1 << K1;
+  constexpr int kPow3[6] = {1, 3, 9, 27, 81, 243};
+  constexpr int cells = kPow3[K1];
+  u64* const Mb = reinterpret_cast<u64*>(gram_lds + 36864);   // (behind ca / cb; a block with no partial left the LDS untouched)
+  u64* const Wb = Mb + X * X;
+  __shared__ int last_flag;
+  __syncthreads();
+  if (tid < X * X) Mb[tid] = m_acc;
+  __syncthreads();
+  u64* src = Mb;
+  u64* dst = Wb;
 #pragma unroll
   for (int j = 0; j < K1; ++j) {
     const int side = X >> j, half = side / 2, pow3 = kPow3[j], n_out = half * half * pow3 * 3;
-    for (int o = tid; o < n_out; o += kBlock) {
+    for (int o = tid; o < n_out; o += kGramThreads) {
       const int d = o % 3, dig = (o / 3) % pow3, yx = o / (3 * pow3), yr = yx % half, xr = yx / half;
       auto at = [&](int bx, int by) { return src[((2 * xr + bx) * side + (2 * yr + by)) * pow3 + dig]; };
       u64 v;
@@ -402,7 +347,60 @@ gram_finish_kernel(F f, const int* __restrict__ partials, unsigned n_partials, u
     __syncthreads();
     u64* t = src; src = dst; dst = t;
   }
-  publish_cells<cells>(out, tid < cells ? src[tid] : 0);   // (unsharded: the wide mailbox; sharded: as a grid pass's cells)
+  u64 total = tid < cells ? src[tid] : 0;
+  if (gridDim.x > 1) {
+    // hand-off as in finish_pass (Guideline 16, R1): write-through stores, every storing wave drains, ticket; the last block acquires
+    if (tid < cells) __hip_atomic_store(rows + (size_t)blockIdx.x * kGramRowWords + tid, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (t == gridDim.x - 1) ? 1 : 0;
+      if (last) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      last_flag = last;
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    // thread = (slice of the blocks, cell): a wave's load reads one contiguous run of a row; sixteen loads of a thread in flight
+    constexpr int kSlices = kGramThreads / kGramRowWords;   // 4
+    u64* const fin = Mb;                                    // [kSlices][kGramRowWords]
+    {
+      const int slice = tid / kGramRowWords, c = tid % kGramRowWords;
+      u64 part = 0;
+      if (c < cells) {
+        const int n_blocks = gridDim.x;
+        for (int b0 = slice; b0 < n_blocks; b0 += kSlices * 16) {
+          u64 x[16];
+#pragma unroll
+          for (int u = 0; u < 16; ++u) {
+            const int b = b0 + u * kSlices;
+            x[u] = (b < n_blocks) ? __hip_atomic_load(rows + (size_t)b * kGramRowWords + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+          }
+#pragma unroll
+          for (int u = 0; u < 8; ++u) x[u] = f.add(x[u], x[u + 8]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) x[u] = f.add(x[u], x[u + 4]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) part = f.add(part, x[u]);
+        }
+      }
+      fin[slice * kGramRowWords + c] = part;
+    }
+    if (tid == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // every block has drawn: back to rest
+    __syncthreads();
+    total = 0;
+    if (tid < cells) {
+#pragma unroll
+      for (int q = 0; q < kSlices; ++q) total = f.add(total, fin[q * kGramRowWords + tid]);
+    }
+  }
+  publish_cells<cells>(out, total);   // (unsharded: the wide mailbox; sharded: as a grid pass's cells)
 }
+#undef SC_GRAM_READ12
+#undef SC_GRAM_WAIT12
+#undef SC_TR8
 
 }  // namespace sc

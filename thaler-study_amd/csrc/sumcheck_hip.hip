@@ -91,10 +91,12 @@ bool load_rccl(std::string* why) {
 // launch leaves this shard's own sums in its own mailbox and the handle's host thread adds them - no collective at all
 enum class Transport { kNone, kRccl, kHost, kPeer, kLocal };
 constexpr int kMaxSubs = 8;          // devices behind one multi-device handle (one node)
-constexpr int kTailEntries = 32;     // a pass of such a handle whose outputs have <= this many entries per table writes them to
-                                     // pinned host memory (sc_ctx::h_tail): the host finishes the proof from them
-constexpr int kTailSlots = 64;       // provers of one handle that can hold a tail slot at a time (the others use pool memory)
-constexpr size_t kTailSlotWords = 4 * (size_t)kTailEntries;   // [parity][table][kTailEntries]
+constexpr int kTailLogMax = 10;
+constexpr int kTailEntries = 1 << kTailLogMax;   // a pass whose outputs have <= 2^host_tail_log <= this many entries per table writes them to
+                                     // pinned host memory (sc_ctx::h_tail): the host finishes the proof from them (option "host_tail_log")
+constexpr int kTailSmallLog = 5;     // ... and what a pass_kernel launch may hand over: one wave's stores (finish_pass drains wave 0 only)
+constexpr int kTailSlots = 32;       // provers of one context / handle that can hold a tail slot at a time (the others stay on the device)
+constexpr size_t kTailSlotWords = 2 * (size_t)kTailEntries;   // [table][kTailEntries]
 constexpr int kWgMaxBlocks = 1024;   // blocks of a wgrid_pass_kernel launch at most: 32 groups of 32
 
 }  // namespace
@@ -128,10 +130,11 @@ struct sc_ctx {
   u64* d_wg_partials = nullptr;   // [kWgMaxBlocks][kGridChunk]
   u64* d_wg_groups = nullptr;     // [kWgMaxBlocks / 32][kGridChunk]
   unsigned* d_wg_tickets = nullptr;
-  u64* d_gram_totals = nullptr;   // gram_finish_kernel: the 256 Gram entries mod p + its ticket (zero at rest); allocated on first use
+  u64* d_gram_rows = nullptr;     // gram_pass_kernel: the blocks' rows of 81 cells + its ticket (zero at rest); allocated on first use
   int fold_dma = 1;       // pass_kernel<4,2>: the LDS-DMA form (kernels/pass.hpp; Goldilocks)
   int pipe32 = 1, pipe32_log = 20, pipe32_blocks = 0;   // pass_kernel<3,2>: the pipelined whole-tile form on tables of >= 2^pipe32_log entries
   int gram_log = 21;              // first pass of an unsharded proof on tables of >= 2^gram_log entries: kernels/gram.hpp (0: never)
+  int host_tail_log = kTailLogMax;   // folded tables of <= 2^this entries go to pinned host memory and the host finishes the proof (0: off)
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
                       // cheaper than the ~25 us of collective latency of each further sharded pass
   // grid cap of the streaming kernels: three 256-thread blocks per CU (set in sc_ctx_create).
@@ -195,9 +198,10 @@ struct sc_ctx {
 
   // multi-device handle (sc_ctx_create_multi, engine/multi.inc).  The handle itself owns no device state: `subs` are ordinary
   // contexts, one per entry of devices[], shard d = rank d of world subs.size() on Transport::kLocal; `mrt` holds one
-  // launcher thread per further device.  In a sub, `parent` points back and h_tail / d_tail are its pinned tail buffers:
-  // kTailSlots slots of [parity][table][kTailEntries] words; a prover of the handle holds one slot (the same index on every
-  // shard, handed out from the handle's tail_free) from creation to destruction
+  // launcher thread per further device.  In a sub, `parent` points back.
+  // h_tail / d_tail (every context): pinned, device-mapped tail buffers, kTailSlots slots of [table][kTailEntries] words; a
+  // prover holds one slot from creation to destruction (on a handle: the same index on every shard, handed out from the
+  // handle's tail_free)
   std::vector<sc_ctx*> subs;
   sc_ctx* parent = nullptr;
   struct MultiRuntime* mrt = nullptr;

@@ -9,12 +9,12 @@ from . import _lib
 def plan_proof(num_vars, world=1, transport="none", **options):
     """list of dicts (action, kf, ks, log_in, sharded), in launch order; options: the sc_ctx_set_option names the
     schedule depends on (vars_per_pass, first_pass_vars, grid_pass, grid_log, grid_max_vars, grid_sharded, tail_log,
-    use_mailbox, gram_log); unknown names raise"""
+    use_mailbox, gram_log, host_tail_log); unknown names raise"""
     lib = _lib.load()
     opt = _lib.ScPlanOptions()
-    lib.sc_plan_options_default(ctypes.byref(opt))
+    lib.sc_plan_options_default(ctypes.byref(opt), ctypes.sizeof(opt))
     for k, v in options.items():
-        if k not in dict(opt._fields_):
+        if k == "struct_size" or k not in dict(opt._fields_):
             raise KeyError("not a schedule option: %s" % k)
         setattr(opt, k, int(v))
     cap = 128
