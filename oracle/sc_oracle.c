@@ -101,7 +101,9 @@ static inline u64 splitmix64(u64 x) {
 }
 /* out[i] = Montgomery form of (splitmix64(seed + start + i) mod p) */
 void sco_generate(const sco_field* f, u64 seed, u64 start, size_t len, u64* out) {
-  for (size_t i = 0; i < len; ++i) out[i] = sco_to_mont(f, splitmix64(seed + start + i));
+  long i;   /* (entries are independent: large tables are filled by all cores - the n = 28 parity tests build 2 x 2 GiB) */
+#pragma omp parallel for schedule(static) if (len >= ((size_t)1 << 20))
+  for (i = 0; i < (long)len; ++i) out[i] = sco_to_mont(f, splitmix64(seed + start + (u64)i));
 }
 u64 sco_challenge(const sco_field* f, u64 seed, u64 j) {
   return sco_to_mont(f, splitmix64(seed + j));
