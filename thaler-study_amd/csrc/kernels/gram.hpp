@@ -364,27 +364,29 @@ gram_pass_kernel(F f, const unsigned char* __restrict__ A, const unsigned char* 
     }
     __syncthreads();
     if (!last_flag) return;
-    // thread = (slice of the blocks, cell): a wave's load reads one contiguous run of a row; sixteen loads of a thread in flight
+    // thread = (slice of the blocks, cell): a wave's load reads one contiguous run of a row.  EVERY load of a thread is in flight
+    // at once (64 at 256 blocks): the rows were written by other XCDs and come from memory, ~1.5 us a round trip - with batches
+    // of sixteen the last block spent four of them here (the fused pass measured 7 us over the loop alone, r05 first run)
     constexpr int kSlices = kGramThreads / kGramRowWords;   // 4
+    constexpr int kU = 64;
     u64* const fin = Mb;                                    // [kSlices][kGramRowWords]
     {
       const int slice = tid / kGramRowWords, c = tid % kGramRowWords;
       u64 part = 0;
       if (c < cells) {
         const int n_blocks = gridDim.x;
-        for (int b0 = slice; b0 < n_blocks; b0 += kSlices * 16) {
-          u64 x[16];
+        for (int b0 = slice; b0 < n_blocks; b0 += kSlices * kU) {
+          u64 x[kU];
 #pragma unroll
-          for (int u = 0; u < 16; ++u) {
+          for (int u = 0; u < kU; ++u) {
             const int b = b0 + u * kSlices;
             x[u] = (b < n_blocks) ? __hip_atomic_load(rows + (size_t)b * kGramRowWords + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
           }
 #pragma unroll
-          for (int u = 0; u < 8; ++u) x[u] = f.add(x[u], x[u + 8]);
+          for (int w = kU / 2; w >= 1; w >>= 1)
 #pragma unroll
-          for (int u = 0; u < 4; ++u) x[u] = f.add(x[u], x[u + 4]);
-#pragma unroll
-          for (int u = 0; u < 4; ++u) part = f.add(part, x[u]);
+            for (int u = 0; u < w; ++u) x[u] = f.add(x[u], x[u + w]);
+          part = f.add(part, x[0]);
         }
       }
       fin[slice * kGramRowWords + c] = part;

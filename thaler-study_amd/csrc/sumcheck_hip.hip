@@ -146,6 +146,10 @@ struct sc_ctx {
   // 0 = not asked yet)
   int resident_blocks[2][5][4] = {};
   int time_kernels = 0;
+  // where a proof's wall time goes on the HOST side (always on: four clock reads per pass): ns spent spinning on the mailbox (the
+  // kernels + their launch latency) and ns spent inside the pass launches (buffers, weights, hipLaunchKernelGGL); the rest of a
+  // proof's wall time is the host's arithmetic between them.  Options "stat_wait_ns" / "stat_launch_ns" (get), "stat_reset" (set)
+  uint64_t stat_wait_ns = 0, stat_launch_ns = 0;
   int nt_load_log = 22;   // tables of >= 2^this entries are loaded nontemporal (measured: 21-25 equal, 27 and off worse)
   int nt_store_log = 25;  // outputs of >= 2^this entries are stored nontemporal
 
