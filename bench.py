@@ -472,7 +472,11 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
             same = r["transcript"] == runs[0]["transcript"]
             if not same:
                 raise SystemExit("PARITY FAILURE: the %s and %s data planes produced different transcripts" % (runs[0]["plane"], plane))
-            if r["elapsed"] < runs[0]["elapsed"]:
+            # the headline is the fastest plane - never one whose collectives were served by a stand-in for librccl
+            # (SC_RCCL_LIBRARY: tests/rccl_double on one-GPU boxes): that plane is timed and reported, not ranked
+            def stand_in(pl):
+                return pl == "rccl" and bool(os.environ.get("SC_RCCL_LIBRARY"))
+            if (r["elapsed"] < runs[0]["elapsed"] and not stand_in(plane)) or (stand_in(runs[0]["plane"]) and not stand_in(plane)):
                 runs[0], r = r, runs[0]
             r.pop("tables")
             if r["ctx"] is not None:
@@ -492,6 +496,11 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                                "comm_nranks": r["comm_nranks"]} for r in runs}
     for plane, why in failed.items():
         transports[plane] = {"ms_per_step": None, "error": why}
+    if "rccl" in transports:
+        # which library served the collectives of the RCCL plane: librccl, or whatever SC_RCCL_LIBRARY names (on a one-GPU box the
+        # test double of tests/rccl_double - a functional run of the N > 1 control flow, not a measurement of RCCL)
+        lib = os.environ.get("SC_RCCL_LIBRARY")
+        transports["rccl"]["library"] = ("SC_RCCL_LIBRARY=" + lib + (" (test double: not RCCL, never the headline)" if "double" in os.path.basename(lib) else "")) if lib else "librccl"
 
     muladds = 5 * 2**n - 7
     alg_bytes = 64 * 2**n - 96

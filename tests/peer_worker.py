@@ -1,5 +1,8 @@
-"""One rank of the multi-process peer-transport tests (launched by torch.distributed.run; every rank on GPU 0).
-SC_PEER_WORKER_MODE = parity | faults | widened.  Not collected by pytest.
+"""One rank of the multi-process transport tests (launched by torch.distributed.run; every rank on GPU 0).
+SC_PEER_WORKER_MODE = parity | faults | widened | rccl_death.  Not collected by pytest.
+SC_WORKER_TRANSPORT = peer (default: the in-kernel exchange over HIP IPC) | rccl (Transport::kRccl: ncclAllReduce behind every
+sharded pass, ncclAllGather at the tail - on a one-GPU box through tests/rccl_double, selected by SC_RCCL_LIBRARY, because
+RCCL itself refuses two ranks on one device).
 
 The library's bound on an in-kernel wait for a peer (peer_spin_ms, default 2 s) is the skew it tolerates between the
 ranks' launches of the same pass; the ranks of a real run call in lockstep.  Here every rank does seconds of oracle
@@ -18,6 +21,19 @@ sys.path.insert(0, os.path.join(ROOT, "oracle"))
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
+TRANSPORT = os.environ.get("SC_WORKER_TRANSPORT", "peer")
+
+
+def attach(pkg, ctx, rank, world):
+    if TRANSPORT == "rccl":
+        pkg.distributed.attach_rccl(ctx, rank, world)
+        assert ctx.get_option("transport") == 1
+    else:
+        pkg.distributed.attach_peer(ctx, rank, world)          # default peer_spin_ms: the connect's handshake absorbed the start-up lag
+        assert ctx.get_option("transport") == 3
+    assert ctx.rank_world() == (rank, world) and ctx.get_option("comm_nranks") == world
+
+
 def shard_tables(pkg, ctx, pyref, n, rank, world, seeds=None):
     D = pkg.distributed
     sa, sb = seeds or (pyref.SEED_A, pyref.SEED_B)
@@ -33,8 +49,7 @@ def parity(pkg, dist, pyref, Oracle, rank, world):
     for p in (pyref.GOLDILOCKS, 389):
         o = Oracle(p)
         ctx = pkg.Context(pkg.Field(p), device=0)
-        D.attach_peer(ctx, rank, world)          # default peer_spin_ms: the connect's handshake absorbed the start-up lag
-        assert ctx.rank_world() == (rank, world) and ctx.get_option("comm_nranks") == world and ctx.get_option("transport") == 3
+        attach(pkg, ctx, rank, world)
         # grid_sharded 1: the shards go on with five-round passes (cells exchanged inside the kernel) down to one entry;
         # 0: two-round passes with the exchange, gather at tail_log, unsharded tail
         for n, tail_log, gs in [(1, 0, 1), (2, 0, 1), (5, 0, 1), (12, 0, 1), (12, 5, 0), (12, 0, 0), (16, 12, 1), (16, 12, 0), (20, 16, 1),
@@ -52,7 +67,7 @@ def parity(pkg, dist, pyref, Oracle, rank, world):
             c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
             log = ctx.launch_log(reset=True)
             ctx.set_option("time_kernels", 0)
-            if gs and nl >= 6:      # the shard's own variables are served five at a time, then one small launch for the rank bits
+            if gs and nl >= 6 and TRANSPORT == "peer":      # the shard's own variables are served five at a time, then one small launch for the rank bits
                 assert [r["kind"] for r in log].count("grid_pass") >= 2 and log[-1]["log_in"] <= 5 + world.bit_length() - 1, log
             final = g.evaluate([int(x) for x in ch])
             hs = g.hypercube_sum()
@@ -74,15 +89,16 @@ def parity(pkg, dist, pyref, Oracle, rank, world):
         ctx.set_option("tail_log", 0)
         ctx.set_option("grid_sharded", 1)
         dist.barrier()
-        try:
-            pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R + (7 if rank == 1 else 0))
-            raise AssertionError("different challenges were accepted")
-        except pkg.SumcheckHipError as e:
-            assert e.code == 5 and "different challenges" in str(e), e
+        if TRANSPORT == "peer":      # (the digest travels in the in-kernel exchange: the peer plane's check)
+            try:
+                pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R + (7 if rank == 1 else 0))
+                raise AssertionError("different challenges were accepted")
+            except pkg.SumcheckHipError as e:
+                assert e.code == 5 and "different challenges" in str(e), e
         dist.barrier()
         del a, b, g
         ctx.close()
-    print("PEER-OK rank %d" % rank, flush=True)
+    print("%s-OK rank %d" % (TRANSPORT.upper(), rank), flush=True)
 
 
 def widened(pkg, dist, pyref, Oracle, rank, world):
@@ -98,8 +114,9 @@ def widened(pkg, dist, pyref, Oracle, rank, world):
     F = pkg.Field(p)
     g_ = world.bit_length() - 1
     ctx = pkg.Context(F, device=0)
-    ctx.set_option("arena_log", 8)
-    D.attach_peer(ctx, rank, world)
+    if TRANSPORT == "peer":
+        ctx.set_option("arena_log", 8)
+    attach(pkg, ctx, rank, world)
     # ---- sharded G::new at n = 8 (2^16-entry matrices; the f_a all-reduce moves 2 x 2^8 limbs) + the proof on it
     n = 8
     pt = np.array([o.challenge(pyref.SEED_PT, j) for j in range(2 * n)], dtype=np.uint64)
@@ -282,6 +299,46 @@ def faults(pkg, dist, pyref, Oracle, rank, world):
     print("FAULTS-OK rank %d" % rank, flush=True)
 
 
+def rccl_death(pkg, dist, pyref, Oracle, rank, world):
+    """a rank that dies: the last rank leaves the job between two proofs (os._exit: no destructor, no goodbye); the collective of
+    every surviving rank must FAIL - SC_ERR_RCCL within the double's bound (SC_RCCL_DOUBLE_TIMEOUT_MS), a poisoned-or-refusing
+    context afterwards - and never hang or return a transcript"""
+    p = pyref.GOLDILOCKS
+    o = Oracle(p)
+    ctx = pkg.Context(pkg.Field(p), device=0)
+    attach(pkg, ctx, rank, world)
+    n = 14
+    a, b, _ = shard_tables(pkg, ctx, pyref, n, rank, world)
+    g = pkg.matrix_multiplication.G(a, b)
+    dist.barrier()
+    c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)       # everyone is alive: the oracle's transcript
+    ref = o.prove(o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n), ch)
+    assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+    dist.barrier()
+    if rank == world - 1:
+        print("RCCL-DEATH rank %d leaves" % rank, flush=True)
+        sys.stdout.flush()
+        os._exit(0)
+    t0 = time.perf_counter()
+    try:
+        pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+        raise AssertionError("a proof finished although a rank is dead")
+    except pkg.SumcheckHipError as e:
+        assert e.code == 3, e                                                   # SC_ERR_RCCL
+    took = time.perf_counter() - t0
+    assert took < 15.0, took                                                    # bounded (the bound was set to 1.5 s), not a hang
+    try:                                                                        # and every later collective fails at once
+        t0 = time.perf_counter()
+        pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+        raise AssertionError("a proof finished although a rank is dead")
+    except pkg.SumcheckHipError as e:
+        assert e.code in (3, 5), e
+        assert time.perf_counter() - t0 < 5.0
+    print("RCCL-DEATH-OK rank %d" % rank, flush=True)
+    sys.stdout.flush()
+    os._exit(0)      # (no control-plane barrier: a rank is gone)
+
+
 def main():
     import torch
     import torch.distributed as dist
@@ -293,7 +350,7 @@ def main():
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     pkg = ge.load_package()
     mode = os.environ.get("SC_PEER_WORKER_MODE", "parity")
-    {"parity": parity, "faults": faults, "widened": widened}[mode](pkg, dist, pyref, Oracle, rank, world)
+    {"parity": parity, "faults": faults, "widened": widened, "rccl_death": rccl_death}[mode](pkg, dist, pyref, Oracle, rank, world)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -60,11 +60,21 @@ std::string g_create_error;
 
 bool load_rccl(std::string* why) {
   if (g_rccl.handle) return true;
+  // SC_RCCL_LIBRARY: the RCCL build to use (a path; e.g. a site's own build) - that one or nothing, never a silent second choice
+  const char* chosen = getenv("SC_RCCL_LIBRARY");
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
   void* h = nullptr;
-  for (const char* n : names) {
-    h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
-    if (h) break;
+  if (chosen && *chosen) {
+    h = dlopen(chosen, RTLD_NOW | RTLD_LOCAL);
+    if (!h) {
+      *why = std::string("dlopen(SC_RCCL_LIBRARY=") + chosen + ") failed: " + dlerror();
+      return false;
+    }
+  } else {
+    for (const char* n : names) {
+      h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (h) break;
+    }
   }
   if (!h) {
     *why = std::string("dlopen(librccl) failed: ") + dlerror();
