@@ -429,3 +429,205 @@ def test_multi_handle_from_a_compiled_caller(n, n_dev):
     out = subprocess.run([exe, str(n), str(n_dev)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "ALL OK" in out.stdout and out.stdout.count("verifier accepts") == 2, out.stdout
+
+
+def test_multi_cross_device_handoffs_are_ordered():
+    """the cross-device copies of a handle (the triangle prover's gather of the adjacency table and its rows of the
+    square, G::new's block exchange) read parts another device's stream may still be writing and write into recycled pool blocks
+    of another context.  sc_table_fix_variables returns unsynchronised by design: its output goes STRAIGHT into a prover create,
+    many times over, with other work recycling the pools in between - every transcript must be the oracle's"""
+    import random
+    pkg = load_package()
+    p = GOLD
+    o = oracle(p)
+    n_dev = 4
+    ctx = multi_ctx(pkg, p, n_dev)
+    F = ctx.field
+    gen = random.Random(99)
+    k = 6                                  # 64 "vertices": adjacency tables of 2^12 entries (field-valued: the generic square)
+    for rep in range(12):
+        extra = 1 + rep % 3                # fold away 1..3 variables of a larger table first
+        big = o.generate(1000 + rep, 2 * k + extra)
+        r = [F.from_int(gen.randrange(p)) for _ in range(extra)]
+        want_adj = o.fix_variables(big, r)
+        t_big = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2 * k + extra, big)
+        adj = t_big.fix_variables(r)       # launched, not waited for ...
+        G = pkg.triangle_counting.G(adj, adj, adj, k)
+        eng = G.native_prover()            # ... and gathered to every device at once
+        ch = [F.from_int(gen.randrange(p)) for _ in range(3 * k)]
+        ref = o.tri_prove(want_adj, k, ch)
+        assert eng.c1() == ref["c_1"], rep
+        for j in range(3 * k):
+            assert eng.round_evals(ch[j - 1] if j else F.one, j) == [int(x) for x in ref["evals"][j]], (rep, j)
+        del eng, G
+        # G::new on freshly folded matrices (the block exchange writes into the other devices' pool blocks)
+        n = 5
+        A = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2 * n + 1, o.generate(2000 + rep, 2 * n + 1)).fix_variables(r[:1])
+        B = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2 * n + 1, o.generate(3000 + rep, 2 * n + 1)).fix_variables(r[:1])
+        pt = [F.from_int(gen.randrange(p)) for _ in range(2 * n)]
+        g2 = pkg.matrix_multiplication.G.new_from_tables(ctx, n, A, B, pt)
+        fa, fb = o.g_new(n, o.fix_variables(o.generate(2000 + rep, 2 * n + 1), r[:1]), o.fix_variables(o.generate(3000 + rep, 2 * n + 1), r[:1]),
+                         np.array(pt, dtype=np.uint64))
+        assert np.array_equal(g2.f_a.to_evaluations(), fa) and np.array_equal(g2.f_b.to_evaluations(), fb), rep
+        del g2, A, B, adj, t_big
+    ctx.close()
+
+
+# ---- round 5: the handle's gaps closed (VERDICT r04 missing 4 / next 5) - tables with fewer entries than devices, fix_variables
+# across the device bits, relabel, and the callers' GENERIC trait path (plain fix_variables -> to_univariate, no native engine)
+
+@pytest.mark.parametrize("n_dev", [2, 8])
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+def test_multi_tables_across_the_device_bits(p, n_dev):
+    """upload / generate / clone / download / evaluate (LE, BE) / evaluate_many of tables from ONE entry up; fix_variables of every
+    k (LE and BE: through and beyond the shards, down to the constant), relabel, the product calls on shards of one entry - oracle"""
+    pkg = load_package()
+    o = oracle(p)
+    ctx = multi_ctx(pkg, p, n_dev)
+    F = ctx.field
+    for n in (0, 1, 2, 3, 4, 6, 9):
+        ev = o.generate(50 + n, n)
+        t = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, ev)
+        assert np.array_equal(t.to_evaluations(), ev) and np.array_equal(t.clone().to_evaluations(), ev)
+        gen = pkg.DenseMultilinearExtension.generate(ctx, 50 + n, n)
+        assert np.array_equal(gen.to_evaluations(), ev)
+        pt = [o.challenge(pyref.SEED_PT, j) for j in range(n)]
+        if n == 0:
+            assert t.evaluate([]) == int(ev[0])
+            continue
+        assert t.evaluate(pt) == o.evaluate(ev, pt) and t.evaluate(pt, order=pkg.ORDER_BE) == o.vsbw(ev, pt)
+        for k in range(n + 1):
+            for order in (pkg.ORDER_LE, pkg.ORDER_BE):
+                got = t.fix_variables(pt[:k], order=order).to_evaluations()
+                assert np.array_equal(got, o.fix_variables(ev, pt[:k], order=order)), (n, k, order)
+        if n >= 2:
+            h = n // 2
+            assert np.array_equal(t.relabel(0, h, h).to_evaluations(), o.relabel(ev, 0, h, h)), n
+        if n >= 1:
+            ev2 = o.generate(90 + n, n)
+            t2 = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, n, ev2)
+            g2 = pkg.matrix_multiplication.G(t, t2)
+            assert g2.round_evals() == [int(x) for x in o.round_evals(ev, ev2)], n
+            assert g2.hypercube_sum() == o.c1(ev, ev2)
+            assert np.array_equal(g2.to_evaluations(), o.to_evaluations(ev, ev2))
+    ctx.close()
+
+
+@pytest.mark.parametrize("n_dev", [2, 8])
+def test_multi_generic_prover_loop_matmul_g(n_dev):
+    """the reference's generic Prover over matrix_multiplication::G on a handle with the native engine switched off:
+    Prover::new -> to_evaluations().sum(), every round fix_variables(&[r]) -> to_univariate (sum-check-protocol/src/lib.rs:88-112)
+    - down through the device bits to the last variable; G::new on matrices smaller than the device count"""
+    pkg = load_package()
+    scp = pkg.sum_check_protocol
+    p = GOLD
+    o = oracle(p)
+    ctx = multi_ctx(pkg, p, n_dev)
+    for n in (1, 2, 3, 5, 8):
+        oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+        ch = challenges(o, n)
+        ref = o.prove(oa, ob, ch)
+        a, b = tables(pkg, ctx, n)
+        g = pkg.matrix_multiplication.G(a, b)
+        g.native_prover = lambda: None
+        prover = scp.Prover.new(g)
+        assert prover.c_1() == ref["c_1"]
+        r_j = ctx.field.one
+        for j in range(n):
+            g_j = prover.round(r_j, j)
+            dense = [0, 0, 0]
+            for d, cf in g_j.coeffs:
+                dense[d] = cf
+            assert dense == [int(x) for x in o.interpolate(ref["evals"][j])], (n, j)
+            r_j = int(ch[j])
+    # G::new with fewer columns than devices (1x1 .. 4x4 matrices)
+    F = ctx.field
+    for n in (1, 2):
+        A, B = o.generate(7, 2 * n), o.generate(8, 2 * n)
+        pt = [o.challenge(pyref.SEED_PT, j) for j in range(2 * n)]
+        fa, fb = o.g_new(n, A, B, np.array(pt, dtype=np.uint64))
+        At = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2 * n, A)
+        Bt = pkg.DenseMultilinearExtension.from_evaluations_vec(ctx, 2 * n, B)
+        g = pkg.matrix_multiplication.G.new_from_tables(ctx, n, At, Bt, pt)
+        assert np.array_equal(g.f_a.to_evaluations(), fa) and np.array_equal(g.f_b.to_evaluations(), fb), n
+    ctx.close()
+
+
+@pytest.mark.parametrize("n_dev", [2, 8])
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+def test_multi_generic_trait_path_w(p, n_dev):
+    """gkr_protocol::round_polynomial::W on a handle WITHOUT its native engine: to_evaluations, hypercube_sum, and the
+    reference's fallback loop fix_variables(&[r]) -> to_univariate for every round (gkr-protocol/src/round_polynomial.rs:59-90),
+    plus evaluate on every partially fixed state - against the oracle's W prover"""
+    import random
+    from test_gpu_gkr import make_circuit, random_circuit
+    pkg = load_package()
+    gp = pkg.gkr_protocol
+    o = oracle(p)
+    ctx = multi_ctx(pkg, p, n_dev)
+    F = ctx.field
+    g_ = n_dev.bit_length() - 1
+    rng = random.Random(31 + n_dev)
+    for ks in ([3, max(g_, 2)], [2, g_ + 2], [4, 5]):
+        layers = random_circuit(rng, ks)
+        circuit = make_circuit(pkg, layers, 1 << ks[-1])
+        inputs = [F.from_int(rng.randrange(p)) for _ in range(1 << ks[-1])]
+        evaluation = circuit.evaluate(F, inputs)
+        k_i, k_next = ks
+        r_i = [F.from_int(rng.randrange(p)) for _ in range(k_i)]
+        oadd, omul = o.wiring_fixed(layers[0], k_next, r_i)
+        ow = np.array(evaluation[1], dtype=np.uint64)
+        ch = [F.from_int(rng.randrange(p)) for _ in range(2 * k_next)]
+        ref = o.w_prove(oadd, omul, ow, ow, ch)
+        assert ref["status"] == 0
+        w = gp.start_round_w(ctx, circuit, evaluation, 0, r_i)
+        assert np.array_equal(w.to_evaluations(), o.w_to_evaluations(oadd, omul, ow, ow)), ks
+        assert w.hypercube_sum(F) == ref["c_1"]
+        cur = w
+        for j in range(2 * k_next):
+            if j:
+                cur = cur.fix_variables([ch[j - 1]])
+            assert cur.num_vars() == 2 * k_next - j
+            assert cur.round_evals() == [int(x) for x in ref["evals"][j]], (ks, j)
+            assert cur.evaluate(ch[j:]) == ref["final_eval"], (ks, j)
+        for kk in (1, k_next, k_next + 1, 2 * k_next):
+            w2 = w.fix_variables(ch[:kk])
+            if kk < 2 * k_next:
+                assert w2.evaluate(ch[kk:]) == ref["final_eval"], (ks, kk)
+    ctx.close()
+
+
+@pytest.mark.parametrize("n_dev", [2, 8])
+@pytest.mark.parametrize("p", [GOLD, 389], ids=pid)
+def test_multi_generic_trait_path_triangle(p, n_dev):
+    """triangle_counting::G on a handle WITHOUT its native engine: the fallback loop of triangle-counting/src/lib.rs:89-132
+    (fix_variables(&[r]) -> to_univariate, every round, down to the constant), to_evaluations, multi-variable fixes across the
+    x / y / z boundaries - against the oracle's triangle prover"""
+    import random
+    from test_gpu_triangle import random_adj
+    pkg = load_package()
+    o = oracle(p)
+    ctx = multi_ctx(pkg, p, n_dev)
+    F = ctx.field
+    gen = random.Random(17 + n_dev)
+    for k in (2, 3, 4):
+        n = 1 << k
+        m = random_adj(gen, n)
+        flat = sum(m, [])
+        g = pkg.triangle_counting.G.new_adj_matrix(ctx, 2 * k, flat)
+        oadj = o.to_mont([1 if b else 0 for b in flat])
+        ch = [F.from_int(gen.randrange(p)) for _ in range(3 * k)]
+        ref = o.tri_prove(oadj, k, ch)
+        assert ref["status"] == 0
+        cur = g
+        assert cur.hypercube_sum(F) == ref["c_1"]
+        if k <= 3:
+            assert np.array_equal(cur.to_evaluations(), o.tri_to_evaluations(oadj, oadj, oadj, k))
+        for j in range(3 * k):
+            if j:
+                cur = cur.fix_variables([ch[j - 1]])
+            assert cur.round_evals() == [int(x) for x in ref["evals"][j]], (k, j)
+        for kk in (1, k, k + 1, 2 * k, 2 * k + 1):
+            g2 = g.fix_variables(ch[:kk])
+            assert g2.evaluate(ch[kk:]) == ref["final_eval"], (k, kk)
+    ctx.close()

@@ -424,6 +424,11 @@ static int multi_table_fix_variables(sc_ctx* m, const sc_table* in, const uint64
 static int multi_table_evaluate(sc_ctx* m, const sc_table* t, const uint64_t* r, size_t n, int order, uint64_t* out);
 static int multi_matmul_g_new(sc_ctx* m, const sc_table* A, const sc_table* B, size_t n, const uint64_t* point, sc_table** a_out,
                               sc_table** b_out);
+static int multi_table_relabel(sc_ctx* m, const sc_table* in, size_t a, size_t b, size_t k, sc_table** out);
+static int multi_gkr_w_to_evaluations(sc_ctx* m, const sc_table* add, const sc_table* mul, const sc_table* w_b, const sc_table* w_c, sc_table** out);
+static int multi_gkr_w_round_sums(sc_ctx* m, const sc_table* add, const sc_table* mul, const sc_table* w_b, const sc_table* w_c, uint64_t out_e[3]);
+static int multi_tri_to_evaluations(sc_ctx* m, const sc_table* f1, const sc_table* f2, const sc_table* f3, size_t var_len, sc_table** out);
+static int multi_tri_round_sums(sc_ctx* m, const sc_table* f1, const sc_table* f2, const sc_table* f3, size_t var_len, uint64_t out_e[3]);
 static int multi_prod2_to_evaluations(sc_ctx* m, const sc_table* a, const sc_table* b, sc_table** out);
 static int multi_prod2_round_sums(sc_ctx* m, const sc_table* a, const sc_table* b, uint64_t out_e[3]);
 static int multi_prod2_sum(sc_ctx* m, const sc_table* a, const sc_table* b, uint64_t* out_c1);
