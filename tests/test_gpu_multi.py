@@ -174,9 +174,9 @@ def test_multi_table_calls_match_oracle(p, n_dev):
                 dense[d] = c
             assert dense == want_c
         if n - g >= 1 and n_dev > 1:
-            with pytest.raises(pkg.SumcheckHipError) as ei:
-                a.fix_variables(pt[:n - g + 1])       # would cross the device shards
-            assert ei.value.code == 6
+            # across the device shards: through the first device since round 5 (SC_ERR_UNSUPPORTED before)
+            for k in sorted({n - g + 1, n - 1, n}):
+                assert np.array_equal(a.fix_variables(pt[:k]).to_evaluations(), o.fix_variables(ta, pt[:k])), (n, k)
     ctx.close()
 
 
@@ -216,15 +216,14 @@ def test_multi_argument_checks_and_unsupported_calls():
     one = pkg.Context(F)
     a, b = tables(pkg, ctx, 10)
     t1 = pkg.DenseMultilinearExtension.generate(one, pyref.SEED_A, 10)
-    with pytest.raises(pkg.SumcheckHipError) as ei:
-        pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, 1)      # fewer entries than devices
-    assert ei.value.code == 1
+    small = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, 1)      # fewer entries than devices: lives on the first one
+    assert np.array_equal(small.to_evaluations(), oracle(GOLD).generate(pyref.SEED_A, 1))
     # tables do not cross between a handle and a one-device context
     with pytest.raises(pkg.SumcheckHipError):
         pkg.matrix_multiplication.prove(one, pkg.matrix_multiplication.G(a, b), pyref.SEED_R)
     with pytest.raises(pkg.SumcheckHipError):
         pkg.matrix_multiplication.prove(ctx, pkg.matrix_multiplication.G(t1, t1), pyref.SEED_R)
-    for call in (lambda: a.relabel(0, 5, 5), lambda: ctx.comm_peer_export(0, 1), lambda: ctx.set_option("use_mailbox", 0),
+    for call in (lambda: ctx.comm_peer_export(0, 1), lambda: ctx.set_option("use_mailbox", 0),
                  lambda: ctx.set_option("peer_spin_ms", 5)):
         with pytest.raises(pkg.SumcheckHipError) as ei:
             call()
