@@ -52,8 +52,6 @@ struct WgOut {
   u64 seq;
   u64* limbs_dev;    // non-null: leave the cells as 2 x 3^KS split limbs here (device memory) and publish nothing
   PeerX px;          // world > 0: a sharded pass - the cells are exchanged with the peers before they are published
-  int agent_out = 0; // the folded tables are read by a pre-launched pass (kernels/pass.hpp, "Pre-launched passes"): write-through at agent scope
-  GoIn go;           // seq != 0: THIS launch is a pre-launched one (the PRE instantiations): it waits for its fold weights
   int host_out = 0;  // the folded tables go to pinned HOST memory and the host reads them as soon as it has seen this launch's
                      // sequence word (option "host_tail_log"): they are stored write-through at system scope.  A plain store sits
                      // in the L2 of the storing block's XCD until that L2 is written back - the release of the block that
@@ -62,7 +60,7 @@ struct WgOut {
 };
 // folded entry i of one table: sum_c w[c] * in[2^KF i + c], stored to the folded table
 template <class F, int KF>
-__device__ __forceinline__ u64 grid_fold1(const F& f, const u64* __restrict__ T, u64* __restrict__ T2, const GridW& gw, size_t i, int out_scope = 0) {
+__device__ __forceinline__ u64 grid_fold1(const F& f, const u64* __restrict__ T, u64* __restrict__ T2, const GridW& gw, size_t i, bool sys_out = false) {
   constexpr int FAN = 1 << KF, NPIECE = FAN / 2;
   const ull2* __restrict__ pt = reinterpret_cast<const ull2*>(T + i * FAN);
   ull2 x[NPIECE];
@@ -76,8 +74,7 @@ __device__ __forceinline__ u64 grid_fold1(const F& f, const u64* __restrict__ T,
     f.acc3_mac(s, x[m].y, gw.w[2 * m + 1]);
   }
   const u64 v = f.acc3_get(s);
-  if (out_scope == 2) __hip_atomic_store(T2 + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // the host reads it
-  else if (out_scope == 1) __hip_atomic_store(T2 + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a pre-launched pass reads it
+  if (sys_out) __hip_atomic_store(T2 + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   else T2[i] = v;
   return v;
 }
@@ -95,7 +92,7 @@ fold_wide_kernel(F f, const u64* __restrict__ T, u64* __restrict__ T2, GridW gw,
 // the block's sums: thread c < 3^KS returns cell c
 template <class F, int KS, bool PF>
 __device__ __forceinline__ u64 wgrid_body(const F& f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2,
-                                          u64* __restrict__ B2, const GridW& gw, int kf, size_t n_out, int out_scope) {
+                                          u64* __restrict__ B2, const GridW& gw, int kf, size_t n_out, bool sys_out) {
   constexpr int kWaves = kBlock / kWave;
   constexpr int kPow3[6] = {1, 3, 9, 27, 81, 243};
   constexpr int cells = kPow3[KS], G = 1 << KS, gpi = kWgEntries >> KS, pairs = gpi * cells;
@@ -187,8 +184,7 @@ __device__ __forceinline__ u64 wgrid_body(const F& f, const u64* __restrict__ A,
             f.acc3_mac(s, x1.x, gw.w[2]);
             f.acc3_mac(s, x1.y, gw.w[3]);
             v = f.acc3_get(s);
-            if (out_scope == 2) __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            else if (out_scope == 1) __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sys_out) __hip_atomic_store(dst + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             else dst[i] = v;
           }
         }
@@ -225,11 +221,11 @@ __device__ __forceinline__ u64 wgrid_body(const F& f, const u64* __restrict__ A,
       if (i < n_out) {
         switch (kf) {   // compile-time fan-in: all loads of an entry are in flight together
           case 0: v = src[i]; break;
-          case 1: v = grid_fold1<F, 1>(f, src, dst, gw, i, out_scope); break;
-          case 2: v = grid_fold1<F, 2>(f, src, dst, gw, i, out_scope); break;
-          case 3: v = grid_fold1<F, 3>(f, src, dst, gw, i, out_scope); break;
-          case 4: v = grid_fold1<F, 4>(f, src, dst, gw, i, out_scope); break;
-          default: v = grid_fold1<F, 5>(f, src, dst, gw, i, out_scope); break;
+          case 1: v = grid_fold1<F, 1>(f, src, dst, gw, i, sys_out); break;
+          case 2: v = grid_fold1<F, 2>(f, src, dst, gw, i, sys_out); break;
+          case 3: v = grid_fold1<F, 3>(f, src, dst, gw, i, sys_out); break;
+          case 4: v = grid_fold1<F, 4>(f, src, dst, gw, i, sys_out); break;
+          default: v = grid_fold1<F, 5>(f, src, dst, gw, i, sys_out); break;
         }
       }
       ef[slot] = v;
@@ -377,8 +373,7 @@ __device__ __forceinline__ void publish_cells(const WgOut& out, u64 total) {
   if (tid == 0) __hip_atomic_store(out.mailbox + kMailboxSeq, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// PRE: the pre-launched form (kernels/pass.hpp): the launch is made before its fold weights exist; it waits for them (await_go)
-template <class F, int KS, bool PF, bool PRE = false>
+template <class F, int KS, bool PF>
 __global__ void __launch_bounds__(kBlock)
 wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
                   GridW gw, int kf, size_t n_out, WgOut out) {
@@ -386,15 +381,7 @@ wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
   constexpr int cells = kPow3[KS];
   __shared__ int lds_flag;
   const int tid = threadIdx.x;
-  const int out_scope = out.host_out ? 2 : out.agent_out ? 1 : 0;
-  u64 total;
-  if constexpr (PRE) {
-    GridW gwl;
-    if (!await_go<(1 << kGridMaxVars)>(out.go, gwl.w)) return;
-    total = wgrid_body<F, KS, PF>(f, A, B, A2, B2, gwl, kf, n_out, out_scope);
-  } else {
-    total = wgrid_body<F, KS, PF>(f, A, B, A2, B2, gw, kf, n_out, out_scope);
-  }
+  u64 total = wgrid_body<F, KS, PF>(f, A, B, A2, B2, gw, kf, n_out, out.host_out != 0);
   if (gridDim.x > 1) {
     // level 1: the blocks of a group of 32
     const int n_blocks = gridDim.x, group = blockIdx.x / kWgGroupBlocks, n_groups = (n_blocks + kWgGroupBlocks - 1) / kWgGroupBlocks;

@@ -65,114 +65,7 @@ struct PassOut {
   u64* mailbox;
   u64 seq;
   PeerX px;
-  int agent_out = 0;   // the folded tables are read by a kernel that is ALREADY RESIDENT when this launch ends (a pre-launched pass,
-                       // below): they are stored write-through (sc1) and every storing wave drains before the block's ticket
 };
-
-// ------------------------------------------------------------------------------------
-// Pre-launched passes (round 5).
-//
-// Between the sums of pass k reaching the host and the first instruction of pass k + 1 lie the host's arithmetic (~2 us), a
-// hipLaunchKernelGGL (~3 us) and the dispatch (~2-3 us): ~7 us per pass, five to six times per proof - a tenth of a proof on a
-// 2^25-entry shard.  Inside sc_prove (where the library owns the loop) pass k + 1 is therefore launched BEFORE the host waits for
-// pass k, on a second stream: everything about it but its fold weights is known from the plan.  Its workgroups become
-// resident as pass k's leave, and wait: block 0 polls pinned host memory for the weights - 16-byte pairs {value, sequence
-// number}, one per lane, so the data is the flag and one PCIe read delivers both - hands them to the other blocks through
-// device memory and everyone starts ~2 us after the host's store (tools/waitvalue.hip: 1.6 us for the round trip against 5.8 us
-// for a launch).  What pass k must do for it: store its outputs write-through and drain them before its ticket (the consumer
-// is resident before this kernel ends, so the end-of-kernel write-back comes too late: PassOut::agent_out / WgOut::agent_out);
-// the consumer issues ONE agent-scope acquire after the go and reads with plain loads (cdna_hip_programming.md Guideline 16).
-// Bounded: block 0 gives up after GoIn::spin_ticks (the host then finds the kernel gone and launches the pass the ordinary
-// way), a cancel word ends it at once (a proof that is abandoned), and the other blocks follow block 0's verdict.
-struct GoIn {
-  const u64* host = nullptr;   // pinned host memory (device-mapped): pairs {value, seq}; pair c < 32 = fold weight c, pair 32 = control
-  u64* dev = nullptr;          // device memory: [0] = seq (| kGoDead) once block 0 has the host's word; [8 .. 8 + 32) the weights
-  u64 seq = 0;                 // this launch's sequence number (the mailbox sequence it will publish); 0: an ordinary launch
-  u64 spin_ticks = 0;          // how long block 0 waits for the host (wall_clock64: 100 MHz)
-};
-constexpr u64 kGoDead = 1ull << 63;
-constexpr int kGoCtl = 32;           // index of the control pair: value 1 = go, 2 = cancel
-constexpr int kGoDevWeights = 8;     // first weight word of GoIn::dev
-
-__device__ __forceinline__ ull2 go_ld16_system(const u64* p) {
-  ull2 v;
-  asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
-  return v;
-}
-__device__ __forceinline__ u64 readlane_u64(u64 v, int lane) {
-  return ((u64)(unsigned)__builtin_amdgcn_readlane((int)(v >> 32), lane) << 32) | (u64)(unsigned)__builtin_amdgcn_readlane((int)v, lane);
-}
-// every thread of the block calls it first thing; false: the launch was cancelled or the host never came (do nothing, exit)
-template <int NW>
-__device__ __forceinline__ bool await_go(const GoIn& go, u64 (&w)[NW]) {
-  static_assert(NW <= kGoCtl, "weights per launch");
-  __shared__ int go_state;   // 0 waiting, 1 go, 2 dead
-  const int tid = threadIdx.x, lane = tid & (kWave - 1);
-  if (tid == 0) go_state = 0;
-  __syncthreads();
-  if (blockIdx.x == 0) {
-    if (tid < NW || tid == kGoCtl) {   // (wave 0)
-      const u64* pair = go.host + 2 * tid;
-      const unsigned long long t0 = wall_clock64();
-      unsigned spins = 0;
-      u64 val = 0;
-      bool have = false;
-      while (true) {
-        const ull2 g = go_ld16_system(pair);
-        if (g.y == go.seq) {
-          val = g.x;
-          have = true;
-          break;
-        }
-        if (*(volatile int*)&go_state == 2) break;
-        if (tid == kGoCtl && (++spins & 15) == 0 && wall_clock64() - t0 > go.spin_ticks) break;
-        __builtin_amdgcn_s_sleep(1);
-      }
-      if (tid == kGoCtl) {
-        if (!(have && val == 1)) *(volatile int*)&go_state = 2;   // cancelled or timed out: the weight lanes stop polling
-      } else if (have) {
-        __hip_atomic_store(go.dev + kGoDevWeights + tid, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the weights have left (write-through) before the flag does
-    __syncthreads();
-    if (tid == 0) {
-      const bool dead = go_state == 2;
-      __hip_atomic_store(go.dev, dead ? (go.seq | kGoDead) : go.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!dead) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // what the pass before wrote: this CU reads it from here on
-        go_state = 1;
-      }
-    }
-  } else if (tid == 0) {
-    const unsigned long long t0 = wall_clock64();
-    unsigned spins = 0;
-    int st = 2;
-    while (true) {
-      const u64 v = __hip_atomic_load(go.dev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((v & ~kGoDead) == go.seq) {
-        st = (v & kGoDead) ? 2 : 1;
-        break;
-      }
-      if ((++spins & 15) == 0 && wall_clock64() - t0 > 4 * go.spin_ticks + 100000000ull) break;   // (block 0 always answers: a safety net)
-      __builtin_amdgcn_s_sleep(2);
-    }
-    if (st == 1) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    go_state = st;
-  }
-  __syncthreads();
-  if (go_state != 1) return false;
-  // the weights: lanes c < NW of every wave fetch word c, the wave broadcasts them into (scalar) registers
-  u64 wv = 0;
-  if (lane < NW) wv = __hip_atomic_load(go.dev + kGoDevWeights + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-  for (int c = 0; c < NW; ++c) w[c] = readlane_u64(wv, c);
-  return true;
-}
-// 16-byte write-through (agent scope) store: the folded tables a pre-launched consumer reads
-__device__ __forceinline__ void st16_agent(ull2* p, ull2 v) {
-  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
-}
 
 __device__ __forceinline__ void publish_value(const PassOut& o, int s, u64 v) {
   if (o.mailbox) {
@@ -489,12 +382,6 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   const ull2* __restrict__ Bp = reinterpret_cast<const ull2*>(B);
   ull2* __restrict__ A2p = reinterpret_cast<ull2*>(A2);
   ull2* __restrict__ B2p = reinterpret_cast<ull2*>(B2);
-  // (a pre-launched consumer reads the folded tables before this kernel has ended: write-through, PassOut::agent_out)
-  const bool agent_out = out.agent_out != 0;
-  auto store_out = [&](ull2* p, ull2 v) {
-    if (agent_out) st16_agent(p, v);
-    else st16<kNtStore>(p, v);
-  };
 
   // inactive lanes carry zeros: they add nothing to the sums and store nothing.  Tables far
   // larger than the 256 MiB Infinity Cache are read once: stream them (nontemporal).
@@ -578,8 +465,8 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
       for (int k = 0; k < NPO; ++k) {
         const size_t q = o0 + (size_t)k * kWave + lane;
         if (q < out_pieces) {
-          store_out(A2p + q, oa[k]);
-          store_out(B2p + q, ob[k]);
+          st16<kNtStore>(A2p + q, oa[k]);
+          st16<kNtStore>(B2p + q, ob[k]);
         }
       }
     }
@@ -741,8 +628,8 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
 #pragma unroll
       for (int k = 0; k < NPO; ++k) {
         const size_t q = o0 + (size_t)k * kWave + lane;
-        store_out(A2p + q, oa[k]);
-        store_out(B2p + q, ob[k]);
+        st16<kNtStore>(A2p + q, oa[k]);
+        st16<kNtStore>(B2p + q, ob[k]);
       }
       accumulate_run<F, KS>(f, acc, a, b);
       bulk_writeback();
@@ -845,8 +732,8 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
 #pragma unroll
       for (int k = 0; k < NPO; ++k) {
         const size_t q = o0 + (size_t)k * kWave + lane;
-        store_out(A2p + q, oa[k]);
-        store_out(B2p + q, ob[k]);
+        st16<kNtStore>(A2p + q, oa[k]);
+        st16<kNtStore>(B2p + q, ob[k]);
       }
       accumulate_run<F, KS>(f, acc, a, b);
       bulk_writeback();
@@ -870,7 +757,6 @@ pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __re
   }
 
   u64 mine;
-  if (agent_out) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every storing wave drains before the block's ticket (finish_pass drains wave 0 only)
   if constexpr (NS >= 9) {
     __syncthreads();   // every wave is done with its transposes
     mine = reduce_cells_lds<F, NS, BS>(f, acc, reinterpret_cast<typename F::Acc*>(lds_t), lds);

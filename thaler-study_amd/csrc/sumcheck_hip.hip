@@ -171,19 +171,6 @@ struct sc_ctx {
   unsigned* d_ticket = nullptr;  // arrival counter of finish_pass (only ever grows)
   bool fold_lds_allowed[4][2] = {};   // fold_kernel<KF, NT>: its dynamic LDS above 64 KiB has been requested
   unsigned ticket_base = 0;
-  // pre-launched passes (kernels/pass.hpp; engine/abi_prover.inc): a second, lower-priority stream, the pinned pairs the host
-  // hands the fold weights over in, the device words block 0 passes them on through
-  hipStream_t stream2 = nullptr;
-  u64* h_go = nullptr;        // pinned, device-mapped: 33 pairs {value, seq}
-  u64* d_go = nullptr;
-  u64* d_goflag = nullptr;    // device: [0] seq | dead, [8..40) weights
-  int prelaunch = 1;          // option "prelaunch": inside sc_prove, launch pass k + 1 before waiting for pass k (0: off)
-  int prelaunch_spin_us = 2000;   // how long such a launch waits for its weights before it gives up (the host then launches again)
-  int ahead = 0;              // passes launched beyond the one whose sums are awaited (0 or 1): collect_* wait for mailbox_seq - ahead
-  int lm_agent_out = 0;       // launch modifiers, set around ONE launch call: its outputs feed a pre-launched pass ...
-  int lm_pre = 0;             // ... it IS the pre-launched pass (stream2, the PRE kernel form, waits for its weights)
-  hipStream_t wait_stream = nullptr;   // the stream the awaited pass runs on (wait_mailbox: has the kernel gone without publishing?)
-  uint64_t stat_prelaunched = 0, stat_pre_fallback = 0;
   u64* h_mailbox = nullptr;   // pinned, device-mapped: sums + sequence word written by the kernel
   u64* d_mailbox = nullptr;   // device alias of h_mailbox
   u64 mailbox_seq = 0;

@@ -7,8 +7,7 @@ pkg = ge.load_package()
 SEED_A, SEED_B, SEED_R = 0xA5A5000000000001, 0xB6B6000000000002, 0xC7C7000000000003
 mm = pkg.matrix_multiplication
 ns = [int(x) for x in sys.argv[1:]] or [25, 28]
-VARIANTS = [("default", {}), ("prelaunch=0", {"prelaunch": 0}), ("host_tail_log=0", {"host_tail_log": 0}),
-            ("prelaunch=0,host_tail=0", {"prelaunch": 0, "host_tail_log": 0}), ("default (again)", {})]
+VARIANTS = [("default", {}), ("host_tail_log=0", {"host_tail_log": 0}), ("host_tail_log=9", {"host_tail_log": 9}), ("default (again)", {})]
 PLAN_KEYS = ("host_tail_log", "grid_max_vars", "grid_log")
 for n in ns:
     ctxs = []
@@ -34,13 +33,12 @@ for n in ns:
                 t0 = time.perf_counter()
                 mm.prove(ctx, g, SEED_R)
                 ts.append(time.perf_counter() - t0)
-            stats[name] = (ctx.get_option("stat_wait_ns") / 15e3, ctx.get_option("stat_launch_ns") / 15e3,
-                           ctx.get_option("stat_prelaunched") / 15.0, ctx.get_option("stat_pre_fallback") / 15.0)
+            stats[name] = (ctx.get_option("stat_wait_ns") / 15e3, ctx.get_option("stat_launch_ns") / 15e3)
     for name, ctx, g, ts in ctxs:
         ts.sort()
         popts = {k: v for k, v in dict(VARIANTS)[name].items() if k in PLAN_KEYS}
-        print("n=%d %-18s median %.1f us  p10 %.1f  min %.1f | per proof: %.1f us waiting for kernels, %.1f us in launches, %.1f launched ahead (%.2f fell back) | %s" % (
-            n, name, ts[len(ts) // 2] * 1e6, ts[len(ts) // 10] * 1e6, ts[0] * 1e6, stats[name][0], stats[name][1], stats[name][2], stats[name][3],
+        print("n=%d %-18s median %.1f us  p10 %.1f  min %.1f | per proof: %.1f us waiting for kernels, %.1f us in launches | %s" % (
+            n, name, ts[len(ts) // 2] * 1e6, ts[len(ts) // 10] * 1e6, ts[0] * 1e6, stats[name][0], stats[name][1],
             " ".join("%s(%d,%d)@%d" % (s["action"], s["kf"], s["ks"], s["log_in"]) for s in pkg.schedule.plan_proof(n, **popts))), flush=True)
     for name, ctx, g, ts in ctxs:
         del g
