@@ -7,7 +7,7 @@ pkg = ge.load_package()
 SEED_A, SEED_B, SEED_R = 0xA5A5000000000001, 0xB6B6000000000002, 0xC7C7000000000003
 mm = pkg.matrix_multiplication
 ns = [int(x) for x in sys.argv[1:]] or [25, 28]
-VARIANTS = [("default", {}), ("host_tail_log=0", {"host_tail_log": 0}), ("host_tail_log=9", {"host_tail_log": 9}), ("default (again)", {})]
+VARIANTS = [("default", {}), ("host_tail_log=0", {"host_tail_log": 0}), ("fold_dma=0", {"fold_dma": 0}), ("default (again)", {})]
 PLAN_KEYS = ("host_tail_log", "grid_max_vars", "grid_log")
 for n in ns:
     ctxs = []
