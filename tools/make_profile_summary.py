@@ -51,7 +51,7 @@ def is_hot(name):
 
 def describe(name):
     """(kind, kf, ks) of a hot kernel from its demangled name"""
-    m = re.search(r"gram_pass_kernel<(\d)(?:, \w+)?>", name)
+    m = re.search(r"gram_pass_kernel<(?:sc::\w+, )?(\d)(?:, \w+)?>", name)
     if m:
         return "gram_pass", 0, int(m.group(1))
     m = re.search(r"gram_finish_kernel<sc::\w+, (\d)>", name)
@@ -72,7 +72,7 @@ def describe(name):
 
 
 if workload == "prover":   # a proof is passes only (the evaluate launches behind it are bench.py's parity gate)
-    HOT = ("pass_kernel<", "wgrid_pass_kernel<", "gram_finish_kernel<")   # ("pass_kernel<" also matches gram_pass_kernel<)
+    HOT = ("pass_kernel<", "wgrid_pass_kernel<")   # ("pass_kernel<" also matches gram_pass_kernel<)
 trace = [r for r in csv.DictReader(open(one(d_stats, "*_kernel_trace.csv"))) if is_hot(r["Kernel_Name"])]
 
 
@@ -94,13 +94,15 @@ def split_steps(rows):
 steps = split_steps(trace)
 # the stats run is `--steps 10 --warmup 2`, the counter runs `--steps 2 --warmup 1`: take the LAST TIMED step
 # (after it bench.py runs its parity checks, which launch the same kernels at other sizes)
-last = steps[11]
+# (prover: bench.py proves once before its warm-up - config.first_proof_ms - so positions shift; the proof that ends the trace is
+# the last timed one either way)
+last = steps[-1] if workload == "prover" else steps[11]
 
 
 def counters(d, cname):
     rows = [r for r in csv.DictReader(open(one(d, "*_counter_collection.csv"))) if r["Counter_Name"] == cname and is_hot(r["Kernel_Name"])]
     st = split_steps(rows)
-    return [float(r["Counter_Value"]) for r in st[2]]
+    return [float(r["Counter_Value"]) for r in (st[-1] if workload == "prover" else st[2])]
 
 
 fetch = counters(d_fetch, "FETCH_SIZE")
