@@ -87,11 +87,19 @@ int sc_ctx_create(const sc_field* f, int device, sc_ctx** out);
  * device's pending challenges, the calling thread serves the remaining rounds.  Results are bit-identical to a one-device context.
  * Also served: sc_gkr_wiring, sc_gkr_prover_* / sc_gkr_prove (the dense W prover: every device streams its rows of c of add_i /
  * mul_i, the small product proofs run on the first device), sc_gkr_w_evaluate, and sc_tri_prover_* / sc_tri_prove /
- * sc_tri_evaluate (every device squares its rows of the adjacency matrix).  Not served (SC_ERR_UNSUPPORTED):
- * sc_table_relabel, sc_table_from_device, the other sc_gkr_w_* and sc_tri_* trait calls (run those on an ordinary context;
- * sc_gkr_prover_create_sparse runs on the handle's first device), fix_variables across the device bits, and the sc_ctx_comm_* calls (the handle is its own communicator;
- * sc_ctx_comm_rank reports rank 0 of 1 - its tables are whole tables; option "n_devices" counts the devices).  sc_table_device_ptr returns NULL; sc_ctx_stream, sc_ctx_kernel_time and
- * sc_ctx_launch_log report the first device (one GPU's launches over its own shard). */
+ * sc_tri_evaluate (every device squares its rows of the adjacency matrix).
+ * Through the handle's FIRST device (round 5: gather, the ordinary call on whole tables, scatter of table results - functional,
+ * not fast; SC_ERR_UNSUPPORTED before): tables with fewer entries than devices (they live on the first device), sc_table_fix_variables
+ * across the device bits (either order), sc_table_relabel, the product calls on one-entry shards, sc_matmul_g_new on matrices with
+ * fewer than two columns per device, and the callers' generic trait calls sc_gkr_w_round_sums / _to_evaluations / _fix_variables
+ * and sc_tri_round_sums / _to_evaluations / _fix_variables - the reference's fallback loop fix_variables(&[r]) -> to_univariate
+ * (gkr-protocol/src/round_polynomial.rs:59-90, triangle-counting/src/lib.rs:89-132) runs on a handle down to the constant.
+ * Not served (SC_ERR_UNSUPPORTED): sc_table_from_device, sc_gkr_prover_create / sc_tri_prover_create on tables with fewer rows than
+ * devices (sc_gkr_prover_create_sparse runs on the handle's first device), and the sc_ctx_comm_* calls (the handle is its own
+ * communicator; sc_ctx_comm_rank reports rank 0 of 1 - its tables are whole tables; option "n_devices" counts the devices).
+ * sc_table_device_ptr returns NULL; sc_ctx_stream, sc_ctx_kernel_time and sc_ctx_launch_log report the first device (one GPU's
+ * launches over its own shard).  A handle is validated on ONE physical device only (devices[] naming device 0 N times: this pool's
+ * boxes have one GPU); its cross-device copies are hipMemcpyPeerAsync and its tail outputs system-scope write-through stores. */
 int sc_ctx_create_multi(const sc_field* f, const int* devices, int n_devices, sc_ctx** out);
 int sc_ctx_destroy(sc_ctx* ctx);
 /* message of the last failing call on ctx (ctx == NULL: last failing sc_ctx_create) */
@@ -149,7 +157,16 @@ const char* sc_last_error(const sc_ctx* ctx);
  *   "dbg_fold_grab"    measurements: tiles per draw of fold_kernel's four-wave launches (0 = the default, 1; 4 = round 3's
  *                      behaviour, profiles/r04_fold_small_grab_ab.txt)
  *   "time_kernels"     HIP-event timing of pass kernels (see sc_ctx_kernel_time)
- *   "nt_load_log" / "nt_store_log"  table log-size from which loads / stores are nontemporal */
+ *   "prewarm"          an ACTION, not a setting: value = num_vars of the proofs to come.  Pays now what the first proof of that size
+ *                      would pay on this context - the library's code object on the device, the resident-grid queries of the plan's
+ *                      kernels, the matrix-core pass's workspace, the pool blocks of every folded table - for callers that prove
+ *                      once (mm_benchmark.rs:88-96 builds g and proves).  On a multi-device handle every device does its shard's
+ *   "stat_reset"       (set) zeroes, and "stat_wait_ns" / "stat_launch_ns" (get) read, where a proof's wall time goes on the host:
+ *                      ns spent waiting for pass kernels (their run time + launch latency) and ns inside the pass launches (buffers,
+ *                      weights, hipLaunchKernelGGL); the rest is host arithmetic between them.  Always on (four clock reads per pass)
+ *   "nt_load_log" / "nt_store_log"  table log-size from which loads / stores are nontemporal
+ * Environment: SC_RCCL_LIBRARY = the RCCL build sc_ctx_comm_init_rccl / sc_comm_unique_id dlopen (a path; default librccl.so.1).
+ * That library or nothing: a path that cannot be loaded is an error, never a silent second choice. */
 int sc_ctx_set_option(sc_ctx* ctx, const char* key, int64_t value);
 /* reads any option back; also read-only: "n_devices" (1, or the devices behind a multi-device handle), "transport" (0 none,
  * 1 RCCL, 2 host callbacks, 3 peer, 4 local = a multi-device handle) and "comm_nranks"
