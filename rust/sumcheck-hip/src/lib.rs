@@ -57,8 +57,16 @@ impl<T: MontConfig<1>> Clone for Context<T> {
     }
 }
 
+/// The library must speak the ABI version these bindings were written against (`SC_ABI_VERSION`: structs that cross the
+/// boundary grow between versions).
+fn check_abi() {
+    let v = unsafe { sys::sc_abi_version() };
+    assert_eq!(v, sys::SC_ABI_VERSION, "libsumcheck_hip speaks ABI version {v}, these bindings {}", sys::SC_ABI_VERSION);
+}
+
 impl<T: MontConfig<1>> Context<T> {
     pub fn new(device: i32) -> Self {
+        check_abi();
         let f = field_of::<T>();
         let mut h = ptr::null_mut();
         let rc = unsafe { sys::sc_ctx_create(&f, device, &mut h) };
@@ -74,6 +82,7 @@ impl<T: MontConfig<1>> Context<T> {
     /// shards are added by the calling thread, so the verifier's `r_j` is drawn once and needs no broadcast
     /// (SURVEY.md section 8e).  Bit-identical to `Context::new`.
     pub fn new_multi(devices: &[i32]) -> Self {
+        check_abi();
         let f = field_of::<T>();
         let mut h = ptr::null_mut();
         let rc = unsafe { sys::sc_ctx_create_multi(&f, devices.as_ptr(), devices.len() as i32, &mut h) };
@@ -82,6 +91,13 @@ impl<T: MontConfig<1>> Context<T> {
             panic!("sc_ctx_create_multi failed ({rc}): {}", msg.to_string_lossy());
         }
         Self { inner: Rc::new(CtxInner(h)), _t: PhantomData }
+    }
+    /// Pay the first-use costs of proofs over `num_vars` variables now (option `prewarm`: the library's code object on the
+    /// device, the resident-grid queries of the plan's kernels, the pool blocks of every folded table) - for a caller that
+    /// proves once, like `matrix-multiplication/benches/mm_benchmark.rs:88-96`.
+    pub fn prewarm(&self, num_vars: usize) {
+        let rc = unsafe { sys::sc_ctx_set_option(self.raw(), b"prewarm\0".as_ptr() as *const _, num_vars as i64) };
+        self.check(rc, "sc_ctx_set_option(prewarm)");
     }
     fn raw(&self) -> *mut sys::sc_ctx {
         self.inner.0

@@ -108,3 +108,28 @@ def test_round_engine_patch_applies_to_the_reference(tmp_path):
     for needle in ("pub trait RoundEngine<F: Field>", "fn hypercube_sum(&self) -> F", "fn native_engine(&self) -> Option<Box<dyn RoundEngine<F>>>",
                    "engine: Option<Box<dyn RoundEngine<F>>>"):
         assert needle in text
+
+
+def test_rccl_library_selection_and_the_test_double():
+    """SC_RCCL_LIBRARY names the RCCL build the product dlopen()s - that file or nothing.  tests/rccl_double (the stand-in that
+    lets the RCCL plane's N > 1 control flow run between processes on one GPU) exports the seven entry points the product
+    resolves, and serves sc_comm_unique_id through the product without a GPU; a path that cannot be loaded is an error that
+    says so, never a silent fall back to librccl."""
+    import subprocess
+    import sys
+    double = os.path.join(ROOT, "tests", "rccl_double", "librccl_double.so")
+    assert os.path.exists(double), "build it: __graft_entry__.build()"
+    syms = subprocess.run(["nm", "-D", "--defined-only", double], capture_output=True, text=True, check=True).stdout
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclCommDestroy", "ncclCommCount", "ncclAllReduce", "ncclAllGather", "ncclGetErrorString"):
+        assert (" T " + name) in syms, name
+    # nothing in the product names the double
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "thaler-study_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".inc", ".hpp", ".h")):
+                assert "rccl_double" not in open(os.path.join(dirpath, f), errors="ignore").read(), os.path.join(dirpath, f)
+    code = ("import sys, ctypes; sys.path.insert(0, %r); import __graft_entry__ as g; pkg = g.load_package(); lib = pkg._lib.load();"
+            "buf = (ctypes.c_uint8 * 128)(); rc = lib.sc_comm_unique_id(buf); print(rc, bytes(buf).split(b'\\0')[0][:16], lib.sc_last_error(None))" % ROOT)
+    ok = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SC_RCCL_LIBRARY=double), timeout=300)
+    assert ok.returncode == 0 and ok.stdout.startswith("0 b'/sc_rccl_double_"), (ok.stdout, ok.stderr[-500:])
+    bad = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, SC_RCCL_LIBRARY="/nonexistent/librccl.so"), timeout=300)
+    assert bad.returncode == 0 and bad.stdout.startswith("3 ") and "SC_RCCL_LIBRARY=/nonexistent/librccl.so" in bad.stdout, (bad.stdout, bad.stderr[-500:])
