@@ -33,7 +33,10 @@ def prove_vs_oracle(pkg, ctx, p, n, ha, hb, tag):
 
 @pytest.mark.parametrize("p", [GOLD, P59, 389, 5, 2**61 - 1], ids=pid)
 @pytest.mark.parametrize("n,opts", [(14, {}), (15, {}), (17, {"max_blocks": 3}), (18, {"grid_log": 10}), (20, {"grid_log": 12}),
-                                    (20, {"max_blocks": 64}), (21, {"grid_log": 9, "max_blocks": 7})])
+                                    (20, {"max_blocks": 64}), (21, {"grid_log": 9, "max_blocks": 7}),
+                                    # several partials per block (an int32 accumulator takes 2^16 rows: normally from n = 29 up): the block
+                                    # reduces each on its own and adds the entries mod p - one block walking two, two blocks walking two each
+                                    (21, {"max_blocks": 1}), (22, {"max_blocks": 2})])
 def test_gram_first_pass_vs_oracle(p, n, opts):
     """first_pass_vars = 4 asks for the matrix-core pass at any size; a small grid_log sends the pass behind it - four pending
     challenges - to pass_kernel<4, 2> instead of wgrid_pass_kernel"""

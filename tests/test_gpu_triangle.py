@@ -231,3 +231,35 @@ def test_matrix_square_paths_vs_oracle(p):
         it = iter(ch)
         c1, evals, _ = pkg.triangle_counting.prove(ctx, g, 0, draw=lambda _u, _j, _e: int(next(it)))     # sc_tri_prove: the same proof in one call
         assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+
+
+@pytest.mark.parametrize("opts", [{}, {"grid_max_vars": 1}, {"vars_per_pass": 1}, {"grid_max_vars": 2, "host_tail_log": 10}, {"host_tail_log": 0},
+                                  {"grid_max_vars": 1, "host_tail_log": 6}], ids=lambda d: ",".join("%s=%d" % kv for kv in d.items()) or "default")
+def test_engine_over_host_finished_phases(opts):
+    """the triangle engine runs three product proofs back to back and takes the partially folded tables of one phase into the
+    next (prover_finish).  With the host finishing small proofs (option host_tail_log, round 5) a phase's sub-prover may have
+    handed its tables to the host - or, with one-round passes, be in host mode - when its phase ends: every round of every
+    phase against the oracle, for schedules that end each phase on the device, in the tail slot and on the host"""
+    pkg = load_package()
+    p = GOLD
+    o = oracle(p)
+    ctx = pkg.Context(pkg.Field(p))
+    for k_, v in opts.items():
+        ctx.set_option(k_, v)
+    F = ctx.field
+    gen = random.Random(23)
+    for k in (2, 3, 5, 6, 7):
+        n = 1 << k
+        m = random_adj(gen, n)
+        flat = sum(m, [])
+        g = pkg.triangle_counting.G.new_adj_matrix(ctx, 2 * k, flat)
+        oadj = o.to_mont([1 if b else 0 for b in flat])
+        ch = [F.from_int(gen.randrange(p)) for _ in range(3 * k)]
+        ref = o.tri_prove(oadj, k, ch)
+        assert ref["status"] == 0
+        eng = g.native_prover()
+        assert eng.c1() == ref["c_1"], (k, opts)
+        for j in range(3 * k):
+            assert eng.round_evals(ch[j - 1] if j else F.one, j) == [int(x) for x in ref["evals"][j]], (k, j, opts)
+        del eng, g
+    ctx.close()

@@ -93,7 +93,7 @@ def one_iteration(rng, nprng, max_n, stats):
         opts = {"vars_per_pass": rng.choice([1, 2]), "first_pass_vars": rng.choice([0, 1, 2, 3, 4, 4]), "grid_pass": rng.randint(0, 1),
                 "grid_log": rng.choice([0, 3, 6, 9, 12, 16, 20]), "grid_max_vars": rng.randint(1, 5), "tail_log": rng.choice([0, 2, 5, 9, 14]),
                 "max_blocks": rng.choice([1, 2, 3, 7, 64, 256, 1024]), "grid_blocks": rng.choice([0, 0, 1, 2, 5, 64]),
-                "gram_log": rng.choice([0, 14, 15, 17, 28])}
+                "gram_log": rng.choice([0, 14, 15, 17, 28]), "host_tail_log": rng.choice([0, 0, 2, 5, 8, 10, 10])}
         if not n_dev and rng.random() < 0.2:
             opts["use_mailbox"] = 0
         for k, v in opts.items():
