@@ -196,6 +196,7 @@ int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset);
 /* 9 was the resident prover kernel (removed in round 3: measured equal to launches) */
 #define SC_KIND_GRID_PASS 10 /* wgrid_pass_kernel: fold kf <= 5 variables of tables of <= 2^20 folded entries + the 3^ks cells of ks <= 5 rounds */
 #define SC_KIND_GRAM_PASS 11   /* gram_pass_kernel: the four-round first pass of a large proof on the int8 matrix cores (ks = 4) */
+#define SC_KIND_WFOLD_PASS 13  /* wfold_pass_kernel: the fold behind the matrix-core first pass serving five rounds (kf = 4, ks = 5; shards and tables of <= 2^wfold_log entries) */
 /* 12 was gram_finish_kernel (rounds 4: a second launch behind the gram pass; folded into gram_pass_kernel in round 5) */
 typedef struct sc_launch_record {
   int32_t kind;           /* SC_KIND_* */
@@ -327,6 +328,7 @@ int sc_prover_num_vars(const sc_prover* pr, size_t* out);
                               * wrote to pinned host memory (log_in = log2 entries per table and device) and serves every remaining
                               * round (ks) itself; no launch.  Always the last step */
 #define SC_PLAN_GRAM_PASS 5  /* gram_pass_kernel: rounds 1..4 of a proof on tables (shards) of >= 2^gram_log entries */
+#define SC_PLAN_WFOLD_PASS 6 /* wfold_pass_kernel: folds the four challenges of the matrix-core pass AND serves five rounds (tables of 2^12 .. 2^wfold_log entries) */
 /* ABI version of this header: bumped whenever a struct below grows or an enum is extended.  sc_abi_version()
  * returns the library's; a caller built against another major version must not pass structs.  Version 5 = round 5. */
 #define SC_ABI_VERSION 5
@@ -336,6 +338,9 @@ typedef struct sc_plan_options {   /* the context options the schedule depends o
                                     * the library reads and writes no field beyond it (fields a caller's struct lacks take their defaults) */
   int32_t vars_per_pass, first_pass_vars, grid_pass, grid_log, grid_max_vars, grid_sharded, tail_log, use_mailbox, gram_log;
   int32_t host_tail_log;           /* since version 5 */
+  int32_t wfold_log;               /* since version 5 */
+  int32_t wfold_min_log;           /* since version 5 */
+  int32_t wfold_always;            /* since version 5 */
 } sc_plan_options;
 typedef struct sc_plan_step {
   int32_t action, kf, ks, log_in, sharded;

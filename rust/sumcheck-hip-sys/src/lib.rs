@@ -60,6 +60,9 @@ pub struct sc_plan_options {
     pub use_mailbox: i32,
     pub gram_log: i32,
     pub host_tail_log: i32,
+    pub wfold_log: i32,
+    pub wfold_min_log: i32,
+    pub wfold_always: i32,
 }
 /// One launch of a planned proof: `action` is one of the `SC_PLAN_*` values of the header.
 #[repr(C)]

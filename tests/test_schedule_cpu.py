@@ -18,7 +18,9 @@ OPTION_SETS = [
     {"grid_max_vars": 1}, {"grid_max_vars": 3}, {"grid_log": 3}, {"grid_log": 26}, {"grid_sharded": 0}, {"grid_sharded": 0, "tail_log": 4},
     {"grid_sharded": 0, "tail_log": 0, "grid_pass": 0}, {"use_mailbox": 0}, {"grid_max_vars": 4, "grid_log": 12, "first_pass_vars": 2},
     {"gram_log": 0}, {"gram_log": 14}, {"first_pass_vars": 4}, {"first_pass_vars": 4, "grid_log": 10}, {"gram_log": 20, "grid_pass": 0},
-    {"host_tail_log": 0}, {"host_tail_log": 3}, {"host_tail_log": 7, "grid_max_vars": 2}, {"host_tail_log": 0, "grid_pass": 0},
+    {"host_tail_log": 0}, {"host_tail_log": 3}, {"host_tail_log": 7, "grid_max_vars": 2}, {"host_tail_log": 0, "grid_pass": 0}, {"host_tail_log": 10},
+    {"wfold_log": 0}, {"wfold_log": 25}, {"wfold_always": 1}, {"wfold_always": 1, "wfold_min_log": 12, "first_pass_vars": 4},
+    {"wfold_always": 1, "wfold_min_log": 12, "grid_log": 26, "gram_log": 0}, {"wfold_always": 1, "host_tail_log": 0},
 ]
 
 
@@ -28,8 +30,9 @@ def check(steps, n, world, transport, opts):
     assert served == n, (served, n)
     cur_log, kf, sharded = n - g, 0, transport != "none" and not (transport == "local" and world == 1)
     gmax = opts.get("grid_max_vars", 5)
-    htl = opts.get("host_tail_log", 10)
+    htl = opts.get("host_tail_log", 11)
     prev = None
+    served_before = 0
     for s in steps:
         assert s["log_in"] == cur_log and s["sharded"] == (sharded if s["action"] != "gather" else True), (s, cur_log, sharded)
         if s["action"] == "gather":
@@ -40,7 +43,7 @@ def check(steps, n, world, transport, opts):
         assert s["kf"] == kf, (s, kf)
         if transport == "local" and world > 1:
             # the devices of one multi-device handle: never a gather or a rank pass; the host finishes the device bits
-            assert s["action"] in ("pass", "grid_pass", "host_tail", "gram_pass")
+            assert s["action"] in ("pass", "grid_pass", "host_tail", "gram_pass", "wfold_pass")
         if s["action"] == "host_tail":
             # the host finishes: always the last step, it serves every round that is left; only a whole prover or the shards of a
             # multi-device handle hand over (the shards of the other transports live in other processes), and only tables the
@@ -50,7 +53,7 @@ def check(steps, n, world, transport, opts):
             assert s is steps[-1] and s["ks"] == n - sum(x["ks"] for x in steps[:-1]) and kf <= 5
             assert opts.get("use_mailbox", 1) == 1 or (local and cur_log == kf)
             assert not sharded or local
-            limit = min(max(htl, 5) if local else htl, 10)
+            limit = min(max(htl, 5) if local else htl, 11)
             handed = prev is not None and prev["kf"] > 0 and cur_log <= limit and (prev["action"] == "grid_pass" or cur_log <= 5)
             assert handed or (local and cur_log == kf), (s, prev, limit)
             cur_log, sharded = 0, False
@@ -63,6 +66,17 @@ def check(steps, n, world, transport, opts):
             assert s is steps[0] and kf == 0 and s["ks"] == 4 and cur_log >= 14 and (not sharded or opts.get("grid_sharded", 1) == 1)
             assert opts.get("vars_per_pass", 2) == 2 and opts.get("use_mailbox", 1) == 1 and opts.get("first_pass_vars", 0) in (0, 4)
             assert opts.get("first_pass_vars", 0) == 4 or (opts.get("gram_log", 21) > 0 and cur_log >= opts.get("gram_log", 21))
+        elif s["action"] == "wfold_pass":
+            # the fold behind a four-round first pass that serves five rounds: round 4, four pending challenges, tables (shards) of
+            # 2^max(12, wfold_min_log) .. 2^wfold_log entries that keep six variables, and a grid pass must be able to take the
+            # five challenges it leaves (the folded table of THAT pass <= 2^grid_log); sharded provers where they take grid passes
+            assert kf == 4 and s["ks"] == 5 and served_before == 4 and cur_log - kf >= 6 and n - served_before >= 6
+            assert max(12, opts.get("wfold_min_log", 21)) <= cur_log <= opts.get("wfold_log", 40)
+            assert cur_log - kf - 5 <= opts.get("grid_log", 20) and opts.get("grid_pass", 1) == 1 and opts.get("use_mailbox", 1) == 1
+            assert opts.get("vars_per_pass", 2) == 2 and gmax >= 5 and (not sharded or opts.get("grid_sharded", 1) == 1)
+            nxt = steps[steps.index(s) + 1]
+            assert nxt["action"] == "grid_pass" and nxt["kf"] == 5
+            cur_log -= kf
         elif s["action"] == "pass":
             assert (kf <= 3 or (kf == 4 and s["ks"] == 2 and steps[0]["action"] == "gram_pass")) and 1 <= s["ks"] <= 3
             assert (s["ks"] < 3 or kf == 0) and cur_log >= kf + s["ks"]
@@ -76,10 +90,11 @@ def check(steps, n, world, transport, opts):
         if s["action"] in ("pass", "grid_pass") and s is not steps[-1] and s["kf"] > 0 and opts.get("use_mailbox", 1) == 1:
             # a pass that COULD hand over (rule above) does: the next step is the host tail
             local = transport == "local" and sharded
-            limit = min(max(htl, 5) if local else htl, 10)
+            limit = min(max(htl, 5) if local else htl, 11)
             if (not sharded or local) and cur_log <= limit and (s["action"] == "grid_pass" or cur_log <= 5):
                 assert steps[steps.index(s) + 1]["action"] == "host_tail", (s, steps)
         kf = s["ks"]
+        served_before += s["ks"]
         prev = s
     # whatever is left after the last launch are the variables its cached grid serves
     assert cur_log >= 0
@@ -99,20 +114,32 @@ def test_known_schedules(plan):
     def sig(steps):
         return [(s["action"], s["kf"], s["ks"], s["log_in"]) for s in steps]
 
-    # the headline: n = 28 on one GPU (bench.py config.schedule of every run): four rounds from the matrix-core pass, then seven
-    # launches where the 27-cell first pass (gram_log = 0: rounds 1 to 3) needs eight
-    # (round 5: one launch for the matrix-core pass, and the host finishes from the 2^10-entry tables the sixth launch leaves:
-    # SIX launches)
-    assert sig(plan(28)) == [("gram_pass", 0, 4, 28), ("pass", 4, 2, 28), ("pass", 2, 2, 24), ("grid_pass", 2, 5, 22), ("grid_pass", 5, 5, 20),
-                             ("grid_pass", 5, 5, 15), ("host_tail", 5, 5, 10)]
-    assert sig(plan(28, host_tail_log=0)) == sig(plan(28))[:6] + [("grid_pass", 5, 5, 10)]
-    assert sig(plan(28, gram_log=0)) == [("pass", 0, 3, 28), ("pass", 3, 2, 28), ("pass", 2, 2, 25), ("pass", 2, 2, 23), ("grid_pass", 2, 5, 21),
-                                         ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14), ("host_tail", 5, 4, 9)]
-    # the shard of an 8-GPU run as a proof of its own: five launches (round 4: seven)
-    assert sig(plan(25)) == [("gram_pass", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 5, 21), ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14),
-                             ("host_tail", 5, 4, 9)]
-    assert sig(plan(20))[0] == ("grid_pass", 0, 5, 20) and sig(plan(21))[0] == ("gram_pass", 0, 4, 21)
-    assert sig(plan(20, first_pass_vars=4))[:2] == [("gram_pass", 0, 4, 20), ("grid_pass", 4, 4, 20)]
+    # the headline: n = 28 on one GPU (bench.py config.schedule of every run): four rounds from the matrix-core pass, five from the
+    # fold behind it (wfold_pass_kernel), three grid passes of 27 / 243 / 81 cells, and the host finishes from the 2^11-entry
+    # tables the fifth launch leaves: FIVE launches (round 4: seven; the 27-cell first pass, gram_log = 0, needs seven)
+    assert sig(plan(28)) == [("gram_pass", 0, 4, 28), ("wfold_pass", 4, 5, 28), ("grid_pass", 5, 3, 24), ("grid_pass", 3, 5, 19),
+                             ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
+    assert sig(plan(28, wfold_log=0)) == [("gram_pass", 0, 4, 28), ("pass", 4, 2, 28), ("pass", 2, 2, 24), ("grid_pass", 2, 4, 22),
+                                          ("grid_pass", 4, 5, 20), ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
+    # (round 5's first half: the host took over at 2^10 entries wherever the even split happened to pass that size)
+    assert sig(plan(28, wfold_log=0, host_tail_log=10)) == [("gram_pass", 0, 4, 28), ("pass", 4, 2, 28), ("pass", 2, 2, 24), ("grid_pass", 2, 5, 22),
+                                                             ("grid_pass", 5, 5, 20), ("grid_pass", 5, 5, 15), ("host_tail", 5, 5, 10)]
+    assert sig(plan(28, host_tail_log=0)) == [("gram_pass", 0, 4, 28), ("wfold_pass", 4, 5, 28), ("grid_pass", 5, 5, 24), ("grid_pass", 5, 5, 19),
+                                              ("grid_pass", 5, 5, 14), ("grid_pass", 5, 4, 9)]
+    assert sig(plan(28, gram_log=0)) == [("pass", 0, 3, 28), ("pass", 3, 2, 28), ("pass", 2, 2, 25), ("pass", 2, 2, 23), ("grid_pass", 2, 3, 21),
+                                         ("grid_pass", 3, 5, 19), ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
+    # the shard of an 8-GPU run as a proof of its own: FOUR launches (round 4: seven; first half of round 5: five)
+    assert sig(plan(25)) == [("gram_pass", 0, 4, 25), ("wfold_pass", 4, 5, 25), ("grid_pass", 5, 5, 21), ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
+    assert sig(plan(25, wfold_log=0)) == [("gram_pass", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 3, 21), ("grid_pass", 3, 5, 19),
+                                          ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
+    # the wfold pass is taken where it saves a launch (25, 27, 28, 29) or replaces a grid pass over the whole table (21 .. 24), not
+    # where pass_kernel<4,2> does the same in as many launches (26) or no grid pass could take its five challenges (30)
+    assert [n for n in range(14, 34) if any(x["action"] == "wfold_pass" for x in plan(n))] == [21, 22, 23, 24, 25, 27, 28, 29]
+    assert len(plan(26)) == len(plan(26, wfold_always=1)) and plan(26, wfold_always=1)[1]["action"] == "wfold_pass"
+    for n, saved in ((25, 1), (27, 1), (28, 1), (29, 2)):
+        assert len(plan(n)) == len(plan(n, wfold_log=0)) - saved
+    assert sig(plan(20))[0] == ("grid_pass", 0, 4, 20) and sig(plan(21))[0] == ("gram_pass", 0, 4, 21)
+    assert sig(plan(20, first_pass_vars=4))[:2] == [("gram_pass", 0, 4, 20), ("grid_pass", 4, 5, 20)]
     # BASELINE config 4: n = 28 over 8 ranks, peer transport - seven launches, seven exchanges, no gather
     s8 = plan(28, 8, "peer")
     assert sig(s8) == [("gram_pass", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 5, 21), ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14),
@@ -124,13 +151,15 @@ def test_known_schedules(plan):
     # the same over RCCL: the shard is gathered when it is down to its pending challenges, the rank bits are one more pass
     r8 = plan(28, 8, "rccl")
     assert sig(r8)[:6] == sig(s8)[:6] and sig(r8)[6:] == [("gather", 0, 0, 4), ("grid_pass", 4, 3, 7)]
-    # ONE process over 8 devices (sc_ctx_create_multi): FIVE launches per device, then every launcher thread folds the five pending
-    # challenges of the 2^9 entries per table its device handed over and the host serves the seven rounds that are left - no gather
+    # ONE process over 8 devices (sc_ctx_create_multi): the n = 25 schedule on every device - FOUR launches - then every launcher
+    # thread folds the four pending challenges of the 2^11 entries per table its device handed over and the host serves the ten
+    # rounds that are left - no gather
     l8 = plan(28, 8, "local")
-    assert sig(l8)[:5] == sig(s8)[:5] and sig(l8)[5:] == [("host_tail", 5, 7, 9)]
-    # (option off: round 4's schedule - a sixth launch, the host takes the 16 entries per table and device it leaves)
+    assert sig(l8)[:4] == sig(plan(25))[:4] and sig(l8)[4:] == [("host_tail", 4, 10, 11)] and all(x["sharded"] for x in l8)
+    # (option off: round 4's rule - the host takes over from <= 32 entries per table and device)
     l8o = plan(28, 8, "local", host_tail_log=0)
-    assert sig(l8o)[:6] == sig(s8)[:6] and sig(l8o)[6:] == [("host_tail", 4, 3, 4)]
+    assert sig(l8o) == [("gram_pass", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 4, 21), ("grid_pass", 4, 5, 19), ("grid_pass", 5, 5, 15),
+                        ("grid_pass", 5, 5, 10), ("host_tail", 5, 3, 5)]
     assert sig(plan(3, 8, "local")) == [("host_tail", 0, 3, 0)]      # one entry per device: the host serves every round
     assert sig(plan(28, 1, "local")) == sig(plan(28))                  # one device behind the handle: the plain schedule
     # two rounds per pass with a gather at 2^16-entry shards (grid_sharded 0): round 1's sharded schedule
@@ -140,13 +169,17 @@ def test_known_schedules(plan):
     assert sig(plan(12)) == [("grid_pass", 0, 4, 12), ("grid_pass", 4, 4, 12), ("host_tail", 4, 4, 8)]
     assert sig(plan(12, host_tail_log=0)) == [("grid_pass", 0, 4, 12), ("grid_pass", 4, 4, 12), ("grid_pass", 4, 4, 8)]
     assert len(plan(20)) == 4 and len(plan(5)) == 1 and sig(plan(10)) == [("grid_pass", 0, 5, 10), ("grid_pass", 5, 5, 10)]
+    # aiming at the hand-over saves a launch where the even split passes the limit late: n = 16 in two launches
+    assert sig(plan(16)) == [("grid_pass", 0, 5, 16), ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
+    assert len(plan(16, host_tail_log=10)) == 4
 
 
 def test_plan_argument_checks(plan):
     pkg = load_package()
     for bad in [dict(num_vars=2, world=8, transport="peer"), dict(num_vars=10, world=3, transport="peer"),
                 dict(num_vars=10, world=2, transport="none"), dict(num_vars=10, world=1, transport="none", grid_max_vars=6),
-                dict(num_vars=10, world=1, transport="none", vars_per_pass=3), dict(num_vars=10, world=1, transport="none", host_tail_log=11)]:
+                dict(num_vars=10, world=1, transport="none", vars_per_pass=3), dict(num_vars=10, world=1, transport="none", host_tail_log=12),
+                dict(num_vars=10, world=1, transport="none", wfold_log=5), dict(num_vars=10, world=1, transport="none", wfold_min_log=3)]:
         with pytest.raises(pkg.SumcheckHipError) as ei:
             plan(**bad)
         assert ei.value.code == 1
@@ -163,7 +196,8 @@ def test_plan_options_struct_is_versioned():
     assert lib.sc_abi_version() == L.ABI_VERSION == 5
     full = L.ScPlanOptions()
     lib.sc_plan_options_default(ctypes.byref(full), ctypes.sizeof(full))
-    assert full.struct_size == ctypes.sizeof(full) == 44 and full.host_tail_log == 10 and full.gram_log == 21
+    assert full.struct_size == ctypes.sizeof(full) == 56 and full.host_tail_log == 11 and full.gram_log == 21
+    assert (full.wfold_log, full.wfold_min_log, full.wfold_always) == (40, 21, 0)
 
     class Old(ctypes.Structure):      # a caller built before host_tail_log existed, with a guard word behind its struct
         _fields_ = [("struct_size", ctypes.c_uint32)] + [(k, ctypes.c_int32) for k in (

@@ -33,14 +33,14 @@ ABI_VERSION = 5   # SC_ABI_VERSION of include/sumcheck_hip.h as this binding was
 class ScPlanOptions(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32)] + [
         (k, ctypes.c_int32) for k in ("vars_per_pass", "first_pass_vars", "grid_pass", "grid_log", "grid_max_vars", "grid_sharded",
-                                      "tail_log", "use_mailbox", "gram_log", "host_tail_log")]
+                                      "tail_log", "use_mailbox", "gram_log", "host_tail_log", "wfold_log", "wfold_min_log", "wfold_always")]
 
 
 class ScPlanStep(ctypes.Structure):
     _fields_ = [(k, ctypes.c_int32) for k in ("action", "kf", "ks", "log_in", "sharded")]
 
 
-PLAN_ACTIONS = {0: "pass", 1: "grid_pass", 2: "rank_pass", 3: "gather", 4: "host_tail", 5: "gram_pass"}
+PLAN_ACTIONS = {0: "pass", 1: "grid_pass", 2: "rank_pass", 3: "gather", 4: "host_tail", 5: "gram_pass", 6: "wfold_pass"}
 TRANSPORTS = {"none": 0, "rccl": 1, "host": 2, "peer": 3, "local": 4}
 
 
@@ -49,7 +49,7 @@ class ScLaunchRecord(ctypes.Structure):
                 ("bytes_read", u64), ("bytes_written", u64), ("ms", ctypes.c_double)]
 
 
-KIND_NAMES = {0: "pass", 2: "evaluate", 3: "fold", 4: "fix_low", 5: "fold_be", 6: "coldot", 7: "gkr", 8: "matsq", 10: "grid_pass", 11: "gram_pass"}
+KIND_NAMES = {0: "pass", 2: "evaluate", 3: "fold", 4: "fix_low", 5: "fold_be", 6: "coldot", 7: "gkr", 8: "matsq", 10: "grid_pass", 11: "gram_pass", 13: "wfold_pass"}
 
 ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, voidp, u64p, size_t)
 ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int, voidp, u64p, u64p, size_t)

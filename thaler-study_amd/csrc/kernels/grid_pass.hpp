@@ -373,15 +373,14 @@ __device__ __forceinline__ void publish_cells(const WgOut& out, u64 total) {
   if (tid == 0) __hip_atomic_store(out.mailbox + kMailboxSeq, out.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-template <class F, int KS, bool PF>
-__global__ void __launch_bounds__(kBlock)
-wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
-                  GridW gw, int kf, size_t n_out, WgOut out) {
+// What every block does with its cells (thread c < 3^KS holds cell c in `total`): two ticket levels, the last block publishes.
+// Every thread of the block calls it (blocks of 256 threads or more).
+template <class F, int KS>
+__device__ __forceinline__ void wgrid_finish(const F& f, u64 total, const WgOut& out) {
   constexpr int kPow3[6] = {1, 3, 9, 27, 81, 243};
   constexpr int cells = kPow3[KS];
   __shared__ int lds_flag;
   const int tid = threadIdx.x;
-  u64 total = wgrid_body<F, KS, PF>(f, A, B, A2, B2, gw, kf, n_out, out.host_out != 0);
   if (gridDim.x > 1) {
     // level 1: the blocks of a group of 32
     const int n_blocks = gridDim.x, group = blockIdx.x / kWgGroupBlocks, n_groups = (n_blocks + kWgGroupBlocks - 1) / kWgGroupBlocks;
@@ -444,6 +443,205 @@ wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
     if (tid <= n_groups) __hip_atomic_store(out.tickets + tid, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   publish_cells<cells>(out, total);
+}
+
+template <class F, int KS, bool PF>
+__global__ void __launch_bounds__(kBlock)
+wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2,
+                  GridW gw, int kf, size_t n_out, WgOut out) {
+  const u64 total = wgrid_body<F, KS, PF>(f, A, B, A2, B2, gw, kf, n_out, out.host_out != 0);
+  wgrid_finish<F, KS>(f, total, out);
+}
+
+// ------------------------------------------------------------------------------------
+// wfold_pass_kernel (round 5): the fold behind the matrix-core first pass that serves FIVE rounds.
+//
+// On a 2^25-entry shard the fold pass (pass_kernel<4,2>, 100 us) and the five-round pass behind it (28 us + a launch) are a third
+// of the proof, and what separates them is not work but a launch: the fold is bound by memory (28 % VALU-busy), the five-round
+// pass by instruction issue per folded entry.  This kernel is pass_kernel<4,.>'s front end - a wave streams 8 KiB sub-steps of
+// both tables (lane <-> 16-byte piece, 1 KiB contiguous per instruction), bounces them through its private LDS region so that
+// every lane folds ITS sixteen entries with one lazy sum, the sub-steps of the two tables rotated against each other and from
+// wave to wave so that the chip's requests cover all HBM channels - with wgrid_pass_kernel<F, 5>'s back end: the tile's 256
+// folded entries per table are eight groups of 32; per group the 64 lanes drop the entries into the wave's extension arrays,
+// fill the {0,1,inf}^5 grid level by level (LDS addresses decoded once) and multiply the 243 cell pairs into four lazy
+// accumulators per lane.  ~2.3x the instructions of the two-round fold, still under its memory time; one launch and one trip to
+// the host less, and the pass behind it reads a 32nd of the tables with five challenges to fold.  Whole tiles only (tables of
+// >= 2^12 entries); cells leave exactly as wgrid_pass_kernel's (wgrid_finish).
+constexpr int kWfThreads = 512;
+template <class F, int NT>
+__global__ void __launch_bounds__(kWfThreads)
+wfold_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2, FoldW fw,
+                  size_t n_tiles, WgOut out) {
+  constexpr bool kNtLoad = (NT & 1) != 0, kNtStore = (NT & 2) != 0, kMix = (NT & 4) != 0;
+  constexpr int KS = 5, cells = 243, OUT = 4, NPS = 8, NP = 32, NPO = 2;   // a tile: 4 sub-steps of 64 outputs x 16 entries per table
+  constexpr int kWaves = kWfThreads / kWave;
+  constexpr int kPow3[6] = {1, 3, 9, 27, 81, 243};
+  // per wave: 8 KiB sub-step | 4 KiB tile outputs (256 + 256) | 4 KiB extension arrays [table][256]
+  constexpr int kRegionWords = 1024 + 512 + 512;
+  __shared__ u64 lds_all[kWaves * kRegionWords];
+  __shared__ int cell_of[kWgEntries], suffix_of[kWgEntries];
+  __shared__ unsigned lds_next;
+  typedef __attribute__((address_space(3))) u64 lds_u64;
+  const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
+  if (tid < kWgEntries) {
+    int c = 0, u = 0, p3 = 1;
+    for (int m = 0; m < KS; ++m) {
+      c += ((tid >> (KS - 1 - m)) & 1) * p3;
+      u += ((tid >> m) & 1) * p3;
+      p3 *= 3;
+    }
+    cell_of[tid] = c;
+    suffix_of[tid] = u;
+  }
+  if (tid == 0) lds_next = 0;
+  __syncthreads();
+  ull2* const reg = reinterpret_cast<ull2*>(lds_all + (size_t)wave * kRegionWords);
+  u64* const xchg = lds_all + (size_t)wave * kRegionWords + 1024;
+  u64* const ef = xchg + 512;
+  const int tbl = lane >> 5, ent = lane & (kWgEntries - 1);
+  const int slot = tbl * kGridChunk + cell_of[ent];
+  unsigned step[KS][3];
+#pragma clang loop unroll(full)
+  for (int j = 0; j < KS; ++j) {
+    const int low = KS - 1 - j, pj = kPow3[j], stride = kPow3[low], items = pj << low;   // per table (one group of 32)
+    const unsigned inv = (1u << 20) / (unsigned)pj + 1u;
+#pragma clang loop unroll(full)
+    for (int q = 0; q < 3; ++q) {
+      const int idx = lane + kWave * q;
+      unsigned d = 0;
+      if (idx < 2 * items) {
+        const int tb = idx >= items ? 1 : 0, id = idx - tb * items;
+        const int sfx = id & ((1 << low) - 1), t = id >> low;
+        const int g = (int)(((unsigned)t * inv) >> 20), pp = t - g * pj;
+        d = 0x80000000u | (unsigned)(size_t)(lds_u64*)(ef + tb * kGridChunk + g * cells + pp * 3 * stride + suffix_of[sfx]);
+      }
+      step[j][q] = d;
+    }
+  }
+  typename F::Acc acc[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) f.acc_zero(acc[k]);
+
+  const ull2* __restrict__ Ap = reinterpret_cast<const ull2*>(A);
+  const ull2* __restrict__ Bp = reinterpret_cast<const ull2*>(B);
+  ull2* __restrict__ A2p = reinterpret_cast<ull2*>(A2);
+  ull2* __restrict__ B2p = reinterpret_cast<ull2*>(B2);
+  const int rot = wave & 3;
+  auto next_tile = [&]() -> size_t {
+    unsigned c = 0;
+    if (lane == 0) c = __hip_atomic_fetch_add(&lds_next, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return (size_t)__builtin_amdgcn_readfirstlane(c) * gridDim.x + blockIdx.x;
+  };
+  auto load_sub = [&](const ull2* __restrict__ T, size_t tile, int o, ull2 (&p)[NPS]) {
+    const ull2* src = T + tile * kWave * NP + (size_t)o * NPS * kWave + lane;
+#pragma unroll
+    for (int k = 0; k < NPS; ++k) p[k] = ld16<kNtLoad>(src + k * kWave);
+  };
+  auto stash = [&](const ull2 (&p)[NPS]) {
+#pragma unroll
+    for (int k = 0; k < NPS; ++k) reg[swz_slot<NPS>(64 * k + lane)] = p[k];
+  };
+  auto fold16 = [&]() -> u64 {
+    typename F::Acc3 sacc;
+    f.acc3_zero(sacc);
+#pragma unroll
+    for (int m = 0; m < NPS; ++m) {
+      const ull2 x = reg[swz_slot<NPS>(NPS * lane + m)];
+      f.acc3_mac(sacc, x.x, fw.w[2 * m]);
+      f.acc3_mac(sacc, x.y, fw.w[2 * m + 1]);
+    }
+    return f.acc3_get(sacc);
+  };
+  // the 243 cells over one group of 32 folded entries per table (wgrid_body's iteration, KS = 5)
+  auto grid_group = [&](int grp) {
+    ef[slot] = xchg[kWave * OUT * tbl + kWgEntries * grp + ent];
+    wave_lds_sync();
+#pragma clang loop unroll(full)
+    for (int j = 0; j < KS; ++j) {
+      const int st = kPow3[KS - 1 - j];
+#pragma clang loop unroll(full)
+      for (int q = 0; q < 3; ++q) {
+        if (2 * (kPow3[j] << (KS - 1 - j)) > kWave * q) {
+          const unsigned d = step[j][q];
+          if (d != 0) {
+            lds_u64* const x = (lds_u64*)(size_t)(d & 0x7FFFFFFFu);
+            x[2 * st] = f.sub(x[st], x[0]);
+          }
+        }
+      }
+      wave_lds_sync();
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = lane + kWave * k;
+      if (p < cells) f.acc_mac(acc[k], ef[p], ef[kGridChunk + p]);
+    }
+    wave_lds_sync();
+  };
+  ull2 pa[NPS], pb[NPS];
+  size_t tile = next_tile();
+  if (tile < n_tiles) {
+    load_sub(Ap, tile, rot, pa);
+    load_sub(Bp, tile, kMix ? rot : rot ^ 2, pb);
+  }
+  while (tile < n_tiles) {
+    const size_t next = next_tile();
+#pragma unroll
+    for (int i = 0; i < OUT; ++i) {
+      const int oa = (i + rot) & 3, ob = kMix ? oa : oa ^ 2, na = (i + 1 + rot) & 3, nb = kMix ? na : na ^ 2;
+      stash(pa);
+      wave_lds_sync();
+      if (i + 1 < OUT) load_sub(Ap, tile, na, pa);
+      else if (next < n_tiles) load_sub(Ap, next, na, pa);
+      const u64 xa = fold16();
+      wave_lds_sync();
+      stash(pb);
+      wave_lds_sync();
+      if (i + 1 < OUT) load_sub(Bp, tile, nb, pb);
+      else if (next < n_tiles) load_sub(Bp, next, nb, pb);
+      const u64 xb = fold16();
+      xchg[kWave * oa + lane] = xa;
+      xchg[kWave * OUT + kWave * ob + lane] = xb;
+      wave_lds_sync();
+      if constexpr (kMix) {   // the two groups this sub-step completed, while the next sub-step's loads are in flight
+#pragma unroll 1
+        for (int g = 0; g < 2; ++g) grid_group(2 * oa + g);
+      }
+    }
+    // the folded tables: the exchange area holds the tile's outputs in index order - stored straight out of it
+    {
+      const ull2* xo = reinterpret_cast<const ull2*>(xchg);
+      const size_t o0 = tile * kWave * NPO;
+#pragma unroll
+      for (int k = 0; k < NPO; ++k) {
+        const size_t q = o0 + (size_t)k * kWave + lane;
+        st16<kNtStore>(A2p + q, xo[kWave * k + lane]);
+        st16<kNtStore>(B2p + q, xo[kWave * NPO + kWave * k + lane]);
+      }
+    }
+    if constexpr (!kMix) {
+#pragma unroll 1
+      for (int grp = 0; grp < 2 * OUT; ++grp) grid_group(grp);
+    } else {
+      wave_lds_sync();   // (the stores' LDS reads before the next tile's outputs)
+    }
+    if (wave == 0 && blockIdx.x < 8) asm volatile("buffer_wbl2 sc1" ::: "memory");   // (the bulk write-back hint of pass_kernel's pipelined forms)
+    tile = next;
+  }
+  // the block's cells: accumulators -> residues, the waves added through LDS (the wave regions are free now)
+  __syncthreads();
+  u64* const red = lds_all;   // [kWaves][kGridChunk]
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int p = lane + kWave * k;
+    red[wave * kGridChunk + p] = (p < cells) ? f.acc_get(acc[k]) : 0;
+  }
+  __syncthreads();
+  u64 total = 0;
+  if (tid < cells) {
+    for (int w = 0; w < kWaves; ++w) total = f.add(total, red[w * kGridChunk + tid]);
+  }
+  wgrid_finish<F, KS>(f, total, out);
 }
 
 // The last pass of a sharded prover on the peer transport: the shard is down to its 2^kf pending entries (kf <= 5),

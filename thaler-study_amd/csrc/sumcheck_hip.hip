@@ -101,7 +101,7 @@ bool load_rccl(std::string* why) {
 // launch leaves this shard's own sums in its own mailbox and the handle's host thread adds them - no collective at all
 enum class Transport { kNone, kRccl, kHost, kPeer, kLocal };
 constexpr int kMaxSubs = 8;          // devices behind one multi-device handle (one node)
-constexpr int kTailLogMax = 10;
+constexpr int kTailLogMax = 11;
 constexpr int kTailEntries = 1 << kTailLogMax;   // a pass whose outputs have <= 2^host_tail_log <= this many entries per table writes them to
                                      // pinned host memory (sc_ctx::h_tail): the host finishes the proof from them (option "host_tail_log")
 constexpr int kTailSmallLog = 5;     // ... and what a pass_kernel launch may hand over: one wave's stores (finish_pass drains wave 0 only)
@@ -145,6 +145,11 @@ struct sc_ctx {
   int pipe32 = 1, pipe32_log = 20, pipe32_blocks = 0;   // pass_kernel<3,2>: the pipelined whole-tile form on tables of >= 2^pipe32_log entries
   int gram_log = 21;              // first pass of an unsharded proof on tables of >= 2^gram_log entries: kernels/gram.hpp (0: never)
   int host_tail_log = kTailLogMax;   // folded tables of <= 2^this entries go to pinned host memory and the host finishes the proof (0: off)
+  int wfold_log = 40;                // the fold behind the matrix-core first pass serves FIVE rounds (wfold_pass_kernel) on tables of <= 2^this entries (0: never)
+  int wfold_min_log = 21;            // ... and of >= 2^this entries (below, a five-round grid pass folds the four challenges)
+  int wfold_always = 0;              // 0: where the proof then needs fewer launches (the planner counts both ways); 1: wherever it can run
+  int wfold_mix = 1;                 // its grid work spread over the sub-steps of a tile (two groups behind each) instead of behind the tile
+  int wfold_blocks = 0;              // its resident grid (0 = not asked yet)
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
                       // cheaper than the ~25 us of collective latency of each further sharded pass
   // grid cap of the streaming kernels: three 256-thread blocks per CU (set in sc_ctx_create).
