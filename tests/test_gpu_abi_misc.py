@@ -25,17 +25,18 @@ def test_launch_log_records_what_ran():
     pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
     log = ctx.launch_log(reset=False)
     assert log == ctx.launch_log(reset=True) and ctx.launch_log() == []
-    # the schedule of DESIGN.md section 4 at n = 20: four passes of five rounds; sizes shrink by kf
-    assert log[0]["kind"] == "grid_pass" and (log[0]["kf"], log[0]["ks"], log[0]["log_in"]) == (0, 5, 20)
+    # the schedule of DESIGN.md section 4 at n = 20: three grid passes (4 + 5 + 4 rounds), the host serves the last seven; sizes
+    # shrink by kf
+    assert log[0]["kind"] == "grid_pass" and (log[0]["kf"], log[0]["ks"], log[0]["log_in"]) == (0, 4, 20)
     size, rounds = 20, 0
     for r in log:
         assert r["kind"] in ("pass", "tail_pass", "grid_pass") and r["log_in"] == size and r["ms"] > 0
         assert r["bytes_read"] == 16 << size and r["bytes_written"] == ((16 << (size - r["kf"])) if r["kf"] else 0)
         size -= r["kf"]
         rounds += r["ks"]
-    # the smallest tables: up to five rounds per launch; the last five rounds are the host's (option "host_tail_log": the third
-    # launch left its 2^10-entry tables in pinned host memory) - no record, there is no launch
-    assert rounds == 15 and size == 10 and log[-1]["kind"] == "grid_pass" and len(log) == 3
+    # the smallest tables: up to five rounds per launch; the last seven rounds are the host's (option "host_tail_log": the third
+    # launch left its 2^11-entry tables in pinned host memory) - no record, there is no launch
+    assert rounds == 13 and size == 11 and log[-1]["kind"] == "grid_pass" and len(log) == 3
     n_launch, ms = ctx.kernel_time(reset=True)
     assert n_launch == len(log) and abs(ms - sum(r["ms"] for r in log)) < 1e-6   # the totals of the same records
     assert ctx.kernel_time(reset=True) == (0, 0.0)

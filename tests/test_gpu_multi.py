@@ -126,11 +126,11 @@ def test_multi_n28_equals_one_device():
         assert c8 == c1 and np.array_equal(ev8, evals) and np.array_equal(ch8, ch), n_dev
         assert G.evaluate([int(x) for x in ch]) == final
         if n_dev == 8:
-            # (shard 0's launches: the matrix-core first pass, the four-variable fold, three five-round passes; the launcher threads
-            # fold the five pending challenges of the 2^9 entries per table and device the last one hands over, the host serves
-            # the seven rounds that are left: FIVE launches per device - round 4: seven)
+            # (shard 0's launches: the matrix-core first pass, the four-variable fold that serves five rounds, two grid passes; the
+            # launcher threads fold the four pending challenges of the 2^11 entries per table and device the last one hands
+            # over, the host serves the ten rounds that are left: FOUR launches per device - round 4: seven)
             assert [(r["kind"], r["kf"], r["ks"], r["log_in"]) for r in log] == [
-                ("gram_pass", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 5, 21), ("grid_pass", 5, 5, 19), ("grid_pass", 5, 5, 14)]
+                ("gram_pass", 0, 4, 25), ("wfold_pass", 4, 5, 25), ("grid_pass", 5, 5, 21), ("grid_pass", 5, 4, 16)]
         del G, a, b
         ctx.close()
 
