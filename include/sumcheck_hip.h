@@ -341,6 +341,7 @@ typedef struct sc_plan_options {   /* the context options the schedule depends o
   int32_t wfold_log;               /* since version 5 */
   int32_t wfold_min_log;           /* since version 5 */
   int32_t wfold_always;            /* since version 5 */
+  int32_t wfold5_min_log;          /* since version 5 */
 } sc_plan_options;
 typedef struct sc_plan_step {
   int32_t action, kf, ks, log_in, sharded;

@@ -63,6 +63,7 @@ pub struct sc_plan_options {
     pub wfold_log: i32,
     pub wfold_min_log: i32,
     pub wfold_always: i32,
+    pub wfold5_min_log: i32,
 }
 /// One launch of a planned proof: `action` is one of the `SC_PLAN_*` values of the header.
 #[repr(C)]

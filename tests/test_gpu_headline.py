@@ -42,7 +42,7 @@ def test_oracle_all_cores_form_is_the_reference_shaped_one():
         oracle_transcript(p, 16)
 
 
-@pytest.mark.parametrize("p,n", [(GOLD, 26), (GOLD, 28), (P59, 26), (P59, 28), (GOLD, 25), (GOLD, 27)], ids=lambda v: pid(v) if v > 64 else "n%d" % v)
+@pytest.mark.parametrize("p,n", [(GOLD, 26), (GOLD, 28), (P59, 26), (P59, 28), (GOLD, 25), (GOLD, 27), (P59, 27)], ids=lambda v: pid(v) if v > 64 else "n%d" % v)
 def test_default_schedule_vs_oracle(p, n):
     """configs[2] / configs[3] on one GPU, default options: the transcript is the oracle's, the launches are the plan's"""
     pkg = load_package()

@@ -50,15 +50,20 @@ def run_vs_oracle(pkg, p, n, opts, expect_wfold=True, devices=None):
 
 @pytest.mark.parametrize("p", [GOLD, P59, 389, 5, 2**61 - 1], ids=pid)
 @pytest.mark.parametrize("n,opts", [(16, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1}),      # one block, 16 tiles
+                                    # the (5, ks) form behind it on the small tables: (5, 4) on ONE tile, (5, 5) on 4 / 8 tiles
+                                    (16, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1, "host_tail_log": 0, "wfold5_min_log": 12}),
+                                    (19, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1, "host_tail_log": 0, "wfold5_min_log": 12, "max_blocks": 3}),
                                     (18, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1, "max_blocks": 3}),
                                     (18, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1, "host_tail_log": 0}),   # the device serves every round
                                     (20, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1}),
-                                    (21, {}), (21, {"wfold_mix": 0}), (22, {"max_blocks": 5, "wfold_mix": 0}), (22, {"max_blocks": 5}), (22, {"nt_load_log": 12, "nt_store_log": 12}), (23, {"max_blocks": 64})])
+                                    (21, {}), (22, {"max_blocks": 5}), (22, {"nt_load_log": 12, "nt_store_log": 12}), (23, {"max_blocks": 64})])
 def test_wfold_pass_vs_oracle(p, n, opts):
     pkg = load_package()
-    popts = {k: v for k, v in opts.items() if k in ("first_pass_vars", "wfold_min_log", "wfold_always", "host_tail_log")}
+    popts = {k: v for k, v in opts.items() if k in ("first_pass_vars", "wfold_min_log", "wfold_always", "host_tail_log", "wfold5_min_log")}
     plan = pkg.schedule.plan_proof(n, **popts)
     assert plan[1] == {"action": "wfold_pass", "kf": 4, "ks": 5, "log_in": n, "sharded": False}, plan_str(plan)
+    if "wfold5_min_log" in opts:
+        assert plan[2]["action"] == "wfold_pass" and plan[2]["kf"] == 5 and plan[2]["ks"] == (4 if n == 16 else 5), plan_str(plan)
     run_vs_oracle(pkg, p, n, opts)
 
 
@@ -86,6 +91,7 @@ def test_planner_takes_wfold_where_it_pays():
     pkg = load_package()
     pp = pkg.schedule.plan_proof
     assert plan_str(pp(25)) == "gram_pass(0,4)@25 wfold_pass(4,5)@25 grid_pass(5,5)@21 grid_pass(5,4)@16 host_tail(4,7)@11"
+    assert plan_str(pp(28)) == "gram_pass(0,4)@28 wfold_pass(4,5)@28 wfold_pass(5,3)@24 grid_pass(3,5)@19 grid_pass(5,4)@16 host_tail(4,7)@11"
     assert pp(26)[1] == {"action": "pass", "kf": 4, "ks": 2, "log_in": 26, "sharded": False}
     for n in range(1, 21):
         assert "wfold_pass" not in plan_str(pp(n)), n

@@ -21,6 +21,7 @@ OPTION_SETS = [
     {"host_tail_log": 0}, {"host_tail_log": 3}, {"host_tail_log": 7, "grid_max_vars": 2}, {"host_tail_log": 0, "grid_pass": 0}, {"host_tail_log": 10},
     {"wfold_log": 0}, {"wfold_log": 25}, {"wfold_always": 1}, {"wfold_always": 1, "wfold_min_log": 12, "first_pass_vars": 4},
     {"wfold_always": 1, "wfold_min_log": 12, "grid_log": 26, "gram_log": 0}, {"wfold_always": 1, "host_tail_log": 0},
+    {"wfold5_min_log": 12}, {"wfold5_min_log": 12, "wfold_min_log": 12, "first_pass_vars": 4, "wfold_always": 1, "host_tail_log": 0},
 ]
 
 
@@ -70,12 +71,19 @@ def check(steps, n, world, transport, opts):
             # the fold behind a four-round first pass that serves five rounds: round 4, four pending challenges, tables (shards) of
             # 2^max(12, wfold_min_log) .. 2^wfold_log entries that keep six variables, and a grid pass must be able to take the
             # five challenges it leaves (the folded table of THAT pass <= 2^grid_log); sharded provers where they take grid passes
-            assert kf == 4 and s["ks"] == 5 and served_before == 4 and cur_log - kf >= 6 and n - served_before >= 6
-            assert max(12, opts.get("wfold_min_log", 21)) <= cur_log <= opts.get("wfold_log", 40)
-            assert cur_log - kf - 5 <= opts.get("grid_log", 20) and opts.get("grid_pass", 1) == 1 and opts.get("use_mailbox", 1) == 1
-            assert opts.get("vars_per_pass", 2) == 2 and gmax >= 5 and (not sharded or opts.get("grid_sharded", 1) == 1)
+            # ... or a grid pass with five challenges to fold over such a table, in the same kernel's (5, ks) form (never the pass that
+            # hands over to the host: those tables are small)
+            assert max(12, opts.get("wfold_min_log", 21) if kf == 4 else opts.get("wfold5_min_log", 24)) <= cur_log <= opts.get("wfold_log", 40)
+            assert opts.get("grid_pass", 1) == 1 and opts.get("use_mailbox", 1) == 1 and opts.get("vars_per_pass", 2) == 2
+            assert not sharded or opts.get("grid_sharded", 1) == 1
             nxt = steps[steps.index(s) + 1]
-            assert nxt["action"] == "grid_pass" and nxt["kf"] == 5
+            if kf == 4:
+                assert s["ks"] == 5 and served_before == 4 and cur_log - kf >= 6 and n - served_before >= 6 and gmax >= 5
+                assert cur_log - kf - 5 <= opts.get("grid_log", 20)
+                assert nxt["action"] in ("grid_pass", "wfold_pass") and nxt["kf"] == 5
+            else:
+                assert kf == 5 and 3 <= s["ks"] <= gmax and cur_log - kf <= opts.get("grid_log", 20) and cur_log >= kf + s["ks"]
+                assert nxt["action"] != "host_tail"
             cur_log -= kf
         elif s["action"] == "pass":
             assert (kf <= 3 or (kf == 4 and s["ks"] == 2 and steps[0]["action"] == "gram_pass")) and 1 <= s["ks"] <= 3
@@ -113,23 +121,25 @@ def test_plan_invariants(plan, opts):
 def test_known_schedules(plan):
     def sig(steps):
         return [(s["action"], s["kf"], s["ks"], s["log_in"]) for s in steps]
+    W525 = "grid_pass"        # (the (5, ks) form of the streaming kernel: from 2^24-entry tables, wfold5_min_log)
 
     # the headline: n = 28 on one GPU (bench.py config.schedule of every run): four rounds from the matrix-core pass, five from the
     # fold behind it (wfold_pass_kernel), three grid passes of 27 / 243 / 81 cells, and the host finishes from the 2^11-entry
     # tables the fifth launch leaves: FIVE launches (round 4: seven; the 27-cell first pass, gram_log = 0, needs seven)
-    assert sig(plan(28)) == [("gram_pass", 0, 4, 28), ("wfold_pass", 4, 5, 28), ("grid_pass", 5, 3, 24), ("grid_pass", 3, 5, 19),
+    # (the third launch folds five challenges over 2^24-entry tables: the streaming kernel's (5, 3) form)
+    assert sig(plan(28)) == [("gram_pass", 0, 4, 28), ("wfold_pass", 4, 5, 28), ("wfold_pass", 5, 3, 24), ("grid_pass", 3, 5, 19),
                              ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
     assert sig(plan(28, wfold_log=0)) == [("gram_pass", 0, 4, 28), ("pass", 4, 2, 28), ("pass", 2, 2, 24), ("grid_pass", 2, 4, 22),
                                           ("grid_pass", 4, 5, 20), ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
     # (round 5's first half: the host took over at 2^10 entries wherever the even split happened to pass that size)
     assert sig(plan(28, wfold_log=0, host_tail_log=10)) == [("gram_pass", 0, 4, 28), ("pass", 4, 2, 28), ("pass", 2, 2, 24), ("grid_pass", 2, 5, 22),
                                                              ("grid_pass", 5, 5, 20), ("grid_pass", 5, 5, 15), ("host_tail", 5, 5, 10)]
-    assert sig(plan(28, host_tail_log=0)) == [("gram_pass", 0, 4, 28), ("wfold_pass", 4, 5, 28), ("grid_pass", 5, 5, 24), ("grid_pass", 5, 5, 19),
+    assert sig(plan(28, host_tail_log=0)) == [("gram_pass", 0, 4, 28), ("wfold_pass", 4, 5, 28), ("wfold_pass", 5, 5, 24), ("grid_pass", 5, 5, 19),
                                               ("grid_pass", 5, 5, 14), ("grid_pass", 5, 4, 9)]
     assert sig(plan(28, gram_log=0)) == [("pass", 0, 3, 28), ("pass", 3, 2, 28), ("pass", 2, 2, 25), ("pass", 2, 2, 23), ("grid_pass", 2, 3, 21),
                                          ("grid_pass", 3, 5, 19), ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
     # the shard of an 8-GPU run as a proof of its own: FOUR launches (round 4: seven; first half of round 5: five)
-    assert sig(plan(25)) == [("gram_pass", 0, 4, 25), ("wfold_pass", 4, 5, 25), ("grid_pass", 5, 5, 21), ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
+    assert sig(plan(25)) == [("gram_pass", 0, 4, 25), ("wfold_pass", 4, 5, 25), (W525, 5, 5, 21), ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
     assert sig(plan(25, wfold_log=0)) == [("gram_pass", 0, 4, 25), ("pass", 4, 2, 25), ("grid_pass", 2, 3, 21), ("grid_pass", 3, 5, 19),
                                           ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
     # the wfold pass is taken where it saves a launch (25, 27, 28, 29) or replaces a grid pass over the whole table (21 .. 24), not
@@ -196,8 +206,8 @@ def test_plan_options_struct_is_versioned():
     assert lib.sc_abi_version() == L.ABI_VERSION == 5
     full = L.ScPlanOptions()
     lib.sc_plan_options_default(ctypes.byref(full), ctypes.sizeof(full))
-    assert full.struct_size == ctypes.sizeof(full) == 56 and full.host_tail_log == 11 and full.gram_log == 21
-    assert (full.wfold_log, full.wfold_min_log, full.wfold_always) == (40, 21, 0)
+    assert full.struct_size == ctypes.sizeof(full) == 60 and full.host_tail_log == 11 and full.gram_log == 21
+    assert (full.wfold_log, full.wfold_min_log, full.wfold_always, full.wfold5_min_log) == (40, 21, 0, 24)
 
     class Old(ctypes.Structure):      # a caller built before host_tail_log existed, with a guard word behind its struct
         _fields_ = [("struct_size", ctypes.c_uint32)] + [(k, ctypes.c_int32) for k in (

@@ -33,7 +33,7 @@ ABI_VERSION = 5   # SC_ABI_VERSION of include/sumcheck_hip.h as this binding was
 class ScPlanOptions(ctypes.Structure):
     _fields_ = [("struct_size", ctypes.c_uint32)] + [
         (k, ctypes.c_int32) for k in ("vars_per_pass", "first_pass_vars", "grid_pass", "grid_log", "grid_max_vars", "grid_sharded",
-                                      "tail_log", "use_mailbox", "gram_log", "host_tail_log", "wfold_log", "wfold_min_log", "wfold_always")]
+                                      "tail_log", "use_mailbox", "gram_log", "host_tail_log", "wfold_log", "wfold_min_log", "wfold_always", "wfold5_min_log")]
 
 
 class ScPlanStep(ctypes.Structure):

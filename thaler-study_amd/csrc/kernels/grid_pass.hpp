@@ -454,36 +454,44 @@ wgrid_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
 }
 
 // ------------------------------------------------------------------------------------
-// wfold_pass_kernel (round 5): the fold behind the matrix-core first pass that serves FIVE rounds.
+// wfold_pass_kernel (round 5): a fold of four or five challenges over a LARGE table that serves up to five rounds.
 //
-// On a 2^25-entry shard the fold pass (pass_kernel<4,2>, 100 us) and the five-round pass behind it (28 us + a launch) are a third
-// of the proof, and what separates them is not work but a launch: the fold is bound by memory (28 % VALU-busy), the five-round
-// pass by instruction issue per folded entry.  This kernel is pass_kernel<4,.>'s front end - a wave streams 8 KiB sub-steps of
-// both tables (lane <-> 16-byte piece, 1 KiB contiguous per instruction), bounces them through its private LDS region so that
-// every lane folds ITS sixteen entries with one lazy sum, the sub-steps of the two tables rotated against each other and from
-// wave to wave so that the chip's requests cover all HBM channels - with wgrid_pass_kernel<F, 5>'s back end: the tile's 256
-// folded entries per table are eight groups of 32; per group the 64 lanes drop the entries into the wave's extension arrays,
-// fill the {0,1,inf}^5 grid level by level (LDS addresses decoded once) and multiply the 243 cell pairs into four lazy
-// accumulators per lane.  ~2.3x the instructions of the two-round fold, still under its memory time; one launch and one trip to
-// the host less, and the pass behind it reads a 32nd of the tables with five challenges to fold.  Whole tiles only (tables of
-// >= 2^12 entries); cells leave exactly as wgrid_pass_kernel's (wgrid_finish).
+// On a 2^25-entry shard the fold pass behind the matrix-core pass (pass_kernel<4,2>, 100 us) and the five-round pass behind it
+// (26 us + a launch) are a third of the proof, and what separates them is not work but a launch: the fold is bound by memory
+// (28 % VALU-busy), the five-round pass by instruction issue per folded entry.  This kernel is pass_kernel<4,.>'s front end - a
+// wave streams 8 KiB sub-steps of both tables (lane <-> 16-byte piece, 1 KiB contiguous per instruction), bounces them through
+// its private LDS region so that every lane folds ITS sixteen entries with one lazy sum, the order of the sub-steps rotated from
+// wave to wave so that the chip's requests cover all HBM channels - with wgrid_pass_kernel<F, KS>'s back end: every sub-step
+// leaves 64 (KF = 4) or 32 (KF = 5: the halves of an output sit in neighbouring lanes, out = h0 + r_5 (h1 - h0)) folded entries
+// per table, i.e. two or one iterations of wgrid_body - the 64 lanes drop 32 entries per table into the wave's extension arrays,
+// fill the {0,1,inf}^KS grids level by level (LDS addresses decoded once) and multiply the cell pairs into four lazy
+// accumulators per lane - done right behind the sub-step, while the next sub-step's loads are in flight (behind the whole tile
+// instead: +3 us at n = 25).  (4, 5): ~2.3x the instructions of the two-round fold, still under its memory time - 112 us against
+// 101 + 26 + a trip to the host at n = 25; (5, ks) on 2^23..2^25-entry tables: what wgrid_pass_kernel - made for tables that sit
+// in the caches - streams at 4.5 TB/s.  Whole tiles only (tables of >= 2^12 entries); cells leave exactly as
+// wgrid_pass_kernel's (wgrid_finish).  r_top: the fifth challenge (KF = 5), in the tables' representation.
 constexpr int kWfThreads = 512;
-template <class F, int NT>
+template <class F, int KF, int KS, bool NT>
 __global__ void __launch_bounds__(kWfThreads)
 wfold_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64* __restrict__ A2, u64* __restrict__ B2, FoldW fw,
-                  size_t n_tiles, WgOut out) {
-  constexpr bool kNtLoad = (NT & 1) != 0, kNtStore = (NT & 2) != 0, kMix = (NT & 4) != 0;
-  constexpr int KS = 5, cells = 243, OUT = 4, NPS = 8, NP = 32, NPO = 2;   // a tile: 4 sub-steps of 64 outputs x 16 entries per table
+                  u64 r_top, size_t n_tiles, WgOut out) {
+  static_assert(KF == 4 || KF == 5, "four or five pending challenges");
+  static_assert(KS >= 1 && KS <= 5, "one to five rounds");
+  constexpr int OUT = 4, NPS = 8, NP = 32;          // a tile: 4 sub-steps of 8 KiB (1024 entries) per table
+  constexpr int OUTS = kWave >> (KF - 4);           // folded entries per table and sub-step
+  constexpr int TILE_OUT = OUT * OUTS;              // ... and tile (256 / 128)
+  constexpr int NPO = TILE_OUT / (2 * kWave);       // 16-byte stores per lane, table and tile (2 / 1)
   constexpr int kWaves = kWfThreads / kWave;
   constexpr int kPow3[6] = {1, 3, 9, 27, 81, 243};
-  // per wave: 8 KiB sub-step | 4 KiB tile outputs (256 + 256) | 4 KiB extension arrays [table][256]
+  constexpr int cells = kPow3[KS], G = 1 << KS, gpi = kWgEntries >> KS, pairs = gpi * cells;
+  // per wave: 8 KiB sub-step | 4 KiB tile outputs [table][256] | 4 KiB extension arrays [table][256]
   constexpr int kRegionWords = 1024 + 512 + 512;
   __shared__ u64 lds_all[kWaves * kRegionWords];
   __shared__ int cell_of[kWgEntries], suffix_of[kWgEntries];
   __shared__ unsigned lds_next;
   typedef __attribute__((address_space(3))) u64 lds_u64;
   const int tid = threadIdx.x, lane = tid & (kWave - 1), wave = tid / kWave;
-  if (tid < kWgEntries) {
+  if (tid < kWgEntries) {   // (wgrid_body's tables)
     int c = 0, u = 0, p3 = 1;
     for (int m = 0; m < KS; ++m) {
       c += ((tid >> (KS - 1 - m)) & 1) * p3;
@@ -499,11 +507,11 @@ wfold_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
   u64* const xchg = lds_all + (size_t)wave * kRegionWords + 1024;
   u64* const ef = xchg + 512;
   const int tbl = lane >> 5, ent = lane & (kWgEntries - 1);
-  const int slot = tbl * kGridChunk + cell_of[ent];
+  const int slot = tbl * kGridChunk + (ent >> KS) * cells + cell_of[ent & (G - 1)];
   unsigned step[KS][3];
 #pragma clang loop unroll(full)
   for (int j = 0; j < KS; ++j) {
-    const int low = KS - 1 - j, pj = kPow3[j], stride = kPow3[low], items = pj << low;   // per table (one group of 32)
+    const int low = KS - 1 - j, pj = kPow3[j], stride = kPow3[low], items = (gpi * pj) << low;   // per table (32 entries)
     const unsigned inv = (1u << 20) / (unsigned)pj + 1u;
 #pragma clang loop unroll(full)
     for (int q = 0; q < 3; ++q) {
@@ -535,12 +543,13 @@ wfold_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
   auto load_sub = [&](const ull2* __restrict__ T, size_t tile, int o, ull2 (&p)[NPS]) {
     const ull2* src = T + tile * kWave * NP + (size_t)o * NPS * kWave + lane;
 #pragma unroll
-    for (int k = 0; k < NPS; ++k) p[k] = ld16<kNtLoad>(src + k * kWave);
+    for (int k = 0; k < NPS; ++k) p[k] = ld16<NT>(src + k * kWave);
   };
   auto stash = [&](const ull2 (&p)[NPS]) {
 #pragma unroll
     for (int k = 0; k < NPS; ++k) reg[swz_slot<NPS>(64 * k + lane)] = p[k];
   };
+  // the lane's sixteen entries under the first four challenges; KF = 5: the pair of lanes (2o, 2o + 1) holds the halves of output o
   auto fold16 = [&]() -> u64 {
     typename F::Acc3 sacc;
     f.acc3_zero(sacc);
@@ -550,9 +559,22 @@ wfold_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
       f.acc3_mac(sacc, x.x, fw.w[2 * m]);
       f.acc3_mac(sacc, x.y, fw.w[2 * m + 1]);
     }
-    return f.acc3_get(sacc);
+    const u64 h = f.acc3_get(sacc);
+    if constexpr (KF == 5) {
+      const u64 hn = __shfl_xor(h, 1);
+      return f.add(h, f.mul(r_top, f.sub(hn, h)));   // (what the even lane holds is the output)
+    } else {
+      return h;
+    }
   };
-  // the 243 cells over one group of 32 folded entries per table (wgrid_body's iteration, KS = 5)
+  auto put = [&](u64* dst, int o, u64 x) {   // sub-step o's outputs into the tile's exchange area
+    if constexpr (KF == 5) {
+      if ((lane & 1) == 0) dst[OUTS * o + (lane >> 1)] = x;
+    } else {
+      dst[OUTS * o + lane] = x;
+    }
+  };
+  // the cells over 32 folded entries per table (wgrid_body's iteration)
   auto grid_group = [&](int grp) {
     ef[slot] = xchg[kWave * OUT * tbl + kWgEntries * grp + ent];
     wave_lds_sync();
@@ -561,7 +583,7 @@ wfold_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
       const int st = kPow3[KS - 1 - j];
 #pragma clang loop unroll(full)
       for (int q = 0; q < 3; ++q) {
-        if (2 * (kPow3[j] << (KS - 1 - j)) > kWave * q) {
+        if (2 * ((gpi * kPow3[j]) << (KS - 1 - j)) > kWave * q) {
           const unsigned d = step[j][q];
           if (d != 0) {
             lds_u64* const x = (lds_u64*)(size_t)(d & 0x7FFFFFFFu);
@@ -574,7 +596,7 @@ wfold_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
       const int p = lane + kWave * k;
-      if (p < cells) f.acc_mac(acc[k], ef[p], ef[kGridChunk + p]);
+      if (p < pairs) f.acc_mac(acc[k], ef[p], ef[kGridChunk + p]);
     }
     wave_lds_sync();
   };
@@ -582,31 +604,30 @@ wfold_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
   size_t tile = next_tile();
   if (tile < n_tiles) {
     load_sub(Ap, tile, rot, pa);
-    load_sub(Bp, tile, kMix ? rot : rot ^ 2, pb);
+    load_sub(Bp, tile, rot, pb);
   }
   while (tile < n_tiles) {
     const size_t next = next_tile();
 #pragma unroll
     for (int i = 0; i < OUT; ++i) {
-      const int oa = (i + rot) & 3, ob = kMix ? oa : oa ^ 2, na = (i + 1 + rot) & 3, nb = kMix ? na : na ^ 2;
+      const int o = (i + rot) & 3, no = (i + 1 + rot) & 3;
       stash(pa);
       wave_lds_sync();
-      if (i + 1 < OUT) load_sub(Ap, tile, na, pa);
-      else if (next < n_tiles) load_sub(Ap, next, na, pa);
+      if (i + 1 < OUT) load_sub(Ap, tile, no, pa);
+      else if (next < n_tiles) load_sub(Ap, next, no, pa);
       const u64 xa = fold16();
       wave_lds_sync();
       stash(pb);
       wave_lds_sync();
-      if (i + 1 < OUT) load_sub(Bp, tile, nb, pb);
-      else if (next < n_tiles) load_sub(Bp, next, nb, pb);
+      if (i + 1 < OUT) load_sub(Bp, tile, no, pb);
+      else if (next < n_tiles) load_sub(Bp, next, no, pb);
       const u64 xb = fold16();
-      xchg[kWave * oa + lane] = xa;
-      xchg[kWave * OUT + kWave * ob + lane] = xb;
+      put(xchg, o, xa);
+      put(xchg + kWave * OUT, o, xb);
       wave_lds_sync();
-      if constexpr (kMix) {   // the two groups this sub-step completed, while the next sub-step's loads are in flight
+      // the groups this sub-step completed, while the next sub-step's loads are in flight
 #pragma unroll 1
-        for (int g = 0; g < 2; ++g) grid_group(2 * oa + g);
-      }
+      for (int g = 0; g < OUTS / kWgEntries; ++g) grid_group(o * (OUTS / kWgEntries) + g);
     }
     // the folded tables: the exchange area holds the tile's outputs in index order - stored straight out of it
     {
@@ -615,16 +636,11 @@ wfold_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
 #pragma unroll
       for (int k = 0; k < NPO; ++k) {
         const size_t q = o0 + (size_t)k * kWave + lane;
-        st16<kNtStore>(A2p + q, xo[kWave * k + lane]);
-        st16<kNtStore>(B2p + q, xo[kWave * NPO + kWave * k + lane]);
+        st16<false>(A2p + q, xo[kWave * k + lane]);
+        st16<false>(B2p + q, xo[kWave * OUT / 2 + kWave * k + lane]);
       }
     }
-    if constexpr (!kMix) {
-#pragma unroll 1
-      for (int grp = 0; grp < 2 * OUT; ++grp) grid_group(grp);
-    } else {
-      wave_lds_sync();   // (the stores' LDS reads before the next tile's outputs)
-    }
+    wave_lds_sync();   // (the stores' LDS reads before the next tile's outputs)
     if (wave == 0 && blockIdx.x < 8) asm volatile("buffer_wbl2 sc1" ::: "memory");   // (the bulk write-back hint of pass_kernel's pipelined forms)
     tile = next;
   }
@@ -634,12 +650,13 @@ wfold_pass_kernel(F f, const u64* __restrict__ A, const u64* __restrict__ B, u64
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int p = lane + kWave * k;
-    red[wave * kGridChunk + p] = (p < cells) ? f.acc_get(acc[k]) : 0;
+    red[wave * kGridChunk + p] = (p < pairs) ? f.acc_get(acc[k]) : 0;
   }
   __syncthreads();
   u64 total = 0;
   if (tid < cells) {
-    for (int w = 0; w < kWaves; ++w) total = f.add(total, red[w * kGridChunk + tid]);
+    for (int w = 0; w < kWaves; ++w)
+      for (int g = 0; g < gpi; ++g) total = f.add(total, red[w * kGridChunk + g * cells + tid]);
   }
   wgrid_finish<F, KS>(f, total, out);
 }

@@ -147,8 +147,8 @@ struct sc_ctx {
   int host_tail_log = kTailLogMax;   // folded tables of <= 2^this entries go to pinned host memory and the host finishes the proof (0: off)
   int wfold_log = 40;                // the fold behind the matrix-core first pass serves FIVE rounds (wfold_pass_kernel) on tables of <= 2^this entries (0: never)
   int wfold_min_log = 21;            // ... and of >= 2^this entries (below, a five-round grid pass folds the four challenges)
+  int wfold5_min_log = 24;           // a grid pass with FIVE challenges to fold over tables of >= 2^this entries runs in the same kernel's (5, ks) form
   int wfold_always = 0;              // 0: where the proof then needs fewer launches (the planner counts both ways); 1: wherever it can run
-  int wfold_mix = 1;                 // its grid work spread over the sub-steps of a tile (two groups behind each) instead of behind the tile
   int wfold_blocks = 0;              // its resident grid (0 = not asked yet)
   int tail_log = 16;  // shard log-size at which a sharded prover gathers: a 512 KiB all-gather per table is
                       // cheaper than the ~25 us of collective latency of each further sharded pass
