@@ -52,12 +52,19 @@ def parity(pkg, dist, pyref, Oracle, rank, world):
         attach(pkg, ctx, rank, world)
         # grid_sharded 1: the shards go on with five-round passes (cells exchanged inside the kernel) down to one entry;
         # 0: two-round passes with the exchange, gather at tail_log, unsharded tail
-        for n, tail_log, gs in [(1, 0, 1), (2, 0, 1), (5, 0, 1), (12, 0, 1), (12, 5, 0), (12, 0, 0), (16, 12, 1), (16, 12, 0), (20, 16, 1),
-                                (20, 16, 0), (22, 16, 1)]:
+        # WF: the matrix-core first pass and wfold_pass_kernel - (4, 5), then (5, ks) - on the (small) shards; its cells cross the ranks
+        # like a grid pass's
+        WF = {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1, "wfold5_min_log": 12}
+        WF_OFF = {"first_pass_vars": 0, "wfold_min_log": 21, "wfold_always": 0, "wfold5_min_log": 24}
+        for n, tail_log, gs, extra in [(1, 0, 1, None), (2, 0, 1, None), (5, 0, 1, None), (12, 0, 1, None), (12, 5, 0, None), (12, 0, 0, None),
+                                       (16, 12, 1, None), (16, 12, 0, None), (20, 16, 1, None), (20, 16, 0, None), (22, 16, 1, None),
+                                       (21, 0, 1, WF), (22, 0, 1, WF)]:
             if n < world.bit_length() - 1:
                 continue            # fewer entries than ranks
             ctx.set_option("tail_log", tail_log)
             ctx.set_option("grid_sharded", gs)
+            for k, v in (extra or WF_OFF).items():
+                ctx.set_option(k, v)
             a, b, nl = shard_tables(pkg, ctx, pyref, n, rank, world)
             g = pkg.matrix_multiplication.G(a, b)
             assert g.num_vars() == n
@@ -67,6 +74,8 @@ def parity(pkg, dist, pyref, Oracle, rank, world):
             c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
             log = ctx.launch_log(reset=True)
             ctx.set_option("time_kernels", 0)
+            if extra:
+                assert [r["kind"] for r in log][:3] == ["gram_pass", "wfold_pass", "wfold_pass"], log
             if gs and nl >= 6 and TRANSPORT == "peer":      # the shard's own variables are served five at a time, then one small launch for the rank bits
                 assert [r["kind"] for r in log].count("grid_pass") >= 2 and log[-1]["log_in"] <= 5 + world.bit_length() - 1, log
             final = g.evaluate([int(x) for x in ch])

@@ -48,7 +48,7 @@ class Loopback:
         return allreduce, allgather
 
 
-def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove", transport="host"):
+def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove", transport="host", extra=None):
     lb = Loopback(world)
     results = [None] * world
     errors = []
@@ -61,6 +61,8 @@ def run_virtual_ranks(pkg, p, n, world, tail_log, vpp, what="prove", transport="
             ctx.set_option("vars_per_pass", min(vpp, 2))
             ctx.set_option("first_pass_vars", vpp if vpp >= 3 else min(vpp, 2))    # (4: the matrix-core first pass on the shards)
             ctx.set_option("grid_pass", 1 if vpp >= 3 else 0)
+            for k, v in (extra or {}).items():
+                ctx.set_option(k, v)
             if transport == "peer":
                 # in-kernel exchange through peer-mapped inboxes; threads of one process share the address space
                 ctx.set_option("peer_spin_ms", 20000)
@@ -125,6 +127,30 @@ def test_virtual_ranks_match_oracle(p, world, vpp):
         if tail_log == 0 and n - g >= 4:
             assert lb.n_allreduce >= 2
         assert lb.n_allgather >= 2  # the tail gather of both tables
+
+
+WFOLD_ON_SMALL_SHARDS = {"wfold_min_log": 12, "wfold_always": 1, "wfold5_min_log": 12}
+
+
+@pytest.mark.parametrize("transport,world", [("host", 2), ("host", 8), ("peer", 2)])
+@pytest.mark.parametrize("p", [GOLD, 2**64 - 59], ids=pid)
+def test_virtual_ranks_wfold_pass_on_the_shards(p, transport, world):
+    """wfold_pass_kernel on the shards of the rank transports (its cells cross the ranks as a grid pass's: split limbs through the
+    collective / the in-kernel exchange): matrix-core first pass, (4, 5) fold, and the (5, ks) form behind it, on shards of
+    2^17 .. 2^19 entries - every rank's transcript is the oracle's"""
+    pkg = load_package()
+    o = oracle(p)
+    g = world.bit_length() - 1
+    for n in (20, 21):
+        plan = pkg.schedule.plan_proof(n, world, transport, first_pass_vars=4, **WFOLD_ON_SMALL_SHARDS)
+        assert [s["action"] for s in plan][:3] == ["gram_pass", "wfold_pass", "wfold_pass"] and all(s["sharded"] for s in plan[:3]), plan
+        oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+        ref = o.prove(oa, ob, challenges(o, n))
+        results, _ = run_virtual_ranks(pkg, p, n, world, 0, 4, transport=transport, extra=WFOLD_ON_SMALL_SHARDS)
+        for rank, (c1, evals, chn, final, e0, s0) in enumerate(results):
+            assert c1 == ref["c_1"], (n, rank)
+            assert np.array_equal(evals, ref["evals"]), (n, rank)
+            assert final == ref["final_eval"] and s0 == ref["c_1"]
 
 
 def test_rccl_world1():
