@@ -85,6 +85,8 @@ def _kernel_name(rec):
         return "sc::pass_kernel<GoldilocksMont,%d,%d> on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
     if k == "grid_pass":
         return "sc::wgrid_pass_kernel<GoldilocksMont,ks> (kf=%d, ks=%d) on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
+    if k == "wfold_pass":
+        return "sc::wfold_pass_kernel<GoldilocksMont,%d,%d> on 2^%d-entry tables" % (rec["kf"], rec["ks"], rec["log_in"])
     if k == "gram_pass":      # field-agnostic: exact integer limb products on the int8 matrix cores (kernels/gram.hpp)
         return "sc::gram_pass_kernel<%d> (rounds 1..%d from one read) on 2^%d-entry tables" % (rec["ks"], rec["ks"], rec["log_in"])
     if k == "gram_finish":
@@ -535,10 +537,11 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
     # the first folding pass of a 2^28-entry proof has two speeds, box to box and context to context (DESIGN.md section 11,
     # experiments/r03_fold_pass_two_modes.md, experiments/r04_vmm_placement.md): say which one this run drew
     fold_pass_mode = None
-    fp_rec = next((k for k in kernels if k["_key"][0] == "pass" and k["_key"][1] in (3, 4) and k["_key"][2] == 2 and k["_key"][3] >= 27), None)
+    fp_rec = next((k for k in kernels if ((k["_key"][0] == "pass" and k["_key"][1] in (3, 4) and k["_key"][2] == 2) or
+                                          (k["_key"][0] == "wfold_pass" and k["_key"][1] == 4)) and k["_key"][3] >= 27), None)
     if fp_rec and fp_rec["GBps"]:
         fold_pass_mode = {"mode": "fast" if fp_rec["GBps"] >= 5900.0 else "slow", "GBps": fp_rec["GBps"], "avg_us": fp_rec["avg_us"],
-                          "note": "the first folding pass (pass_kernel<3,2>, or <4,2> behind the four-round first pass) on the caller's tables: 'fast' >= 5.9 TB/s (reads at 6.9 + writes at 4.6 TB/s add up), "
+                          "note": "the first folding pass (wfold_pass_kernel<4,5> behind the four-round first pass; pass_kernel<4,2> / <3,2> in the other schedules) on the caller's tables: 'fast' >= 5.9 TB/s (reads at 6.9 + writes at 4.6 TB/s add up), "
                                   "'slow' is what a plain 8:1 read/write stream gets on the same box (5.4-5.8 TB/s)"}
 
     result = None

@@ -59,6 +59,9 @@ def describe(name):
         return "gram_finish", 0, int(m.group(1))
     if "wgrid_pass_kernel<" in name:
         return "grid_pass", -1, -1       # kf, ks from bench.py's schedule
+    m = re.search(r"wfold_pass_kernel<sc::\w+, (\d), (\d), \w+>", name)
+    if m:
+        return "wfold_pass", int(m.group(1)), int(m.group(2))
     m = re.search(r"pass_kernel<sc::\w+, (\d), (\d)(?:, \d+)?>", name)
     if m:
         return "pass", int(m.group(1)), int(m.group(2))
@@ -119,6 +122,8 @@ def _bench_name(kind, kf, ks, log_in):
         return "sc::pass_kernel<GoldilocksMont,%d,%d> on 2^%d-entry tables" % (kf, ks, log_in)
     if kind == "grid_pass":
         return "sc::wgrid_pass_kernel<GoldilocksMont,ks> (kf=%d, ks=%d) on 2^%d-entry tables" % (kf, ks, log_in)
+    if kind == "wfold_pass":
+        return "sc::wfold_pass_kernel<GoldilocksMont,%d,%d> on 2^%d-entry tables" % (kf, ks, log_in)
     if kind == "gram_pass":
         return "sc::gram_pass_kernel<%d> (rounds 1..%d from one read) on 2^%d-entry tables" % (ks, ks, log_in)
     if kind == "gram_finish":
