@@ -120,12 +120,20 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      with gram_pass_kernel: rounds 1..4 from ONE read, as exact integer limb products of the tables'
  *                      bytes on the int8 matrix cores; every block reduces its accumulators to the 81 cells mod p and the
  *                      block that finishes last adds them (ONE launch since round 5); the pass behind it folds four
- *                      variables (pass_kernel<4,2>).  DESIGN.md section 4
- *   "host_tail_log"    (default 10; 0..10) the host finishes the proof: a pass whose folded tables have <= 2^host_tail_log
+ *                      variables (wfold_pass_kernel<4,5>, or pass_kernel<4,2>: below).  DESIGN.md section 4
+ *   "wfold_log"        (default 40; 0 = never, else 12..40) the pass behind the matrix-core pass - four pending challenges, round 4 -
+ *                      on tables (shards) of 2^"wfold_min_log" (default 21) .. 2^wfold_log entries may be wfold_pass_kernel<4,5>:
+ *                      it folds the four challenges AND serves FIVE rounds (pass_kernel<4,2>: two).  Taken where the proof then
+ *                      needs fewer launches (the planner counts both ways: n = 25, 27, 28, 29 on one device) or where the
+ *                      alternative is a grid pass streaming the whole table (n = 21..24); "wfold_always" = 1: wherever it can
+ *                      run.  "wfold5_min_log" (default 24): a grid pass with FIVE challenges to fold over tables of >= 2^this
+ *                      entries runs in the same kernel's (5, 3..5) form.  Same results; DESIGN.md sections 4, 5
+ *   "host_tail_log"    (default 11; 0..11) the host finishes the proof: a pass whose folded tables have <= 2^host_tail_log
  *                      entries (per device on a multi-device handle) writes them to pinned host memory instead of the
  *                      pool, and every later round is served by the host from them - fold the pending challenges
- *                      (<= 2^11 multiply-adds), then one sub-microsecond round at a time - with NO further launch: the
- *                      last launch (or two) of every proof and every shard, ~13 us each, disappears.  Not a CPU path
+ *                      (<= 2^12 multiply-adds), then one sub-microsecond round at a time - with NO further launch: the
+ *                      last launch (or two) of every proof and every shard, ~13 us each, disappears; the planner aims its
+ *                      grid passes at this hand-over (fewest launches up to it, fewest rounds per pass among those).  Not a CPU path
  *                      for the hot loop: what the host touches is what is left when 2^-18 of the work remains.  Applies
  *                      to unsharded provers (incl. a sharded one after its gather) and to multi-device handles; five-round
  *                      passes (and any pass with <= 32 outputs) hand over, 0 = off (a multi-device handle then hands
@@ -196,7 +204,7 @@ int sc_ctx_kernel_time(sc_ctx* ctx, double out[2], int reset);
 /* 9 was the resident prover kernel (removed in round 3: measured equal to launches) */
 #define SC_KIND_GRID_PASS 10 /* wgrid_pass_kernel: fold kf <= 5 variables of tables of <= 2^20 folded entries + the 3^ks cells of ks <= 5 rounds */
 #define SC_KIND_GRAM_PASS 11   /* gram_pass_kernel: the four-round first pass of a large proof on the int8 matrix cores (ks = 4) */
-#define SC_KIND_WFOLD_PASS 13  /* wfold_pass_kernel: the fold behind the matrix-core first pass serving five rounds (kf = 4, ks = 5; shards and tables of <= 2^wfold_log entries) */
+#define SC_KIND_WFOLD_PASS 13  /* wfold_pass_kernel: a fold of kf = 4 / 5 variables of large tables that serves ks = 5 / 3..5 rounds (behind the matrix-core first pass; the pass behind that) */
 /* 12 was gram_finish_kernel (rounds 4: a second launch behind the gram pass; folded into gram_pass_kernel in round 5) */
 typedef struct sc_launch_record {
   int32_t kind;           /* SC_KIND_* */
@@ -328,7 +336,8 @@ int sc_prover_num_vars(const sc_prover* pr, size_t* out);
                               * wrote to pinned host memory (log_in = log2 entries per table and device) and serves every remaining
                               * round (ks) itself; no launch.  Always the last step */
 #define SC_PLAN_GRAM_PASS 5  /* gram_pass_kernel: rounds 1..4 of a proof on tables (shards) of >= 2^gram_log entries */
-#define SC_PLAN_WFOLD_PASS 6 /* wfold_pass_kernel: folds the four challenges of the matrix-core pass AND serves five rounds (tables of 2^12 .. 2^wfold_log entries) */
+#define SC_PLAN_WFOLD_PASS 6 /* wfold_pass_kernel: folds kf = 4 challenges (behind the matrix-core pass) and serves five rounds, or kf = 5 and ks = 3..5
+                              * on tables of >= 2^wfold5_min_log entries: the streaming fold with a grid pass's cells */
 /* ABI version of this header: bumped whenever a struct below grows or an enum is extended.  sc_abi_version()
  * returns the library's; a caller built against another major version must not pass structs.  Version 5 = round 5. */
 #define SC_ABI_VERSION 5
