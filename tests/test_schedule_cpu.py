@@ -184,6 +184,24 @@ def test_known_schedules(plan):
     assert len(plan(16, host_tail_log=10)) == 4
 
 
+def test_new_planner_never_needs_more_launches(plan):
+    """aiming at the hand-over and the five-round fold only ever remove launches: against the even split with the hand-over at
+    2^10 entries (round 5's first half) and against the device alone, for whole provers and the shards of a handle"""
+    def launches(steps):
+        return sum(1 for s in steps if s["action"] != "host_tail")
+    for world, transport in [(1, "none"), (2, "local"), (8, "local")]:
+        g = world.bit_length() - 1
+        for n in range(max(g, 1), 41):
+            new = launches(plan(n, world, transport))
+            assert new <= launches(plan(n, world, transport, wfold_log=0, host_tail_log=10)), (n, world)
+            assert new <= launches(plan(n, world, transport, wfold_log=0)), (n, world)
+            assert new <= launches(plan(n, world, transport, host_tail_log=0)), (n, world)
+    # the rank transports never hand over while sharded: the wfold pass must not cost them a launch either
+    for world, transport in [(2, "peer"), (8, "peer"), (8, "rccl"), (4, "host")]:
+        for n in range(world.bit_length() - 1, 41):
+            assert launches(plan(n, world, transport)) <= launches(plan(n, world, transport, wfold_log=0)), (n, world, transport)
+
+
 def test_plan_argument_checks(plan):
     pkg = load_package()
     for bad in [dict(num_vars=2, world=8, transport="peer"), dict(num_vars=10, world=3, transport="peer"),

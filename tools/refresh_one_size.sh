@@ -1,4 +1,4 @@
-TAG=r05; NV=25
+TAG=${1:-r05}; NV=${2:-25}   # tools/refresh_one_size.sh <tag> <n>: one prover size of refresh_profiles.sh alone (un-profiled line, stats, two PMC passes, summary)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp; export SC_BENCH_RAMP_MS=0
 mkdir -p $O/profiles_$TAG
