@@ -137,3 +137,34 @@ def test_block_per_cu_instantiations_fit_one_cu(isa):
         assert u["ScratchSize [bytes/lane]"] == 0, (frag, u)
         body = kernel_body(text, frag)
         assert re.search(r"ds_add_rtn_u32", body), frag               # the tile counter
+
+
+def test_wfold_pass_is_what_the_design_says(isa):
+    """kernels/grid_pass.hpp, wfold_pass_kernel: two waves per SIMD and one block per CU (131 KB of LDS), nothing in scratch, the
+    nontemporal hint on the NT instances' loads and on none of the others', and the sub-step's eight loads issued as one batch
+    (no load waits for an LDS operation of the same sub-step in between: the batch is what keeps 16 KiB per wave in flight)"""
+    text, usage = isa
+    for fld in (GOLD, "INS_11MontGenericE"):
+        for kf, ks in ((4, 5), (5, 3), (5, 4), (5, 5)):
+            u = kernel_usage(usage, "wfold_pass_kernel%sLi%dELi%dELb1E" % (fld, kf, ks))
+            # (the generic field's constants + sixteen weights + the exchange descriptor: a couple of SGPRs go to VGPR lanes, never to memory)
+            assert u["ScratchSize [bytes/lane]"] == 0 and u["VGPRs Spill"] == 0 and u["SGPRs Spill"] <= (0 if fld == GOLD else 4), (fld, kf, ks, u)
+            assert u["Occupancy [waves/SIMD]"] == 2 and u["VGPRs"] <= 256, (fld, kf, ks, u)
+            assert 128 * 1024 <= u["LDS Size [bytes/block]"] <= 160 * 1024, (fld, kf, ks, u)
+    nt = kernel_body(text, "wfold_pass_kernel%sLi4ELi5ELb1E" % GOLD)
+    plain = kernel_body(text, "wfold_pass_kernel%sLi4ELi5ELb0E" % GOLD)
+    loads_nt = re.findall(r"global_load_dwordx4[^\n]*", nt)
+    table_loads = [l for l in loads_nt if "sc0 sc1" not in l]        # (the system-scope poll of the in-kernel exchange is no table load)
+    assert len(table_loads) >= 64 and all(" nt" in l for l in table_loads), "the streaming fold lost its nontemporal loads"
+    assert not any(" nt" in l for l in re.findall(r"global_(?:load|store)_dwordx4[^\n]*", plain))
+    # batches: runs of >= 8 consecutive table loads with nothing but address arithmetic between them
+    lines = [l.strip() for l in nt.split("\n")]
+    best = run = 0
+    for l in lines:
+        if l.startswith("global_load_dwordx4"):
+            run += 1
+            best = max(best, run)
+        elif l.startswith(("ds_", "s_waitcnt", "s_barrier", "v_mad", "v_mul")):
+            run = 0
+    assert best >= 8, "the eight loads of a sub-step are no longer issued as one batch (%d)" % best
+
