@@ -142,7 +142,7 @@ def test_virtual_ranks_wfold_pass_on_the_shards(p, transport, world):
     o = oracle(p)
     g = world.bit_length() - 1
     for n in (20, 21):
-        plan = pkg.schedule.plan_proof(n, world, transport, first_pass_vars=4, **WFOLD_ON_SMALL_SHARDS)
+        plan = pkg.schedule.plan_proof(n, world, transport, first_pass_vars=4, tail_log=0, **WFOLD_ON_SMALL_SHARDS)     # (tail_log 0: no early gather)
         assert [s["action"] for s in plan][:3] == ["gram_pass", "wfold_pass", "wfold_pass"] and all(s["sharded"] for s in plan[:3]), plan
         oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
         ref = o.prove(oa, ob, challenges(o, n))

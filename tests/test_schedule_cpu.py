@@ -22,6 +22,7 @@ OPTION_SETS = [
     {"wfold_log": 0}, {"wfold_log": 25}, {"wfold_always": 1}, {"wfold_always": 1, "wfold_min_log": 12, "first_pass_vars": 4},
     {"wfold_always": 1, "wfold_min_log": 12, "grid_log": 26, "gram_log": 0}, {"wfold_always": 1, "host_tail_log": 0},
     {"wfold5_min_log": 12}, {"wfold5_min_log": 12, "wfold_min_log": 12, "first_pass_vars": 4, "wfold_always": 1, "host_tail_log": 0},
+    {"tail_log": 26}, {"tail_log": 24, "wfold_always": 1}, {"tail_log": 30, "wfold_always": 1, "grid_log": 14}, {"tail_log": 0},
 ]
 
 
@@ -76,7 +77,7 @@ def check(steps, n, world, transport, opts):
             assert max(12, opts.get("wfold_min_log", 21) if kf == 4 else opts.get("wfold5_min_log", 24)) <= cur_log <= opts.get("wfold_log", 40)
             assert opts.get("grid_pass", 1) == 1 and opts.get("use_mailbox", 1) == 1 and opts.get("vars_per_pass", 2) == 2
             assert not sharded or opts.get("grid_sharded", 1) == 1
-            nxt = steps[steps.index(s) + 1]
+            nxt = next(x for x in steps[steps.index(s) + 1:] if x["action"] != "gather")
             if kf == 4:
                 assert s["ks"] == 5 and served_before == 4 and cur_log - kf >= 6 and n - served_before >= 6 and gmax >= 5
                 assert cur_log - kf - 5 <= opts.get("grid_log", 20)
@@ -158,9 +159,15 @@ def test_known_schedules(plan):
     assert sig(plan(28, 8, "peer", host_tail_log=0)) == sig(s8)     # (the shards of a peer / RCCL / host plane never hand over)
     assert sig(plan(28, 8, "peer", gram_log=0)) == [("pass", 0, 3, 25), ("pass", 3, 2, 25), ("grid_pass", 2, 5, 22), ("grid_pass", 5, 5, 20),
                                                     ("grid_pass", 5, 5, 15), ("grid_pass", 5, 5, 10), ("rank_pass", 5, 3, 5)]
-    # the same over RCCL: the shard is gathered when it is down to its pending challenges, the rank bits are one more pass
+    # the same over RCCL (and host callbacks), where every sharded pass costs a collective: three sharded launches, ONE all-gather of
+    # the 2^16-entry shards (tail_log), two launches on the whole table and the host - five launches, three all-reduces (round 5's
+    # first half: eight and six).  tail_log = 0: the shards go on down to their pending challenges as on the peer plane
     r8 = plan(28, 8, "rccl")
-    assert sig(r8)[:6] == sig(s8)[:6] and sig(r8)[6:] == [("gather", 0, 0, 4), ("grid_pass", 4, 3, 7)]
+    assert sig(r8) == [("gram_pass", 0, 4, 25), ("wfold_pass", 4, 5, 25), ("grid_pass", 5, 4, 21), ("gather", 0, 0, 16), ("grid_pass", 4, 5, 19),
+                       ("grid_pass", 5, 5, 15), ("host_tail", 5, 5, 10)]
+    assert [x["sharded"] for x in r8] == [True, True, True, True, False, False, False] and sig(plan(28, 8, "host")) == sig(r8)
+    r80 = plan(28, 8, "rccl", tail_log=0)
+    assert sig(r80)[:6] == sig(s8)[:6] and sig(r80)[6:] == [("gather", 0, 0, 4), ("grid_pass", 4, 3, 7)]
     # ONE process over 8 devices (sc_ctx_create_multi): the n = 25 schedule on every device - FOUR launches - then every launcher
     # thread folds the four pending challenges of the 2^11 entries per table its device handed over and the host serves the ten
     # rounds that are left - no gather
