@@ -93,7 +93,14 @@ def one_iteration(rng, nprng, max_n, stats):
         opts = {"vars_per_pass": rng.choice([1, 2]), "first_pass_vars": rng.choice([0, 1, 2, 3, 4, 4]), "grid_pass": rng.randint(0, 1),
                 "grid_log": rng.choice([0, 3, 6, 9, 12, 16, 20]), "grid_max_vars": rng.randint(1, 5), "tail_log": rng.choice([0, 2, 5, 9, 14]),
                 "max_blocks": rng.choice([1, 2, 3, 7, 64, 256, 1024]), "grid_blocks": rng.choice([0, 0, 1, 2, 5, 64]),
-                "gram_log": rng.choice([0, 14, 15, 17, 28]), "host_tail_log": rng.choice([0, 0, 2, 5, 8, 10, 10])}
+                "gram_log": rng.choice([0, 14, 15, 17, 28]), "host_tail_log": rng.choice([0, 0, 2, 5, 8, 10, 11, 11]),
+                # (round 5: the five-round fold - (4, 5) and its (5, ks) form - at sizes the fuzz reaches)
+                "wfold_log": rng.choice([0, 16, 40, 40]), "wfold_min_log": rng.choice([12, 12, 14, 21]), "wfold_always": rng.randint(0, 1),
+                "wfold5_min_log": rng.choice([12, 12, 15, 24])}
+        if n >= 14 and rng.random() < 0.3:      # a set the five-round fold can run under (it needs the default two-round schedule around it)
+            opts = {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": rng.randint(0, 1), "wfold5_min_log": rng.choice([12, 12, 24]),
+                    "host_tail_log": rng.choice([0, 5, 9, 11]), "grid_log": rng.choice([12, 16, 20]), "max_blocks": rng.choice([1, 3, 7, 64, 1024]),
+                    "grid_blocks": rng.choice([0, 0, 2, 64]), "nt_load_log": rng.choice([12, 22])}
         if not n_dev and rng.random() < 0.2:
             opts["use_mailbox"] = 0
         for k, v in opts.items():
@@ -152,8 +159,14 @@ def one_iteration(rng, nprng, max_n, stats):
             got.pop()
         assert got == want, (desc, "restrict_poly")
     stats["n_by_dev"][n_dev] = stats["n_by_dev"].get(n_dev, 0) + 1
-    if pkg.schedule.plan_proof(n, **{k: v for k, v in opts.items() if k not in ("max_blocks", "grid_blocks")})[0]["action"] == "gram_pass" and n_dev <= 1:
+    popts = {k: v for k, v in opts.items() if k not in ("max_blocks", "grid_blocks", "nt_load_log")}
+    plan = pkg.schedule.plan_proof(n, n_dev, "local", **popts) if n_dev > 1 else pkg.schedule.plan_proof(n, **popts)
+    if plan[0]["action"] == "gram_pass":
         stats["gram"] = stats.get("gram", 0) + 1
+    for st in plan:
+        if st["action"] == "wfold_pass":
+            key = "wfold%d" % st["kf"]
+            stats[key] = stats.get(key, 0) + 1
     del a, b, g
     ctx.close()
 
@@ -271,9 +284,9 @@ def main():
     except BaseException:
         print("FAILED at iteration %d (seed %d): %s" % (it, seed, stats["last"]), flush=True)
         raise
-    print("fuzz_diff: %d iterations in %.0f s, seed %d, max_n %d, 0 mismatches; product-prover iterations by handle size (0 = plain context): %s; GKR layers %d, triangle graphs %d, refused as unsupported %d; proofs that opened with the matrix-core pass: %d" % (
+    print("fuzz_diff: %d iterations in %.0f s, seed %d, max_n %d, 0 mismatches; product-prover iterations by handle size (0 = plain context): %s; GKR layers %d, triangle graphs %d, refused as unsupported %d; proofs that opened with the matrix-core pass (handles included): %d; wfold launches planned: (4,5) %d, (5,ks) %d" % (
         it, time.time() - t0, seed, max_n, dict(sorted(stats["n_by_dev"].items())), stats.get("gkr", 0), stats.get("triangle", 0),
-        stats.get("unsupported", 0), stats.get("gram", 0)), flush=True)
+        stats.get("unsupported", 0), stats.get("gram", 0), stats.get("wfold4", 0), stats.get("wfold5", 0)), flush=True)
 
 
 main()
