@@ -128,12 +128,14 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      alternative is a grid pass streaming the whole table (n = 21..24); "wfold_always" = 1: wherever it can
  *                      run.  "wfold5_min_log" (default 24): a grid pass with FIVE challenges to fold over tables of >= 2^this
  *                      entries runs in the same kernel's (5, 3..5) form.  Same results; DESIGN.md sections 4, 5
- *   "host_tail_log"    (default 11; 0..11) the host finishes the proof: a pass whose folded tables have <= 2^host_tail_log
+ *   "host_tail_log"    (default 12; 0..12) the host finishes the proof: a pass whose folded tables have <= 2^host_tail_log
  *                      entries (per device on a multi-device handle) writes them to pinned host memory instead of the
  *                      pool, and every later round is served by the host from them - fold the pending challenges
- *                      (<= 2^12 multiply-adds), then one sub-microsecond round at a time - with NO further launch: the
+ *                      (<= 2^13 multiply-adds), then one sub-microsecond round at a time - with NO further launch: the
  *                      last launch (or two) of every proof and every shard, ~13 us each, disappears; the planner aims its
- *                      grid passes at this hand-over (fewest launches up to it, fewest rounds per pass among those).  Not a CPU path
+ *                      grid passes at this hand-over (fewest launches up to it, fewest rounds per pass among those) - at
+ *                      2^11 entries where the larger hand-over saves no launch (the host's first read of what the device
+ *                      wrote costs ~0.1 us per KiB).  Not a CPU path
  *                      for the hot loop: what the host touches is what is left when 2^-18 of the work remains.  Applies
  *                      to unsharded provers (incl. a sharded one after its gather) and to multi-device handles; five-round
  *                      passes (and any pass with <= 32 outputs) hand over, 0 = off (a multi-device handle then hands

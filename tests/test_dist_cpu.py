@@ -66,7 +66,7 @@ def model_sharded_prove(o, D, plan_proof, p, n, rank, world, opts, allreduce, al
             if step["action"] == "host_tail":
                 # (only a whole prover hands over on a host transport: after the gather) engine/abi_prover.inc: host_tail
                 assert not sharded and not steps and step["kf"] == len(pending) and step["ks"] == n - j, (step, j)
-                assert step["log_in"] == int(a.size).bit_length() - 1 <= 11
+                assert step["log_in"] == int(a.size).bit_length() - 1 <= 12
                 host = True
         if host:
             evals.append(host_round(o, [[a, b]], pending, sub, add))

@@ -38,7 +38,7 @@ def test_default_schedule_uses_grid_passes(pkg, p):
     o = oracle(p)
     for n in list(range(1, 19)) + [20, 21, 22]:
         # the default: the launches are the plan's, the host serves what the last launch leaves (option "host_tail_log")
-        ctx.set_option("host_tail_log", 11)
+        ctx.set_option("host_tail_log", 12)
         log = prove_and_check(pkg, ctx, o, n)
         plan = pkg.schedule.plan_proof(n)
         assert [(r["kind"], r["kf"], r["ks"]) for r in log] == [(s["action"], s["kf"], s["ks"]) for s in plan if s["action"] != "host_tail"], (n, log)

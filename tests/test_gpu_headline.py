@@ -62,9 +62,10 @@ def test_default_schedule_vs_oracle(p, n):
     assert not bad, (p, n, "rounds that differ from the oracle", bad)
     plan = pkg.schedule.plan_proof(n)
     assert log == [(s["action"], s["kf"], s["ks"], s["log_in"]) for s in plan if s["action"] != "host_tail"]
-    # (behind the matrix-core pass: wfold_pass_kernel where it saves a launch - n = 25, 27, 28 -, pass_kernel<4,2> at n = 26)
-    assert plan[0]["action"] == "gram_pass" and plan[1]["action"] == ("pass" if n == 26 else "wfold_pass") and plan[1]["kf"] == 4
-    assert plan[-1]["action"] == "host_tail" and len(plan) == (5 if n == 25 else 6)
+    # (behind the matrix-core pass: wfold_pass_kernel - it saves a launch at every one of these sizes; n = 26 ends with a hand-over
+    # of 2^12-entry tables, the others of 2^11)
+    assert plan[0]["action"] == "gram_pass" and plan[1]["action"] == "wfold_pass" and plan[1]["kf"] == 4
+    assert plan[-1]["action"] == "host_tail" and len(plan) == (5 if n in (25, 26) else 6) and plan[-1]["log_in"] == (12 if n == 26 else 11)
     # the verifier's last check against the tables themselves (sum-check-protocol/src/lib.rs:302-307)
     assert verifier_identities(ctx.field, c1, evals, ch, g.evaluate([int(x) for x in ch])) is None
     # a second proof on the same context (warm pool, recycled buffers, the gram ticket back at rest): the same transcript

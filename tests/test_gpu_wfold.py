@@ -92,7 +92,8 @@ def test_planner_takes_wfold_where_it_pays():
     pp = pkg.schedule.plan_proof
     assert plan_str(pp(25)) == "gram_pass(0,4)@25 wfold_pass(4,5)@25 grid_pass(5,5)@21 grid_pass(5,4)@16 host_tail(4,7)@11"
     assert plan_str(pp(28)) == "gram_pass(0,4)@28 wfold_pass(4,5)@28 wfold_pass(5,3)@24 grid_pass(3,5)@19 grid_pass(5,4)@16 host_tail(4,7)@11"
-    assert pp(26)[1] == {"action": "pass", "kf": 4, "ks": 2, "log_in": 26, "sharded": False}
+    assert plan_str(pp(26)) == "gram_pass(0,4)@26 wfold_pass(4,5)@26 grid_pass(5,5)@22 grid_pass(5,4)@17 host_tail(4,8)@12"
+    assert pp(26, host_tail_log=11)[1] == {"action": "pass", "kf": 4, "ks": 2, "log_in": 26, "sharded": False}
     for n in range(1, 21):
         assert "wfold_pass" not in plan_str(pp(n)), n
     ctx = pkg.Context(pkg.Field(GOLD))

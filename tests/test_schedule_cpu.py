@@ -32,7 +32,7 @@ def check(steps, n, world, transport, opts):
     assert served == n, (served, n)
     cur_log, kf, sharded = n - g, 0, transport != "none" and not (transport == "local" and world == 1)
     gmax = opts.get("grid_max_vars", 5)
-    htl = opts.get("host_tail_log", 11)
+    htl = opts.get("host_tail_log", 12)
     prev = None
     served_before = 0
     for s in steps:
@@ -55,7 +55,7 @@ def check(steps, n, world, transport, opts):
             assert s is steps[-1] and s["ks"] == n - sum(x["ks"] for x in steps[:-1]) and kf <= 5
             assert opts.get("use_mailbox", 1) == 1 or (local and cur_log == kf)
             assert not sharded or local
-            limit = min(max(htl, 5) if local else htl, 11)
+            limit = min(max(htl, 5) if local else htl, 12)
             handed = prev is not None and prev["kf"] > 0 and cur_log <= limit and (prev["action"] == "grid_pass" or cur_log <= 5)
             assert handed or (local and cur_log == kf), (s, prev, limit)
             cur_log, sharded = 0, False
@@ -99,7 +99,7 @@ def check(steps, n, world, transport, opts):
         if s["action"] in ("pass", "grid_pass") and s is not steps[-1] and s["kf"] > 0 and opts.get("use_mailbox", 1) == 1:
             # a pass that COULD hand over (rule above) does: the next step is the host tail
             local = transport == "local" and sharded
-            limit = min(max(htl, 5) if local else htl, 11)
+            limit = min(max(htl, 5) if local else htl, 12)
             if (not sharded or local) and cur_log <= limit and (s["action"] == "grid_pass" or cur_log <= 5):
                 assert steps[steps.index(s) + 1]["action"] == "host_tail", (s, steps)
         kf = s["ks"]
@@ -145,10 +145,15 @@ def test_known_schedules(plan):
                                           ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
     # the wfold pass is taken where it saves a launch (25, 27, 28, 29) or replaces a grid pass over the whole table (21 .. 24), not
     # where pass_kernel<4,2> does the same in as many launches (26) or no grid pass could take its five challenges (30)
-    assert [n for n in range(14, 34) if any(x["action"] == "wfold_pass" for x in plan(n))] == [21, 22, 23, 24, 25, 27, 28, 29]
-    assert len(plan(26)) == len(plan(26, wfold_always=1)) and plan(26, wfold_always=1)[1]["action"] == "wfold_pass"
-    for n, saved in ((25, 1), (27, 1), (28, 1), (29, 2)):
+    assert [n for n in range(14, 34) if any(x["action"] == "wfold_pass" for x in plan(n))] == [21, 22, 23, 24, 25, 26, 27, 28, 29]
+    for n, saved in ((25, 1), (26, 1), (27, 1), (28, 1), (29, 2)):
         assert len(plan(n)) == len(plan(n, wfold_log=0)) - saved
+    # the hand-over: <= 2^12 entries (host_tail_log), aimed at 2^11 unless the larger one saves a launch - n = 17, 21, 26
+    assert [n for n in range(1, 34) if plan(n)[-1]["action"] == "host_tail" and plan(n)[-1]["log_in"] == 12] == [17, 21, 26]
+    for n in (17, 21, 26):
+        assert len(plan(n)) == len(plan(n, host_tail_log=11)) - 1
+    assert sig(plan(26)) == [("gram_pass", 0, 4, 26), ("wfold_pass", 4, 5, 26), ("grid_pass", 5, 5, 22), ("grid_pass", 5, 4, 17), ("host_tail", 4, 8, 12)]
+    assert all(len(plan(n)) == len(plan(n, host_tail_log=11)) for n in range(1, 34) if n not in (17, 21, 26))
     assert sig(plan(20))[0] == ("grid_pass", 0, 4, 20) and sig(plan(21))[0] == ("gram_pass", 0, 4, 21)
     assert sig(plan(20, first_pass_vars=4))[:2] == [("gram_pass", 0, 4, 20), ("grid_pass", 4, 5, 20)]
     # BASELINE config 4: n = 28 over 8 ranks, peer transport - seven launches, seven exchanges, no gather
@@ -213,7 +218,7 @@ def test_plan_argument_checks(plan):
     pkg = load_package()
     for bad in [dict(num_vars=2, world=8, transport="peer"), dict(num_vars=10, world=3, transport="peer"),
                 dict(num_vars=10, world=2, transport="none"), dict(num_vars=10, world=1, transport="none", grid_max_vars=6),
-                dict(num_vars=10, world=1, transport="none", vars_per_pass=3), dict(num_vars=10, world=1, transport="none", host_tail_log=12),
+                dict(num_vars=10, world=1, transport="none", vars_per_pass=3), dict(num_vars=10, world=1, transport="none", host_tail_log=13),
                 dict(num_vars=10, world=1, transport="none", wfold_log=5), dict(num_vars=10, world=1, transport="none", wfold_min_log=3)]:
         with pytest.raises(pkg.SumcheckHipError) as ei:
             plan(**bad)
@@ -231,7 +236,7 @@ def test_plan_options_struct_is_versioned():
     assert lib.sc_abi_version() == L.ABI_VERSION == 5
     full = L.ScPlanOptions()
     lib.sc_plan_options_default(ctypes.byref(full), ctypes.sizeof(full))
-    assert full.struct_size == ctypes.sizeof(full) == 60 and full.host_tail_log == 11 and full.gram_log == 21
+    assert full.struct_size == ctypes.sizeof(full) == 60 and full.host_tail_log == 12 and full.gram_log == 21
     assert (full.wfold_log, full.wfold_min_log, full.wfold_always, full.wfold5_min_log) == (40, 21, 0, 24)
 
     class Old(ctypes.Structure):      # a caller built before host_tail_log existed, with a guard word behind its struct

@@ -101,7 +101,8 @@ bool load_rccl(std::string* why) {
 // launch leaves this shard's own sums in its own mailbox and the handle's host thread adds them - no collective at all
 enum class Transport { kNone, kRccl, kHost, kPeer, kLocal };
 constexpr int kMaxSubs = 8;          // devices behind one multi-device handle (one node)
-constexpr int kTailLogMax = 11;
+constexpr int kTailLogMax = 12;
+constexpr int kTailSoftLog = 11;      // the planner aims at <= 2^this where that costs no launch (the host's share doubles with every step above it)
 constexpr int kTailEntries = 1 << kTailLogMax;   // a pass whose outputs have <= 2^host_tail_log <= this many entries per table writes them to
                                      // pinned host memory (sc_ctx::h_tail): the host finishes the proof from them (option "host_tail_log")
 constexpr int kTailSmallLog = 5;     // ... and what a pass_kernel launch may hand over: one wave's stores (finish_pass drains wave 0 only)

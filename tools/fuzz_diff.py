@@ -93,13 +93,13 @@ def one_iteration(rng, nprng, max_n, stats):
         opts = {"vars_per_pass": rng.choice([1, 2]), "first_pass_vars": rng.choice([0, 1, 2, 3, 4, 4]), "grid_pass": rng.randint(0, 1),
                 "grid_log": rng.choice([0, 3, 6, 9, 12, 16, 20]), "grid_max_vars": rng.randint(1, 5), "tail_log": rng.choice([0, 2, 5, 9, 14]),
                 "max_blocks": rng.choice([1, 2, 3, 7, 64, 256, 1024]), "grid_blocks": rng.choice([0, 0, 1, 2, 5, 64]),
-                "gram_log": rng.choice([0, 14, 15, 17, 28]), "host_tail_log": rng.choice([0, 0, 2, 5, 8, 10, 11, 11]),
+                "gram_log": rng.choice([0, 14, 15, 17, 28]), "host_tail_log": rng.choice([0, 0, 2, 5, 8, 10, 11, 12, 12]),
                 # (round 5: the five-round fold - (4, 5) and its (5, ks) form - at sizes the fuzz reaches)
                 "wfold_log": rng.choice([0, 16, 40, 40]), "wfold_min_log": rng.choice([12, 12, 14, 21]), "wfold_always": rng.randint(0, 1),
                 "wfold5_min_log": rng.choice([12, 12, 15, 24])}
         if n >= 14 and rng.random() < 0.3:      # a set the five-round fold can run under (it needs the default two-round schedule around it)
             opts = {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": rng.randint(0, 1), "wfold5_min_log": rng.choice([12, 12, 24]),
-                    "host_tail_log": rng.choice([0, 5, 9, 11]), "grid_log": rng.choice([12, 16, 20]), "max_blocks": rng.choice([1, 3, 7, 64, 1024]),
+                    "host_tail_log": rng.choice([0, 5, 9, 11, 12]), "grid_log": rng.choice([12, 16, 20]), "max_blocks": rng.choice([1, 3, 7, 64, 1024]),
                     "grid_blocks": rng.choice([0, 0, 2, 64]), "nt_load_log": rng.choice([12, 22])}
         if not n_dev and rng.random() < 0.2:
             opts["use_mailbox"] = 0
