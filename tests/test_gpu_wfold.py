@@ -53,17 +53,20 @@ def run_vs_oracle(pkg, p, n, opts, expect_wfold=True, devices=None):
                                     # the (5, ks) form behind it on the small tables: (5, 4) on ONE tile, (5, 5) on 4 / 8 tiles
                                     (16, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1, "host_tail_log": 0, "wfold5_min_log": 12}),
                                     (19, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1, "host_tail_log": 0, "wfold5_min_log": 12, "max_blocks": 3}),
+                                    # the streaming form where NO grid pass could take the five challenges (n >= 30 by default; here grid_log 8)
+                                    (20, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold5_min_log": 12, "grid_log": 8}),
+                                    (21, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold5_min_log": 12, "grid_log": 6, "host_tail_log": 0}),
                                     (18, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1, "max_blocks": 3}),
                                     (18, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1, "host_tail_log": 0}),   # the device serves every round
                                     (20, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1}),
                                     (21, {}), (22, {"max_blocks": 5}), (22, {"nt_load_log": 12, "nt_store_log": 12}), (23, {"max_blocks": 64})])
 def test_wfold_pass_vs_oracle(p, n, opts):
     pkg = load_package()
-    popts = {k: v for k, v in opts.items() if k in ("first_pass_vars", "wfold_min_log", "wfold_always", "host_tail_log", "wfold5_min_log")}
+    popts = {k: v for k, v in opts.items() if k in ("first_pass_vars", "wfold_min_log", "wfold_always", "host_tail_log", "wfold5_min_log", "grid_log")}
     plan = pkg.schedule.plan_proof(n, **popts)
     assert plan[1] == {"action": "wfold_pass", "kf": 4, "ks": 5, "log_in": n, "sharded": False}, plan_str(plan)
     if "wfold5_min_log" in opts:
-        assert plan[2]["action"] == "wfold_pass" and plan[2]["kf"] == 5 and plan[2]["ks"] == (4 if n == 16 else 5), plan_str(plan)
+        assert plan[2]["action"] == "wfold_pass" and plan[2]["kf"] == 5 and plan[2]["ks"] in (3, 4, 5), plan_str(plan)
     run_vs_oracle(pkg, p, n, opts)
 
 

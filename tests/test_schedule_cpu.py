@@ -23,6 +23,7 @@ OPTION_SETS = [
     {"wfold_always": 1, "wfold_min_log": 12, "grid_log": 26, "gram_log": 0}, {"wfold_always": 1, "host_tail_log": 0},
     {"wfold5_min_log": 12}, {"wfold5_min_log": 12, "wfold_min_log": 12, "first_pass_vars": 4, "wfold_always": 1, "host_tail_log": 0},
     {"tail_log": 26}, {"tail_log": 24, "wfold_always": 1}, {"tail_log": 30, "wfold_always": 1, "grid_log": 14}, {"tail_log": 0},
+    {"first_pass_vars": 4, "wfold_min_log": 12, "wfold5_min_log": 12, "grid_log": 8}, {"grid_log": 12, "wfold5_min_log": 14, "wfold_min_log": 14, "gram_log": 14},
 ]
 
 
@@ -80,10 +81,14 @@ def check(steps, n, world, transport, opts):
             nxt = next(x for x in steps[steps.index(s) + 1:] if x["action"] != "gather")
             if kf == 4:
                 assert s["ks"] == 5 and served_before == 4 and cur_log - kf >= 6 and n - served_before >= 6 and gmax >= 5
-                assert cur_log - kf - 5 <= opts.get("grid_log", 20)
                 assert nxt["action"] in ("grid_pass", "wfold_pass") and nxt["kf"] == 5
+                # (the pass behind it: a grid pass, or - folded table too large for one - the streaming form)
+                assert nxt["log_in"] - 5 <= opts.get("grid_log", 20) or nxt["action"] == "wfold_pass"
             else:
-                assert kf == 5 and 3 <= s["ks"] <= gmax and cur_log - kf <= opts.get("grid_log", 20) and cur_log >= kf + s["ks"]
+                # a grid pass's job on a large table - or, where the folded table is too large for a grid pass (whole provers and
+                # the shards of a handle), the only kernel that folds five challenges there
+                assert kf == 5 and 3 <= s["ks"] <= gmax and cur_log >= kf + s["ks"]
+                assert cur_log - kf <= opts.get("grid_log", 20) or not sharded or transport == "local"
                 assert nxt["action"] != "host_tail"
             cur_log -= kf
         elif s["action"] == "pass":
@@ -145,15 +150,20 @@ def test_known_schedules(plan):
                                           ("grid_pass", 5, 4, 16), ("host_tail", 4, 7, 11)]
     # the wfold pass is taken where it saves a launch (25, 27, 28, 29) or replaces a grid pass over the whole table (21 .. 24), not
     # where pass_kernel<4,2> does the same in as many launches (26) or no grid pass could take its five challenges (30)
-    assert [n for n in range(14, 34) if any(x["action"] == "wfold_pass" for x in plan(n))] == [21, 22, 23, 24, 25, 26, 27, 28, 29]
-    for n, saved in ((25, 1), (26, 1), (27, 1), (28, 1), (29, 2)):
+    assert [n for n in range(14, 41) if any(x["action"] == "wfold_pass" for x in plan(n))] == list(range(21, 41))
+    # from n = 30 the pass behind it folds to more than 2^grid_log entries: the streaming form is that pass (5 launches where
+    # pass_kernel<4,2> and the two-round passes behind it need 7 and 8)
+    assert sig(plan(30)) == [("gram_pass", 0, 4, 30), ("wfold_pass", 4, 5, 30), ("wfold_pass", 5, 5, 26), ("grid_pass", 5, 5, 21), ("grid_pass", 5, 4, 16),
+                             ("host_tail", 4, 7, 11)]
+    assert (len(plan(30, wfold_log=0)), len(plan(31)), len(plan(31, wfold_log=0))) == (8, 6, 9)
+    for n, saved in ((25, 1), (26, 1), (27, 1), (28, 1), (29, 2), (30, 2), (31, 3)):
         assert len(plan(n)) == len(plan(n, wfold_log=0)) - saved
     # the hand-over: <= 2^12 entries (host_tail_log), aimed at 2^11 unless the larger one saves a launch - n = 17, 21, 26
-    assert [n for n in range(1, 34) if plan(n)[-1]["action"] == "host_tail" and plan(n)[-1]["log_in"] == 12] == [17, 21, 26]
-    for n in (17, 21, 26):
+    assert [n for n in range(1, 34) if plan(n)[-1]["action"] == "host_tail" and plan(n)[-1]["log_in"] == 12] == [17, 21, 26, 31]
+    for n in (17, 21, 26, 31):
         assert len(plan(n)) == len(plan(n, host_tail_log=11)) - 1
     assert sig(plan(26)) == [("gram_pass", 0, 4, 26), ("wfold_pass", 4, 5, 26), ("grid_pass", 5, 5, 22), ("grid_pass", 5, 4, 17), ("host_tail", 4, 8, 12)]
-    assert all(len(plan(n)) == len(plan(n, host_tail_log=11)) for n in range(1, 34) if n not in (17, 21, 26))
+    assert all(len(plan(n)) == len(plan(n, host_tail_log=11)) for n in range(1, 34) if n not in (17, 21, 26, 31))
     assert sig(plan(20))[0] == ("grid_pass", 0, 4, 20) and sig(plan(21))[0] == ("gram_pass", 0, 4, 21)
     assert sig(plan(20, first_pass_vars=4))[:2] == [("gram_pass", 0, 4, 20), ("grid_pass", 4, 5, 20)]
     # BASELINE config 4: n = 28 over 8 ranks, peer transport - seven launches, seven exchanges, no gather
