@@ -92,7 +92,7 @@ def check(steps, n, world, transport, opts):
                 assert nxt["action"] != "host_tail"
             cur_log -= kf
         elif s["action"] == "pass":
-            assert (kf <= 3 or (kf == 4 and s["ks"] == 2 and steps[0]["action"] == "gram_pass")) and 1 <= s["ks"] <= 3
+            assert (kf <= 3 or (kf == 4 and s["ks"] == 2 and cur_log >= 12)) and 1 <= s["ks"] <= 3      # (pass_kernel<4,2>: whole tiles)
             assert (s["ks"] < 3 or kf == 0) and cur_log >= kf + s["ks"]
             assert s["ks"] <= max(opts.get("vars_per_pass", 2), 1) or (kf == 0 and s["ks"] == 3)
             cur_log -= kf
@@ -222,6 +222,28 @@ def test_new_planner_never_needs_more_launches(plan):
     for world, transport in [(2, "peer"), (8, "peer"), (8, "rccl"), (4, "host")]:
         for n in range(world.bit_length() - 1, 41):
             assert launches(plan(n, world, transport)) <= launches(plan(n, world, transport, wfold_log=0)), (n, world, transport)
+
+
+def test_random_option_sets_are_never_refused(plan):
+    """the option space the GPU fuzz draws from (tools/fuzz_diff.py) and beyond, on the planner alone: every combination the library
+    accepts yields a plan (no state without a kernel - found by the fuzz once: a streaming pass that left four challenges to a
+    table too small for pass_kernel<4,2>) and the plan keeps the invariants above"""
+    import random
+    rng = random.Random(20261004)
+    for _ in range(6000):
+        opts = {}
+        if rng.random() < 0.85:
+            opts = {"vars_per_pass": rng.choice([1, 2, 2, 2]), "first_pass_vars": rng.choice([0, 0, 1, 2, 3, 4, 4]), "grid_pass": rng.choice([0, 1, 1, 1]),
+                    "grid_log": rng.choice([0, 3, 6, 9, 12, 16, 20, 26]), "grid_max_vars": rng.randint(1, 5), "tail_log": rng.choice([0, 2, 5, 9, 14, 16, 24]),
+                    "gram_log": rng.choice([0, 14, 15, 17, 21, 28]), "host_tail_log": rng.choice([0, 2, 5, 8, 10, 11, 12]),
+                    "wfold_log": rng.choice([0, 16, 40, 40]), "wfold_min_log": rng.choice([12, 12, 14, 21]), "wfold_always": rng.randint(0, 1),
+                    "wfold5_min_log": rng.choice([12, 12, 15, 24]), "grid_sharded": rng.choice([0, 1, 1]), "use_mailbox": rng.choice([0, 1, 1, 1, 1])}
+            for k in rng.sample(sorted(opts), rng.randint(0, 6)):      # (some at their defaults)
+                del opts[k]
+        world, transport = rng.choice([(1, "none"), (1, "none"), (1, "local"), (2, "local"), (8, "local"), (2, "peer"), (8, "peer"), (4, "rccl"), (8, "host")])
+        n = rng.randint(max(world.bit_length() - 1, 1), 40)
+        steps = plan(n, world, transport, **opts)
+        check(steps, n, world, transport, opts)
 
 
 def test_plan_argument_checks(plan):
