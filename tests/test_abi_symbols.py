@@ -10,6 +10,9 @@ import pytest
 from conftest import ROOT, has_gpu, load_package
 
 
+HEADER = open(os.path.join(ROOT, "include", "sumcheck_hip.h")).read()
+
+
 def header_functions():
     text = open(os.path.join(ROOT, "include", "sumcheck_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
@@ -85,6 +88,40 @@ def test_rust_sys_crate_declares_the_same_abi():
         assert m, ty
         for meth in ("fn evaluate", "fn fix_variables", "fn to_univariate", "fn num_vars", "fn to_evaluations", "fn native_engine"):
             assert meth in m.group(1), (ty, meth)
+
+
+def _header_struct_fields(name):
+    """field names of `typedef struct <name> { ... } <name>;` in the header, in order (comments stripped)"""
+    text = re.sub(r"/\*.*?\*/", "", HEADER, flags=re.S)
+    m = re.search(r"typedef struct %s \{(.*?)\} %s;" % (name, name), text, flags=re.S)
+    assert m, name
+    out = []
+    for decl in m.group(1).split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        out.append(first.split()[-1].split("[")[0])
+        out += [r.strip().split("[")[0] for r in rest]
+    return out
+
+
+def test_structs_that_cross_the_abi_have_the_same_fields_everywhere():
+    """sc_field, sc_launch_record, sc_plan_options, sc_plan_step: the header's fields, in order, are the ctypes binding's and the
+    Rust -sys crate's (a struct that grows in one place only would shift every field behind it)"""
+    pkg = load_package()
+    L = pkg._lib
+    sys_rs = open(os.path.join(ROOT, "rust", "sumcheck-hip-sys", "src", "lib.rs")).read()
+    for cname, ctype in (("sc_plan_options", L.ScPlanOptions), ("sc_plan_step", L.ScPlanStep), ("sc_launch_record", L.ScLaunchRecord)):
+        fields = _header_struct_fields(cname)
+        assert [f[0] for f in ctype._fields_] == fields, (cname, fields)
+        m = re.search(r"pub struct %s \{(.*?)\n\}" % cname, sys_rs, flags=re.S)
+        assert m, cname
+        assert re.findall(r"pub (\w+):", m.group(1)) == fields, (cname, fields)
+    # every plan action / launch kind of the header has a name in the binding
+    for prefix, table in (("SC_PLAN_", L.PLAN_ACTIONS), ("SC_KIND_", L.KIND_NAMES)):
+        values = {int(v) for _, v in re.findall(r"#define (%s\w+) (\d+)" % prefix, HEADER)}
+        assert values <= set(table) | {1}, (prefix, values - set(table))
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/sum-check-protocol"), reason="the reference tree is only present in the build container")
