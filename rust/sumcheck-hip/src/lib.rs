@@ -9,7 +9,7 @@ use std::marker::PhantomData;
 use std::ptr;
 use std::rc::Rc;
 
-use ark_ff::{BigInt, Fp64, MontBackend, MontConfig};
+use ark_ff::{BigInt, Fp64, MontBackend, MontConfig, Zero};
 use ark_poly::univariate::SparsePolynomial;
 use sum_check_protocol::SumCheckPolynomial;
 use sumcheck_hip_sys as sys;
@@ -175,14 +175,38 @@ impl<T: MontConfig<1>> Clone for GpuG<T> {
     }
 }
 
-fn round_poly<T: MontConfig<1>>(e: [u64; 3]) -> SparsePolynomial<F64<T>> {
+fn round_coeffs<T: MontConfig<1>>(e: [u64; 3]) -> [F64<T>; 3] {
     let f = field_of::<T>();
     let mut c = [0u64; 3];
     let rc = unsafe { sys::sc_interpolate_quadratic(&f, e.as_ptr(), c.as_mut_ptr()) };
     assert_eq!(rc, sys::SC_OK);
+    [from_word::<T>(c[0]), from_word::<T>(c[1]), from_word::<T>(c[2])]
+}
+
+/// The round polynomial as `triangle_counting::G` and `W` hand it out: `Evaluations::interpolate()` then `p.into()`
+/// (`From<DensePolynomial>`), i.e. the non-zero coefficients only.
+fn round_poly<T: MontConfig<1>>(e: [u64; 3]) -> SparsePolynomial<F64<T>> {
+    let c = round_coeffs::<T>(e);
     SparsePolynomial::from_coefficients_vec(
-        c.iter().enumerate().map(|(d, w)| (d, from_word::<T>(*w))).collect(),
+        c.iter().enumerate().filter(|(_, w)| !w.is_zero()).map(|(d, w)| (d, *w)).collect(),
     )
+}
+
+/// The round polynomial as `matrix_multiplication::G` hands it out: the reference adds three Lagrange terms, each built
+/// by `from_coefficients_vec`, and `SparsePolynomial`'s `+` returns the other operand untouched when one operand is zero.
+/// The terms through x = 1 and x = 2 carry an explicit zero constant, so when H(0) = 0 and exactly one of H(1), H(2) is
+/// non-zero the sum keeps a `(0, 0)` term; everywhere else only non-zero terms remain.  Same values either way - this
+/// keeps `serialize_uncompressed` (fiat-shamir) byte-identical with the CPU `G`.
+fn round_poly_lagrange<T: MontConfig<1>>(e: [u64; 3]) -> SparsePolynomial<F64<T>> {
+    let c = round_coeffs::<T>(e);
+    let keeps_zero_constant = e[0] == 0 && ((e[1] == 0) != (e[2] == 0));
+    let mut terms: Vec<(usize, F64<T>)> = Vec::with_capacity(3);
+    for (d, w) in c.iter().enumerate() {
+        if !w.is_zero() || (d == 0 && keeps_zero_constant) {
+            terms.push((d, *w));
+        }
+    }
+    SparsePolynomial::from_coefficients_vec(terms)
 }
 
 impl<T: MontConfig<1>> GpuG<T> {
@@ -227,7 +251,7 @@ impl<T: MontConfig<1>> SumCheckPolynomial<F64<T>> for GpuG<T> {
         let mut e = [0u64; 3];
         let rc = unsafe { sys::sc_prod2_round_sums(ctx.raw(), self.f_a.h, self.f_b.h, e.as_mut_ptr()) };
         ctx.check(rc, "sc_prod2_round_sums");
-        round_poly::<T>(e)
+        round_poly_lagrange::<T>(e)
     }
 
     fn num_vars(&self) -> usize {
@@ -286,7 +310,7 @@ impl<T: MontConfig<1>> sum_check_protocol::RoundEngine<F64<T>> for ProverEngine<
         let mut e = [0u64; 3];
         let rc = unsafe { sys::sc_prover_round(self.h, word::<T>(&r_prev), j, e.as_mut_ptr()) };
         self.g.f_a.ctx.check(rc, "sc_prover_round");
-        round_poly::<T>(e)
+        round_poly_lagrange::<T>(e)
     }
 }
 

@@ -201,6 +201,29 @@ int main() {
     std::printf("ok multilinear_extensions::example_from_book\n");
   }
 
+  {  // the round polynomial's canonical form (matrix-multiplication/src/lib.rs:17-60 adds three SparsePolynomials): every
+     // (H(0), H(1), H(2)) of F_5^3 - the rule tests/golden/fs_transcripts.json lists term by term (tests/test_oracle_fs.py)
+    int explicit_zero = 0;
+    for (uint64_t e0 = 0; e0 < 5; ++e0) for (uint64_t e1 = 0; e1 < 5; ++e1) for (uint64_t e2 = 0; e2 < 5; ++e2) {
+      F e[3] = {f5.from_int(e0), f5.from_int(e1), f5.from_int(e2)};
+      SparsePolynomial q = matrix_multiplication::round_poly_lagrange(f5, e);
+      for (uint64_t x = 0; x < 3; ++x) REQUIRE(q.evaluate(f5, f5.from_int(x)) == e[x]);
+      bool expect_zero_term = e0 == 0 && (e1 == 0) != (e2 == 0);
+      size_t zeros = 0;
+      for (size_t t = 0; t < q.coeffs.size(); ++t) {
+        if (t) REQUIRE(q.coeffs[t - 1].first < q.coeffs[t].first);
+        if (q.coeffs[t].second == 0) { ++zeros; REQUIRE(q.coeffs[t].first == 0); }
+      }
+      REQUIRE(zeros == (expect_zero_term ? 1u : 0u));
+      explicit_zero += (int)zeros;
+      SparsePolynomial d = matrix_multiplication::round_poly_from_evals(f5, e);      // W / triangle: `p.into()`
+      for (auto& t : d.coeffs) REQUIRE(t.second != 0);
+      for (uint64_t x = 0; x < 3; ++x) REQUIRE(d.evaluate(f5, f5.from_int(x)) == e[x]);
+    }
+    REQUIRE(explicit_zero == 8);
+    std::printf("ok SparsePolynomial canonical forms\n");
+  }
+
   Matrix a = {{f5.from_int(0), f5.from_int(1)}, {f5.from_int(2), f5.from_int(0)}};
   Matrix b = {{f5.from_int(1), f5.from_int(0)}, {f5.from_int(0), f5.from_int(4)}};
   Matrix c = {{f5.from_int(0), f5.from_int(4)}, {f5.from_int(2), f5.from_int(0)}};

@@ -65,7 +65,7 @@ def deserialize_poly(field, data, off=0):
         d = int.from_bytes(data[off:off + 8], "little")
         c, off = deserialize_field(field, data, off + 8)
         coeffs.append((d, c))
-    return SparsePolynomial.from_coefficients_vec(field, coeffs), off
+    return SparsePolynomial(field, coeffs), off        # the derived CanonicalDeserialize: the Vec as it was written
 
 
 class Sha256FieldHasher:

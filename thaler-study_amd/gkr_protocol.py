@@ -242,7 +242,7 @@ def restrict_poly(b, c, mle):
     assert bb.size == k and cc.size == k
     out = np.zeros(k + 1, dtype=np.uint64)
     ctx.check(ctx.lib.sc_table_restrict_to_line(ctx.h, mle.h, _u64p(bb), _u64p(cc), k, _u64p(out)))
-    return SparsePolynomial.from_coefficients_vec(ctx.field, [(d, int(v)) for d, v in enumerate(out)])
+    return SparsePolynomial.from_dense(ctx.field, [int(v) for v in out])
 
 
 # ---- the GKR message state machines (gkr-protocol/src/lib.rs:38-218, :324-474) -----------------------

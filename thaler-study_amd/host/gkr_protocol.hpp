@@ -132,9 +132,7 @@ inline SparsePolynomial restrict_poly(const std::vector<F>& b, const std::vector
   const size_t k = mle.num_vars();
   std::vector<F> coeffs(k + 1);
   mle.ctx().check(sc_table_restrict_to_line(mle.ctx().raw(), mle.raw(), b.data(), c.data(), k, coeffs.data()), "sc_table_restrict_to_line");
-  std::vector<std::pair<size_t, F>> terms;
-  for (size_t d = 0; d <= k; ++d) terms.push_back({d, coeffs[d]});
-  return SparsePolynomial::from_coefficients_vec(terms);
+  return SparsePolynomial::from_dense(coeffs);
 }
 
 // lib.rs:255-289 / :231-252

@@ -89,24 +89,31 @@ using sum_check_protocol::SumCheckPolynomial;
 using sumcheck_hip::Context;
 using sumcheck_hip::DeviceMle;
 
-// :17-60 - generic three-point Lagrange form with three divisions, like the reference
+// :17-60 - three Lagrange terms (one division each), each a SparsePolynomial::from_coefficients_vec, summed with
+// SparsePolynomial's add: arkworks' canonical form of the sum, explicit zero constant term included where it arises
 inline SparsePolynomial interpolate_quadratic_poly(const Field& f, const std::array<std::pair<F, F>, 3>& pts) {
-  F c[3] = {0, 0, 0};
+  SparsePolynomial sum;
   for (int i = 0; i < 3; ++i) {
     int j = (i + 1) % 3, k = (i + 2) % 3;
     F den = f.mul(f.sub(pts[i].first, pts[j].first), f.sub(pts[i].first, pts[k].first));
     F w = f.mul(pts[i].second, f.inv(den));
-    c[0] = f.add(c[0], f.mul(f.mul(pts[j].first, pts[k].first), w));
-    c[1] = f.add(c[1], f.mul(f.sub(f.neg(pts[j].first), pts[k].first), w));
-    c[2] = f.add(c[2], w);
+    SparsePolynomial term = SparsePolynomial::from_coefficients_vec(
+        {{0, f.mul(f.mul(pts[j].first, pts[k].first), w)}, {1, f.mul(f.sub(f.neg(pts[j].first), pts[k].first), w)}, {2, w}});
+    sum = i == 0 ? term : sum.add(f, term);
   }
-  return SparsePolynomial::from_coefficients_vec({{0, c[0]}, {1, c[1]}, {2, c[2]}});
+  return sum;
 }
 
+// the round polynomial as triangle_counting::G and W hand it out (`p.into()` of a DensePolynomial): non-zero terms only
 inline SparsePolynomial round_poly_from_evals(const Field& f, const F e[3]) {
   F c[3];
   if (sc_interpolate_quadratic(&f.c, e, c) != SC_OK) throw std::runtime_error("sc_interpolate_quadratic");
-  return SparsePolynomial::from_coefficients_vec({{0, c[0]}, {1, c[1]}, {2, c[2]}});
+  return SparsePolynomial::from_dense({c[0], c[1], c[2]});
+}
+
+// the round polynomial as matrix_multiplication::G hands it out (:124-130): the three-term sum over the points 0, 1, 2
+inline SparsePolynomial round_poly_lagrange(const Field& f, const F e[3]) {
+  return interpolate_quadratic_poly(f, {{{f.from_int(0), e[0]}, {f.from_int(1), e[1]}, {f.from_int(2), e[2]}}});
 }
 
 // :12-15
@@ -137,7 +144,7 @@ class G : public SumCheckPolynomial {
   SparsePolynomial to_univariate() const override {
     F e[3];
     ctx().check(sc_prod2_round_sums(ctx().raw(), f_a_->raw(), f_b_->raw(), e), "sc_prod2_round_sums");
-    return round_poly_from_evals(field(), e);
+    return round_poly_lagrange(field(), e);
   }
   size_t num_vars() const override { return f_a_->num_vars(); }
   std::vector<F> to_evaluations() const override {
@@ -164,7 +171,7 @@ class G : public SumCheckPolynomial {
     SparsePolynomial round(F r_prev, size_t j) override {
       F e[3];
       ctx().check(sc_prover_round(h_, r_prev, j, e), "sc_prover_round");
-      return round_poly_from_evals(ctx().field(), e);
+      return round_poly_lagrange(ctx().field(), e);
     }
    private:
     const Context& ctx() const { return f_a_->ctx(); }

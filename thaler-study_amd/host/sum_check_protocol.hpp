@@ -8,6 +8,7 @@
 //
 // Field elements are Montgomery words (uint64_t), exactly ark-ff's Fp64<MontBackend<_,1>>.
 #pragma once
+#include <algorithm>
 #include <cstdint>
 #include <memory>
 #include <optional>
@@ -76,13 +77,44 @@ class BooleanHypercube {
   uint64_t current_;
 };
 
-// ark_poly::univariate::SparsePolynomial<F>: sorted (degree, coeff) terms, zero coefficients dropped
+// ark_poly::univariate::SparsePolynomial<F>: (degree, coeff) terms sorted by degree, in arkworks' canonical form (what
+// serialize_uncompressed puts on the wire, fiat-shamir/src/lib.rs:45-61): from_coefficients_vec pops the TRAILING zero terms
+// of the vector as given, then sorts (zero terms elsewhere stay); add returns the other operand as is when one is zero, else
+// merges, dropping a term of both whose sum is zero and copying a term of one as is; from_dense (`From<DensePolynomial>`)
+// keeps the non-zero coefficients.
 struct SparsePolynomial {
   std::vector<std::pair<size_t, F>> coeffs;
   static SparsePolynomial from_coefficients_vec(std::vector<std::pair<size_t, F>> v) {
+    while (!v.empty() && v.back().second == 0) v.pop_back();
+    std::stable_sort(v.begin(), v.end(), [](const std::pair<size_t, F>& a, const std::pair<size_t, F>& b) { return a.first < b.first; });
+    if (!v.empty() && v.back().second == 0) throw std::logic_error("from_coefficients_vec: the highest term is zero");
     SparsePolynomial p;
-    for (auto& t : v) if (t.second != 0) p.coeffs.push_back(t);
+    p.coeffs = std::move(v);
     return p;
+  }
+  static SparsePolynomial from_dense(const std::vector<F>& dense) {
+    SparsePolynomial p;
+    for (size_t d = 0; d < dense.size(); ++d) if (dense[d] != 0) p.coeffs.push_back({d, dense[d]});
+    return p;
+  }
+  bool is_zero() const { for (auto& t : coeffs) if (t.second != 0) return false; return true; }
+  SparsePolynomial add(const Field& f, const SparsePolynomial& o) const {
+    if (is_zero()) return o;
+    if (o.is_zero()) return *this;
+    SparsePolynomial out;
+    size_t i = 0, k = 0;
+    while (i < coeffs.size() && k < o.coeffs.size()) {
+      if (coeffs[i].first < o.coeffs[k].first) out.coeffs.push_back(coeffs[i++]);
+      else if (coeffs[i].first > o.coeffs[k].first) out.coeffs.push_back(o.coeffs[k++]);
+      else {
+        F c = f.add(coeffs[i].second, o.coeffs[k].second);
+        if (c != 0) out.coeffs.push_back({coeffs[i].first, c});
+        ++i, ++k;
+      }
+    }
+    for (; i < coeffs.size(); ++i) out.coeffs.push_back(coeffs[i]);
+    for (; k < o.coeffs.size(); ++k) out.coeffs.push_back(o.coeffs[k]);
+    return out;
   }
   F evaluate(const Field& f, F x) const {
     F acc = 0;

@@ -24,11 +24,22 @@ def interpolate_quadratic_poly(field, points):
 
 
 def _round_poly_from_evals(ctx, e):
-    """the three sums -> SparsePolynomial through sc_interpolate_quadratic (:124-130)"""
+    """the three sums -> the round polynomial as triangle_counting::G and W hand it out: coefficients through
+    sc_interpolate_quadratic, then `DensePolynomial -> SparsePolynomial` (`p.into()`,
+    triangle-counting/src/lib.rs:129-131, gkr-protocol/src/round_polynomial.rs:87-89): non-zero terms only"""
     ev = (u64 * 3)(*[int(x) for x in e])
     c = (u64 * 3)()
     ctx.check(ctx.lib.sc_interpolate_quadratic(ctx.field.ref(), ev, c))
-    return SparsePolynomial.from_coefficients_vec(ctx.field, [(d, int(c[d])) for d in range(3)])
+    return SparsePolynomial.from_dense(ctx.field, [int(c[d]) for d in range(3)])
+
+
+def _round_poly_lagrange(ctx, e):
+    """the three sums -> the round polynomial as matrix_multiplication::G hands it out (:124-130): the sum of three
+    Lagrange terms, which in arkworks' canonical form can carry an explicit zero constant term (e.g. H(0) = H(2) = 0)
+    - the same values as sc_interpolate_quadratic's, and on the wire the reference's bytes"""
+    f = ctx.field
+    poly = interpolate_quadratic_poly(f, [(f.zero, int(e[0])), (f.one, int(e[1])), (f.two, int(e[2]))])
+    return poly
 
 
 class _NativeProver:
@@ -54,7 +65,7 @@ class _NativeProver:
         return self.last_evals
 
     def round(self, r_prev, j):
-        return _round_poly_from_evals(self.ctx, self.round_evals(r_prev, j))
+        return _round_poly_lagrange(self.ctx, self.round_evals(r_prev, j))
 
     def __del__(self):
         try:
@@ -118,7 +129,7 @@ class G(SumCheckPolynomial):
         return [int(x) for x in e]
 
     def to_univariate(self):
-        return _round_poly_from_evals(self.ctx, self.round_evals())
+        return _round_poly_lagrange(self.ctx, self.round_evals())
 
     def fold_and_univariate(self, r):
         """fix_variables(&[r]) + to_univariate in one pass over HBM"""
@@ -128,7 +139,7 @@ class G(SumCheckPolynomial):
         self.ctx.check(self.ctx.lib.sc_prod2_fold_and_sums(self.ctx.h, self.f_a.h, self.f_b.h, rr,
                                                           ctypes.byref(ha), ctypes.byref(hb), e))
         g = G(DenseMultilinearExtension(self.ctx, ha), DenseMultilinearExtension(self.ctx, hb))
-        return g, _round_poly_from_evals(self.ctx, [int(x) for x in e])
+        return g, _round_poly_lagrange(self.ctx, [int(x) for x in e])
 
     def num_vars(self):
         return self.f_a.num_vars() + self._log_world()

@@ -64,19 +64,34 @@ class BooleanHypercube:
 
 
 class SparsePolynomial:
-    """ark_poly::univariate::SparsePolynomial<F>: sorted (degree, coeff) pairs, zero
-    coefficients dropped (`from_coefficients_vec`)."""
+    """ark_poly::univariate::SparsePolynomial<F>: (degree, coeff) terms sorted by degree, in arkworks'
+    canonical form - which is what `serialize_uncompressed` puts on the wire (fiat-shamir/src/lib.rs:45-61):
+
+      from_coefficients_vec  pops the TRAILING zero terms of the vector as given, then sorts; zero terms
+                             elsewhere stay
+      a + b                  if a is zero: b as is; if b is zero: a as is; else a merge in which a term of
+                             both is dropped when the sum is zero and a term of one is copied as is
+      from_dense             (`From<DensePolynomial>`) keeps the non-zero coefficients only"""
 
     def __init__(self, field, coeffs):
         self.field = field
-        merged = {}
-        for d, c in coeffs:
-            merged[d] = field.add(merged.get(d, 0), c)
-        self.coeffs = sorted((d, c) for d, c in merged.items() if c != 0)
+        self.coeffs = [(int(d), int(c)) for d, c in coeffs]
 
     @classmethod
     def from_coefficients_vec(cls, field, coeffs):
+        coeffs = [(int(d), int(c)) for d, c in coeffs]
+        while coeffs and coeffs[-1][1] == 0:
+            coeffs.pop()
+        coeffs.sort(key=lambda t: t[0])
+        assert not coeffs or coeffs[-1][1] != 0, "from_coefficients_vec: the highest term is zero (arkworks panics here)"
         return cls(field, coeffs)
+
+    @classmethod
+    def from_dense(cls, field, dense):
+        return cls(field, [(d, int(c)) for d, c in enumerate(dense) if int(c) != 0])
+
+    def is_zero(self):
+        return all(c == 0 for _, c in self.coeffs)
 
     def evaluate(self, x):
         f = self.field
@@ -92,7 +107,24 @@ class SparsePolynomial:
         return self.coeffs[-1][0] if self.coeffs else 0
 
     def __add__(self, other):
-        return SparsePolynomial(self.field, self.coeffs + other.coeffs)
+        if self.is_zero():
+            return SparsePolynomial(self.field, other.coeffs)
+        if other.is_zero():
+            return SparsePolynomial(self.field, self.coeffs)
+        a, b, out, i, k = self.coeffs, other.coeffs, [], 0, 0
+        while i < len(a) and k < len(b):
+            if a[i][0] < b[k][0]:
+                out.append(a[i])
+                i += 1
+            elif a[i][0] > b[k][0]:
+                out.append(b[k])
+                k += 1
+            else:
+                c = self.field.add(a[i][1], b[k][1])
+                if c != 0:
+                    out.append((a[i][0], c))
+                i, k = i + 1, k + 1
+        return SparsePolynomial(self.field, out + a[i:] + b[k:])
 
     def __eq__(self, other):
         return isinstance(other, SparsePolynomial) and self.coeffs == other.coeffs
