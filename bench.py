@@ -140,11 +140,48 @@ def all_agree(torch, dist, ok):
 
 
 def load_traffic(key):
+    """the PMC record of one workload from profiles/traffic.json (the builder's rocprofv3 --pmc runs; this run cannot collect its
+    own: the profiler has to wrap the program from its start) - or None when the record was measured on other kernel sources than
+    the ones in this tree (tools/provenance.py: a fingerprint of thaler-study_amd/csrc stored with every record)"""
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if not os.path.exists(tpath):
         return None
     with open(tpath) as f:
-        return json.load(f).get(key)
+        rec = json.load(f).get(key)
+    if rec is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import provenance
+    prov = rec.get("provenance") or {}
+    now = provenance.csrc_fingerprint()
+    rec["_stale"] = None if prov.get("csrc_sha16") == now else (
+        "profiles/traffic.json[%s] was measured on kernel sources %s (%s), this tree has %s: PMC bytes withheld until "
+        "tools/refresh_profiles.sh is run again" % (key, prov.get("csrc_sha16") or "without a fingerprint", prov.get("tag") or rec.get("source", "?")[:3], now))
+    return rec
+
+
+def traffic_source(rec):
+    """`roofline.traffic_source`: which run the PMC bytes belong to"""
+    prov = rec.get("provenance") or {}
+    return ("profiles/traffic.json: `%s` on the builder's GPU box, %s, commit %s, kernel sources %s (= this tree's); FETCH_SIZE x 2 KiB + "
+            "WRITE_SIZE x 1 KiB per MI355X_MICROARCH.md; not collected in this run, handed out only if this run's launch-log bytes agree "
+            "within 2 %%" % (prov.get("command"), prov.get("date"), prov.get("commit") or "not recorded", prov.get("csrc_sha16")))
+
+
+def reference_probe():
+    """could the reference itself (Rust) be timed beside the GPU on this box?  It needs cargo, an
+    offline registry holding the arkworks crates, and the reference's sources - which bench.py may not read at run time on the
+    GPU box (they are not there).  Returns what was found; the CPU baseline stays the C port unless all three exist."""
+    import glob
+    import shutil
+    cargo = shutil.which("cargo")
+    home = os.environ.get("CARGO_HOME") or os.path.expanduser("~/.cargo")
+    crates = glob.glob(os.path.join(home, "registry", "src", "*", "ark-poly-*")) + glob.glob(os.path.join(ROOT, "rust", "vendor", "ark-poly*"))
+    src = os.environ.get("SC_REFERENCE_DIR")
+    have_src = bool(src) and os.path.isfile(os.path.join(src, "matrix-multiplication", "Cargo.toml"))
+    return {"cargo": cargo or "absent", "rustc": shutil.which("rustc") or "absent", "offline_ark_crates": bool(crates),
+            "reference_sources": src if have_src else "absent (SC_REFERENCE_DIR unset; never on the GPU box)",
+            "usable": bool(cargo) and bool(crates) and have_src}
 
 
 def attach_plane(plane, pkg, ctx, rank, world, dist):
@@ -551,7 +588,10 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
         tkey = "n%d_gpus%d_vpp%d_first%d" % (n, world, args.vars_per_pass, first_pass) + ("" if FIELD["name"] == "GoldilocksMont" else "_generic")
         tj = load_traffic(tkey)
         traffic, traffic_step, traffic_check = None, None, "no PMC record for %s in profiles/traffic.json" % tkey
-        if tj:
+        if tj and tj["_stale"]:
+            traffic_check = tj["_stale"]
+            sys.stderr.write("bench.py: " + traffic_check + "\n")
+        elif tj:
             traffic_step = tj.get("hbm_bytes_per_step")
             per_kernel = tj.get("kernels", {})
             if dom and dom["kernel"] in per_kernel:
@@ -608,8 +648,7 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                 "unit": "GB/s",
                 "frac": dom["GBps"] / HBM_PEAK_GBS if dom and dom["GBps"] else None,
                 "traffic": traffic,
-                "traffic_source": ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE of the same command on the builder's box "
-                                   "(not collected in this run; used only if this run's launch-log bytes agree within 2 %)") if traffic else None,
+                "traffic_source": traffic_source(tj) if traffic else traffic_check,
                 "bytes_per_launch": dom["bytes_per_launch"] if dom else None,
                 "avg_launch_us": dom["avg_us"] if dom else None,
                 "per_gpu": True,
@@ -636,9 +675,11 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
             },
         }
 
-    # ---- CPU baseline: the reference-shaped port, 1 core, bounded sample (N = 1 only) -------
+    # ---- CPU baseline: the reference-shaped port, 1 core, bounded sample - on rank 0's host cores, at every N (the CPU
+    # prover does not shard: a line of an N-GPU run carries the same baseline an N = 1 run on this box would) ----------------
     nc = cpu_sample_size(args.cpu_num_vars)
-    if rank == 0 and world == 1 and nc > 0:
+    probe = reference_probe() if rank == 0 else None
+    if rank == 0 and nc > 0:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         from oracle import Oracle   # the checker / CPU baseline: only this leg touches oracle/
         import pyref
@@ -654,13 +695,21 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
         cpu_mt_s = time.perf_counter() - tc
         if c1_mt != c1_cpu or not np.array_equal(ev_mt, ev_cpu):
             raise SystemExit("oracle: multi-threaded and single-threaded runs disagree")
-        # the same sample through the GPU path must agree bit for bit
-        del a, b, g
-        ga, gb = syn.tables(ctx, nc)
-        c1_gpu, ev_gpu, ch_gpu = mm.prove(ctx, mm.G(ga, gb), syn.SEED_R)
-        if c1_gpu != c1_cpu or not np.array_equal(ev_gpu, ev_cpu) or not np.array_equal(ch_gpu, och):
-            raise SystemExit("PARITY FAILURE: GPU and CPU oracle disagree at n=%d" % nc)
-        result["config"]["parity_gate"] += "; bit-exact vs CPU oracle at n=%d ok" % nc
+        del oa, ob
+        if world == 1:
+            # the same sample through the GPU path must agree bit for bit
+            del a, b, g
+            ga, gb = syn.tables(ctx, nc)
+            c1_gpu, ev_gpu, ch_gpu = mm.prove(ctx, mm.G(ga, gb), syn.SEED_R)
+            if c1_gpu != c1_cpu or not np.array_equal(ev_gpu, ev_cpu) or not np.array_equal(ch_gpu, och):
+                raise SystemExit("PARITY FAILURE: GPU and CPU oracle disagree at n=%d" % nc)
+            result["config"]["parity_gate"] += "; bit-exact vs CPU oracle at n=%d ok" % nc
+        elif nc == n:
+            # N > 1: the sharded proofs that were timed ARE this instance (same n, same seeds): their transcript - identical on
+            # every plane, checked above - against the oracle's, bit for bit
+            if best["transcript"] != (c1_cpu, ev_cpu.tobytes()):
+                raise SystemExit("PARITY FAILURE: the sharded GPU transcript and the CPU oracle disagree at n=%d over %d ranks" % (n, world))
+            result["config"]["parity_gate"] += "; the timed %d-rank transcript is bit-exact vs the CPU oracle at n=%d" % (world, n)
         result["cpu_baseline"] = {
             "value": (5 * 2**nc - 7) / cpu_s,
             "unit": "field mul-adds/s",
@@ -669,18 +718,24 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
             "kind": "port",
             "sample": "same synthetic workload at n=%d (%d mul-adds, %.1f s): oracle/sc_oracle.c sco_prover_run, the "
                       "reference-shaped single-thread C restatement (clone + multiply + sum for c_1, copy-fold-copy "
-                      "per table per round, separate sum pass); the Rust reference cannot be built here" % (
-                          nc, 5 * 2**nc - 7, cpu_s),
+                      "per table per round, separate sum pass)%s; the Rust reference itself: %s" % (
+                          nc, 5 * 2**nc - 7, cpu_s,
+                          "" if world == 1 else "; timed on rank 0's host cores while the other ranks wait - the CPU prover is one process whatever N is",
+                          "cargo %s, offline arkworks crates %s, reference sources %s -> not buildable here" % (
+                              "present" if probe["cargo"] != "absent" else "absent", "present" if probe["offline_ark_crates"] else "absent",
+                              "present" if probe["usable"] or not probe["reference_sources"].startswith("absent") else "absent")),
+            "reference_probe": probe,
             "all_cores": {"value": (5 * 2**nc - 7) / cpu_mt_s, "cores": os.cpu_count(), "seconds": cpu_mt_s,
                           "note": "same port with the element loops split over OpenMP threads (BASELINE.md CPU-ref-allT)"},
         }
         # ---- BASELINE configs[1] and configs[2] beside the headline: driver-visible, each with its own
         # in-run oracle gate; after the timed region, a few seconds in all
-        if n == 28 and os.environ.get("SC_BENCH_SECONDARY", "1") == "1":
+        if world == 1 and n == 28 and os.environ.get("SC_BENCH_SECONDARY", "1") == "1":
             del ga, gb
             result["config"]["secondary"] = secondary_configs(pkg, ctx, o, np)
     elif rank == 0:
         result["cpu_baseline"] = None
+        result["config"]["reference_probe"] = probe
     return result
 
 
@@ -861,7 +916,7 @@ def run_mle(args, pkg, torch, dist, rank, world, local_rank):
     tkey = "mle_n%d" % n
     tj = load_traffic(tkey)
     traffic = None
-    if tj and dom["kernel"] in tj.get("kernels", {}):
+    if tj and not tj["_stale"] and dom["kernel"] in tj.get("kernels", {}):
         traffic = tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
     result = {
         "metric": "field mul-adds/sec, multilinear-extensions evaluate + fix_variable, n=%d" % n,
@@ -935,7 +990,7 @@ def roofline_from_log(log, steps, dominant_kind, traffic_key, note, kernel_ms, n
     dom = next((k for k in kernels if k["_key"][0] == dominant_kind), kernels[0])
     tj = load_traffic(traffic_key)
     traffic = None
-    if tj and dom["kernel"] in tj.get("kernels", {}):
+    if tj and not tj["_stale"] and dom["kernel"] in tj.get("kernels", {}):
         traffic = tj["kernels"][dom["kernel"]]["hbm_bytes_per_launch"]
     return {
         "bound": "hbm",
@@ -945,6 +1000,7 @@ def roofline_from_log(log, steps, dominant_kind, traffic_key, note, kernel_ms, n
         "unit": "GB/s",
         "frac": dom["GBps"] / HBM_PEAK_GBS if dom["GBps"] else None,
         "traffic": traffic,
+        "traffic_source": traffic_source(tj) if traffic else (tj["_stale"] if tj else "no PMC record for %s in profiles/traffic.json" % traffic_key),
         "bytes_per_launch": dom["bytes_per_launch"],
         "avg_launch_us": dom["avg_us"],
         "step": {"bytes_moved": moved, "kernel_ms": kernel_ms_per_step, "launches": n_launch / steps,

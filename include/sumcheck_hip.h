@@ -160,6 +160,11 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      ranks' launches of the same pass that is tolerated (default 2000); past it the pass fails
  *                      with SC_ERR_RCCL on every rank that waited.  "peer_connect_ms" (default 120000): how long
  *                      sc_ctx_comm_peer_connect waits for every peer's hello (absorbs the start-up lag of a job)
+ *   "rccl_timeout_ms"  RCCL plane: how long the host waits for work queued behind a collective - a sharded pass's sums, a
+ *                      gathered table - before it gives the communicator up (default 30000).  A collective whose peer is gone
+ *                      (a rank that died or is out of step) never completes on its own; past the bound, or as soon as
+ *                      ncclCommGetAsyncError reports an error, the library calls ncclCommAbort, poisons the context and
+ *                      returns SC_ERR_RCCL from the call that waited and from every later one
  *   "dbg_delay_ms" / "dbg_skip_tag"   fault injection for tests: delay every sharded launch of this rank on the
  *                      host / make its next sharded launch skip an exchange tag (a rank out of step)
  *   "pool_contiguous"  experiments: 1 = pool blocks of >= 1 MiB are asked for as physically contiguous VRAM
@@ -171,9 +176,12 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      would pay on this context - the library's code object on the device, the resident-grid queries of the plan's
  *                      kernels, the matrix-core pass's workspace, the pool blocks of every folded table - for callers that prove
  *                      once (mm_benchmark.rs:88-96 builds g and proves).  On a multi-device handle every device does its shard's
+ *                      share of this (the handle must be healthy: a poisoned handle refuses with SC_ERR_STATE like any other call)
  *   "stat_reset"       (set) zeroes, and "stat_wait_ns" / "stat_launch_ns" (get) read, where a proof's wall time goes on the host:
  *                      ns spent waiting for pass kernels (their run time + launch latency) and ns inside the pass launches (buffers,
- *                      weights, hipLaunchKernelGGL); the rest is host arithmetic between them.  Always on (four clock reads per pass)
+ *                      weights, hipLaunchKernelGGL); the rest is host arithmetic between them.  Always on (four clock reads per pass).
+ *                      On a multi-device handle both read the FIRST device's context only (the devices run side by side: their
+ *                      waits overlap, a sum would count the same wall time N times)
  *   "nt_load_log" / "nt_store_log"  table log-size from which loads / stores are nontemporal
  * Environment: SC_RCCL_LIBRARY = the RCCL build sc_ctx_comm_init_rccl / sc_comm_unique_id dlopen (a path; default librccl.so.1).
  * That library or nothing: a path that cannot be loaded is an error, never a silent second choice. */

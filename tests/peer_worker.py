@@ -1,5 +1,6 @@
-"""One rank of the multi-process transport tests (launched by torch.distributed.run; every rank on GPU 0).
-SC_PEER_WORKER_MODE = parity | faults | widened | rccl_death.  Not collected by pytest.
+"""One rank of the multi-process transport tests (launched by torch.distributed.run; every rank on GPU 0 - or, with
+SC_WORKER_DISTINCT_DEVICES=1 on a box that has them, rank r on GPU r: tests/test_gpu_multi_device.py).
+SC_PEER_WORKER_MODE = parity | faults | widened | rccl_death | headline.  Not collected by pytest.
 SC_WORKER_TRANSPORT = peer (default: the in-kernel exchange over HIP IPC) | rccl (Transport::kRccl: ncclAllReduce behind every
 sharded pass, ncclAllGather at the tail - on a one-GPU box through tests/rccl_double, selected by SC_RCCL_LIBRARY, because
 RCCL itself refuses two ranks on one device).
@@ -22,6 +23,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 
 TRANSPORT = os.environ.get("SC_WORKER_TRANSPORT", "peer")
+DISTINCT = os.environ.get("SC_WORKER_DISTINCT_DEVICES", "0") == "1"
+DEVICE = int(os.environ.get("LOCAL_RANK", "0")) if DISTINCT else 0
 
 
 def attach(pkg, ctx, rank, world):
@@ -48,7 +51,7 @@ def parity(pkg, dist, pyref, Oracle, rank, world):
     D = pkg.distributed
     for p in (pyref.GOLDILOCKS, 389):
         o = Oracle(p)
-        ctx = pkg.Context(pkg.Field(p), device=0)
+        ctx = pkg.Context(pkg.Field(p), device=DEVICE)
         attach(pkg, ctx, rank, world)
         # grid_sharded 1: the shards go on with five-round passes (cells exchanged inside the kernel) down to one entry;
         # 0: two-round passes with the exchange, gather at tail_log, unsharded tail
@@ -122,7 +125,7 @@ def widened(pkg, dist, pyref, Oracle, rank, world):
     o = Oracle(p)
     F = pkg.Field(p)
     g_ = world.bit_length() - 1
-    ctx = pkg.Context(F, device=0)
+    ctx = pkg.Context(F, device=DEVICE)
     if TRANSPORT == "peer":
         ctx.set_option("arena_log", 8)
     attach(pkg, ctx, rank, world)
@@ -206,7 +209,7 @@ def faults(pkg, dist, pyref, Oracle, rank, world):
         return o.prove(o.generate(sa, n), o.generate(sb, n), ch), ch
 
     # ---- 1. a late rank: every sharded launch of one rank delayed by 1 .. 100 ms -------------------------------------
-    ctx = pkg.Context(F, device=0)
+    ctx = pkg.Context(F, device=DEVICE)
     D.attach_peer(ctx, rank, world)
     for n, gs, delay_rank, delay in [(14, 1, 0, 1), (14, 0, world - 1, 7), (18, 1, world - 1, 30), (12, 0, 0, 100), (20, 1, 1 % world, 3)]:
         ctx.set_option("grid_sharded", gs)
@@ -256,7 +259,7 @@ def faults(pkg, dist, pyref, Oracle, rank, world):
     ctx.close()
 
     # ---- 3. gathers longer than the arena go in chunks --------------------------------------------------------------
-    ctx = pkg.Context(F, device=0)
+    ctx = pkg.Context(F, device=DEVICE)
     ctx.set_option("arena_log", 6)                 # 64 words per rank and chunk
     D.attach_peer(ctx, rank, world)
     ctx.set_option("grid_sharded", 0)
@@ -274,7 +277,7 @@ def faults(pkg, dist, pyref, Oracle, rank, world):
 
     # ---- 4. a rank out of step (skips an exchange tag): every rank fails with SC_ERR_RCCL within the bound -----------
     for gs in (1, 0):
-        ctx = pkg.Context(F, device=0)
+        ctx = pkg.Context(F, device=DEVICE)
         ctx.set_option("peer_spin_ms", 400)
         D.attach_peer(ctx, rank, world)
         ctx.set_option("grid_sharded", gs)
@@ -314,9 +317,13 @@ def rccl_death(pkg, dist, pyref, Oracle, rank, world):
     context afterwards - and never hang or return a transcript"""
     p = pyref.GOLDILOCKS
     o = Oracle(p)
-    ctx = pkg.Context(pkg.Field(p), device=0)
+    ctx = pkg.Context(pkg.Field(p), device=DEVICE)
     attach(pkg, ctx, rank, world)
     n = 14
+    bound_ms = int(os.environ.get("SC_WORKER_RCCL_TIMEOUT_MS", "0"))
+    if bound_ms:      # the library's own bound on a collective that never completes (the real librccl; the double in its async mode)
+        ctx.set_option("rccl_timeout_ms", bound_ms)
+        assert ctx.get_option("rccl_timeout_ms") == bound_ms
     a, b, _ = shard_tables(pkg, ctx, pyref, n, rank, world)
     g = pkg.matrix_multiplication.G(a, b)
     dist.barrier()
@@ -334,8 +341,10 @@ def rccl_death(pkg, dist, pyref, Oracle, rank, world):
         raise AssertionError("a proof finished although a rank is dead")
     except pkg.SumcheckHipError as e:
         assert e.code == 3, e                                                   # SC_ERR_RCCL
+        if bound_ms and os.environ.get("SC_RCCL_DOUBLE_ASYNC_HANG") == "1":
+            assert "rccl_timeout_ms" in str(e) and "aborted" in str(e), e       # ended by the library's bound, not by the stand-in
     took = time.perf_counter() - t0
-    assert took < 15.0, took                                                    # bounded (the bound was set to 1.5 s), not a hang
+    assert took < 15.0 + 1e-3 * bound_ms, took                                  # bounded (1.5 s in the double, bound_ms in the library), not a hang
     try:                                                                        # and every later collective fails at once
         t0 = time.perf_counter()
         pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
@@ -348,6 +357,52 @@ def rccl_death(pkg, dist, pyref, Oracle, rank, world):
     os._exit(0)      # (no control-plane barrier: a rank is gone)
 
 
+def headline(pkg, dist, pyref, Oracle, rank, world):
+    """BASELINE configs[3] as it is stated: the n = 28 hypercube over the ranks' devices, one process per GPU, the sums crossing
+    the ranks on the chosen data plane - compared round for round with the CPU oracle's transcript (rank 0 computes it with the
+    all-cores form of the reference-shaped prover and hands it to the others over the control plane)."""
+    import torch
+    p = pyref.GOLDILOCKS
+    o = Oracle(p)
+    ctx = pkg.Context(pkg.Field(p), device=DEVICE)
+    attach(pkg, ctx, rank, world)
+    devs = [None] * world
+    dist.all_gather_object(devs, (DEVICE, torch.cuda.device_count()))
+    if DISTINCT:
+        assert len({d for d, _ in devs}) == world, devs                          # one GPU per rank, all different
+    for n in [int(x) for x in os.environ.get("SC_WORKER_NUM_VARS", "20,28").split(",")]:
+        ref = [None]
+        if rank == 0:
+            oa, ob = o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n)
+            ch = np.array([o.challenge(pyref.SEED_R, j + 1) for j in range(n)], dtype=np.uint64)
+            c1, ev = o.prover_run_mt(oa, ob, ch)
+            del oa, ob
+            ref = [(int(c1), ev.tolist(), ch.tolist())]
+        dist.broadcast_object_list(ref, src=0)
+        c1_ref, ev_ref, ch_ref = ref[0]
+        a, b, nl = shard_tables(pkg, ctx, pyref, n, rank, world)
+        g = pkg.matrix_multiplication.G(a, b)
+        for rep in range(2):                                                       # cold, then warm (pool, communicator, tickets reused)
+            ctx.set_option("time_kernels", 1)
+            ctx.launch_log(reset=True)
+            dist.barrier()
+            c1, evals, ch = pkg.matrix_multiplication.prove(ctx, g, pyref.SEED_R)
+            log = ctx.launch_log(reset=True)
+            ctx.set_option("time_kernels", 0)
+            assert [int(x) for x in ch] == ch_ref and c1 == c1_ref, (n, rep, "c_1")
+            bad = [j for j in range(n) if [int(x) for x in evals[j]] != ev_ref[j]]
+            assert not bad, (n, rep, "rounds that differ from the oracle", bad)
+            plan = pkg.schedule.plan_proof(n, world, "rccl" if TRANSPORT == "rccl" else "peer")
+            assert [(r["kind"], r["kf"], r["ks"]) for r in log] == \
+                [(s["action"], s["kf"], s["ks"]) for s in plan if s["action"] not in ("host_tail", "gather")], (log, plan)
+        assert g.evaluate(ch_ref) is not None
+        del a, b, g
+        dist.barrier()
+    assert ctx.get_option("comm_nranks") == world
+    ctx.close()
+    print("HEADLINE-OK rank %d device %d" % (rank, DEVICE), flush=True)
+
+
 def main():
     import torch
     import torch.distributed as dist
@@ -355,11 +410,11 @@ def main():
     import pyref
     from oracle import Oracle
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-    torch.cuda.set_device(0)
+    torch.cuda.set_device(DEVICE)
     dist.init_process_group(backend="gloo", rank=rank, world_size=world)
     pkg = ge.load_package()
     mode = os.environ.get("SC_PEER_WORKER_MODE", "parity")
-    {"parity": parity, "faults": faults, "widened": widened, "rccl_death": rccl_death}[mode](pkg, dist, pyref, Oracle, rank, world)
+    {"parity": parity, "faults": faults, "widened": widened, "rccl_death": rccl_death, "headline": headline}[mode](pkg, dist, pyref, Oracle, rank, world)
     dist.barrier()
     dist.destroy_process_group()
 

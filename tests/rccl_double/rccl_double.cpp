@@ -13,6 +13,10 @@
 // What it is for: 2 / 4 / 8 processes on one device through sc_ctx_comm_init_rccl - sharded proofs, the tail gather,
 // comm_nranks, a rank that dies (the survivors' collectives fail with ncclSystemError after SC_RCCL_DOUBLE_TIMEOUT_MS,
 // default 20 s, and the library turns that into SC_ERR_RCCL).  What it is NOT: a measurement of RCCL or of xGMI.
+//
+// SC_RCCL_DOUBLE_ASYNC_HANG=1 makes a missing rank look the way it looks under the real library: the collective call returns
+// ncclSuccess and what it queued on the stream never completes (here: a host function that blocks the stream until
+// ncclCommAbort), so the product's own bound - option "rccl_timeout_ms": abort, poison, SC_ERR_RCCL - is what ends the wait.
 #include <fcntl.h>
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
@@ -48,6 +52,7 @@ struct ncclComm {
   Shm* shm = nullptr;
   int rank = 0, nranks = 1;
   char name[64] = {0};
+  std::atomic<int>* aborted = new std::atomic<int>(0);   // (never freed: a blocked host function may still look at it)
 };
 
 namespace {
@@ -74,6 +79,20 @@ bool barrier(ncclComm* c) {
   return true;
 }
 bool usable(ncclComm_t c, ncclDataType_t t) { return c && c->shm && t == ncclUint64 && !c->shm->dead.load(); }
+
+void block_until_abort(void* p) {
+  std::atomic<int>* aborted = (std::atomic<int>*)p;
+  const auto t0 = std::chrono::steady_clock::now();
+  while (!aborted->load(std::memory_order_acquire) &&
+         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 120.0)   // (a test that forgets to abort still ends)
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+}
+// a rank is missing: fail at once (the default), or behave like the real library - success now, a stream that never gets on
+ncclResult_t rank_missing(ncclComm* c, hipStream_t stream) {
+  const char* e = getenv("SC_RCCL_DOUBLE_ASYNC_HANG");
+  if (!e || !*e || *e == '0') return ncclSystemError;
+  return hipLaunchHostFunc(stream, block_until_abort, c->aborted) == hipSuccess ? ncclSuccess : ncclUnhandledCudaError;
+}
 }  // namespace
 
 extern "C" {
@@ -134,6 +153,20 @@ ncclResult_t ncclCommDestroy(ncclComm_t c) {
   return ncclSuccess;
 }
 
+// ncclCommAbort: whatever this communicator left on a stream gives way; the communicator is gone afterwards
+ncclResult_t ncclCommAbort(ncclComm_t c) {
+  if (!c) return ncclSuccess;
+  c->aborted->store(1, std::memory_order_release);
+  if (c->shm) c->shm->dead.store(1);
+  return ncclCommDestroy(c);
+}
+
+ncclResult_t ncclCommGetAsyncError(ncclComm_t c, ncclResult_t* st) {
+  if (!c || !st) return ncclInvalidArgument;
+  *st = ncclSuccess;   // (like the real library between ranks of one node: a peer that stops is not noticed, its kernel just waits)
+  return ncclSuccess;
+}
+
 ncclResult_t ncclCommCount(const ncclComm_t c, int* count) {
   if (!c || !count) return ncclInvalidArgument;
   *count = c->nranks;
@@ -142,7 +175,7 @@ ncclResult_t ncclCommCount(const ncclComm_t c, int* count) {
 
 ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, ncclDataType_t datatype, ncclRedOp_t op, ncclComm_t c,
                            hipStream_t stream) {
-  if (!usable(c, datatype) || op != ncclSum || !sendbuff || !recvbuff) return c && c->shm && c->shm->dead.load() ? ncclSystemError : ncclInvalidArgument;
+  if (!usable(c, datatype) || op != ncclSum || !sendbuff || !recvbuff) return c && c->shm && c->shm->dead.load() ? rank_missing(c, stream) : ncclInvalidArgument;
   c->shm->calls[c->rank].fetch_add(1);
   std::vector<uint64_t> total;
   for (size_t off = 0; off < count; off += kSlotWords) {
@@ -150,7 +183,7 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
     if (hipMemcpyAsync(c->shm->slot[c->rank], (const uint64_t*)sendbuff + off, n * 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess)
       return ncclUnhandledCudaError;
-    if (!barrier(c)) return ncclSystemError;
+    if (!barrier(c)) return rank_missing(c, stream);
     total.assign(n, 0);
     for (int q = 0; q < c->nranks; ++q)
       for (size_t i = 0; i < n; ++i) total[i] += c->shm->slot[q][i];
@@ -163,14 +196,14 @@ ncclResult_t ncclAllReduce(const void* sendbuff, void* recvbuff, size_t count, n
 }
 
 ncclResult_t ncclAllGather(const void* sendbuff, void* recvbuff, size_t sendcount, ncclDataType_t datatype, ncclComm_t c, hipStream_t stream) {
-  if (!usable(c, datatype) || !sendbuff || !recvbuff) return c && c->shm && c->shm->dead.load() ? ncclSystemError : ncclInvalidArgument;
+  if (!usable(c, datatype) || !sendbuff || !recvbuff) return c && c->shm && c->shm->dead.load() ? rank_missing(c, stream) : ncclInvalidArgument;
   c->shm->calls[c->rank].fetch_add(1);
   for (size_t off = 0; off < sendcount; off += kSlotWords) {
     const size_t n = sendcount - off < kSlotWords ? sendcount - off : kSlotWords;
     if (hipMemcpyAsync(c->shm->slot[c->rank], (const uint64_t*)sendbuff + off, n * 8, hipMemcpyDeviceToHost, stream) != hipSuccess ||
         hipStreamSynchronize(stream) != hipSuccess)
       return ncclUnhandledCudaError;
-    if (!barrier(c)) return ncclSystemError;
+    if (!barrier(c)) return rank_missing(c, stream);
     for (int q = 0; q < c->nranks; ++q)
       if (hipMemcpyAsync((uint64_t*)recvbuff + (size_t)q * sendcount + off, c->shm->slot[q], n * 8, hipMemcpyHostToDevice, stream) != hipSuccess)
         return ncclUnhandledCudaError;

@@ -63,7 +63,12 @@ def test_bench_two_ranks_on_one_device():
     # (HIP IPC between the two processes) works on one device; RCCL refuses two ranks on one GPU ("Duplicate GPU
     # detected"), which the line must say instead of hiding - on a multi-GPU node both carry a time; and the one-process
     # plane: rank 0 alone over ONE handle of two devices (sc_ctx_create_multi), the other rank only at the barriers.
-    d = _one_line(_bench(args, port=port + 1))
+    # (with a CPU sample of the same size: an N > 1 line carries cpu_baseline too, and the timed sharded transcript is compared
+    # with the oracle's bit for bit - VERDICT r05 next 1)
+    d = _one_line(_bench(args[:-1] + ["20"], port=port + 1))
+    assert d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0 and "rank 0's host cores" in d["cpu_baseline"]["sample"]
+    assert d["cpu_baseline"]["reference_probe"]["cargo"] == "absent" or d["cpu_baseline"]["reference_probe"]["cargo"].startswith("/")
+    assert "2-rank transcript is bit-exact vs the CPU oracle at n=20" in d["config"]["parity_gate"]
     tr = d["config"]["transports"]
     assert d["n_gpus"] == 2 and d["config"]["transport"].split(" ")[0].split("(")[0] in ("peer", "inproc") and d["value"] > 0
     assert set(tr) == {"peer", "rccl", "inproc"}
@@ -210,12 +215,27 @@ def test_rccl_plane_a_rank_that_dies(nproc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("nproc", [2, 4])
+def test_rccl_plane_a_collective_that_never_completes(nproc):
+    """what a dead rank looks like under the REAL library: ncclAllReduce returns ncclSuccess and what it queued never completes
+    (the double's SC_RCCL_DOUBLE_ASYNC_HANG mode: a host function blocks the stream until ncclCommAbort).  The LIBRARY's bound
+    must end the wait: option "rccl_timeout_ms" -> ncclCommAbort, SC_ERR_RCCL naming the bound, a poisoned context, no hang"""
+    out = _workers(nproc, "rccl_death", 30550 + (os.getpid() % 40) + nproc, timeout=300, transport="rccl",
+                   extra_env={"SC_RCCL_DOUBLE_TIMEOUT_MS": "300", "SC_RCCL_DOUBLE_ASYNC_HANG": "1", "SC_WORKER_RCCL_TIMEOUT_MS": "1500"})
+    assert out.stdout.count("RCCL-DEATH-OK") == nproc - 1, (_quiet(out.stdout, 3000), _quiet(out.stderr))
+
+
+@pytest.mark.gpu
 def test_bench_eight_ranks_all_three_planes():
     """`bench.py --gpus 8` through the driver's launch line with the RCCL double in place: ONE line with all three data planes
     timed - peer, rccl (comm_nranks 8 from the transport itself), inproc - and the same transcript on each"""
     port = 29760 + (os.getpid() % 90)
-    d = _one_line(_bench(["--gpus", "8", "--num-vars", "24", "--steps", "4", "--warmup", "1", "--cpu-num-vars", "0"],
+    d = _one_line(_bench(["--gpus", "8", "--num-vars", "24", "--steps", "4", "--warmup", "1", "--cpu-num-vars", "24"],
                          {"SC_RCCL_LIBRARY": RCCL_DOUBLE}, nproc=8, port=port, timeout=900))
+    # the five keys of a measured line (SURVEY 8d), at N = 8
+    assert d["value"] > 0 and d["config"]["workload"] and d["roofline"]["frac"] > 0 and d["roofline"]["per_gpu"] is True
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["cores"] == 1 and d["cpu_baseline"]["value"] > 0
+    assert "8-rank transcript is bit-exact vs the CPU oracle at n=24" in d["config"]["parity_gate"]
     tr = d["config"]["transports"]
     assert set(tr) == {"peer", "rccl", "inproc"}
     for plane in ("peer", "rccl", "inproc"):

@@ -53,6 +53,9 @@ struct RcclApi {
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t,
                             hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  // optional (every RCCL has them; a stand-in may not): what bounds a collective whose peer is gone
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;
 };
 
 RcclApi g_rccl;
@@ -89,6 +92,8 @@ bool load_rccl(std::string* why) {
   a.AllReduce = (decltype(a.AllReduce))dlsym(h, "ncclAllReduce");
   a.AllGather = (decltype(a.AllGather))dlsym(h, "ncclAllGather");
   a.GetErrorString = (decltype(a.GetErrorString))dlsym(h, "ncclGetErrorString");
+  a.CommAbort = (decltype(a.CommAbort))dlsym(h, "ncclCommAbort");
+  a.CommGetAsyncError = (decltype(a.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
   if (!a.GetUniqueId || !a.CommInitRank || !a.CommDestroy || !a.AllReduce || !a.AllGather) {
     *why = "librccl is missing a required symbol";
     return false;
@@ -208,6 +213,12 @@ struct sc_ctx {
   // lag of a freshly started job (seconds: code objects, first launches) is absorbed by the connect-time handshake
   // (peer_connect_ms), so this can be a real failure detector
   int peer_spin_ms = 2000;
+  // RCCL plane: how long the host waits for work queued behind a collective (a pass's sums, a gathered table) before it gives
+  // the communicator up - ncclCommAbort, the context poisoned, SC_ERR_RCCL.  A collective whose peer is gone never finishes
+  // on its own: its kernel spins on the device.  Generous by default (a healthy collective takes microseconds; a peer may be
+  // seconds late into its first launch)
+  int rccl_timeout_ms = 30000;
+  mutable bool comm_failed = false;   // the communicator was given up: every later failure of this context reports SC_ERR_RCCL
   int peer_connect_ms = 120000;   // how long sc_ctx_comm_peer_connect waits for every peer's hello
   // fault injection (tests): delay every sharded launch of this rank by dbg_delay_ms on the host; dbg_skip_tag = 1
   // makes the next sharded launch skip a tag (a rank that is out of step with its peers)
@@ -267,6 +278,7 @@ int fail(const sc_ctx* ctx, int code, const char* fmt, ...) {
   va_end(ap);
   if (ctx) ctx->err = buf;
   else g_create_error = buf;
+  if (ctx && ctx->comm_failed && code == SC_ERR_HIP) code = SC_ERR_RCCL;   // (whatever broke behind a communicator that was given up)
   return code;
 }
 

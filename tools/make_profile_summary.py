@@ -8,6 +8,7 @@ kernel names bench.py prints)."""
 import csv
 import glob
 import json
+import provenance
 import os
 import re
 import sys
@@ -207,6 +208,10 @@ tj[key] = {
     "hbm_bytes_per_step": tot_p, "fetch_bytes_corrected": sum(fetch) * 2 * 1024, "write_bytes": sum(write) * 1024,
     "kernels": {name: {"hbm_bytes_per_launch": sum(v) / len(v), "launches_per_step": len(v)} for name, v in per_kernel.items()},
     "source": "%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md" % tag,
+    # what the bytes were measured on (tools/provenance.py): bench.py hands them out only while the kernel sources are these
+    "provenance": provenance.record(tag, os.environ.get("SC_PMC_COMMAND") or
+                                    "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --steps 2 --warmup 1 --cpu-num-vars 0"
+                                    + ("" if workload != "prover" or n == 28 else " --num-vars %d" % n) + ("" if FIELD == "GoldilocksMont" else " --field generic")),
 }
 json.dump(tj, open(tj_path, "w"), indent=1)
 print(open(os.path.join(P, "%s_%s_summary.md" % (tag, workload))).read())

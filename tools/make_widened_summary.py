@@ -6,6 +6,7 @@ usage: make_widened_summary.py <tag> <workload> <stats_dir> <fetch_dir> <write_d
 import csv
 import glob
 import json
+import provenance
 import os
 import re
 import sys
@@ -85,6 +86,8 @@ key = {"gkr": "gkr_k%d", "gnew": "gnew_n%d", "triangle": "triangle_k%d"}[workloa
 frag = {"gkr": "gkr_phase1_kernel", "gnew": "coldot_kernel", "triangle": "wgrid_pass_kernel"}[workload]
 cand = [v for k, v in pmc.items() if frag in k]
 tj[key] = {"kernels": {rf["kernel"]: {"hbm_bytes_per_launch": max(cand) if cand else None}},
-           "source": "%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md" % tag}
+           "source": "%s: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), FETCH_SIZE doubled per MI355X_MICROARCH.md" % tag,
+           "provenance": provenance.record(tag, os.environ.get("SC_PMC_COMMAND") or
+                                           "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --workload %s ..." % workload)}
 json.dump(tj, open(tj_path, "w"), indent=1)
 print(open(os.path.join(P, "%s_%s_summary.md" % (tag, workload))).read())
