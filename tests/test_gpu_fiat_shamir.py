@@ -122,7 +122,7 @@ def test_explicit_zero_term_reaches_the_wire():
     ctx = pkg.Context(pkg.Field(5))
     F = ctx.field
     found = 0
-    for a0, a1, b0, b1 in [(0, 1, 1, 0), (1, 3, 0, 1), (4, 2, 0, 1), (0, 1, 3, 4)]:      # H = (0,0,3), (0,3,0), (0,2,0), generic
+    for a0, a1, b0, b1 in [(0, 1, 1, 0), (1, 3, 0, 1), (4, 2, 0, 1), (1, 2, 3, 4)]:      # H = (0,0,3), (0,3,0), (0,2,0), and one with H(0) != 0
         a, b = [a0, a1], [b0, b1]
         e = pyref.g_round_evals(a, b, 5)
         terms = FS.lagrange_quadratic([(0, e[0]), (1, e[1]), (2, e[2])], 5)
