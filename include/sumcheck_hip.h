@@ -349,11 +349,14 @@ int sc_prover_num_vars(const sc_prover* pr, size_t* out);
 #define SC_PLAN_WFOLD_PASS 6 /* wfold_pass_kernel: folds kf = 4 challenges (behind the matrix-core pass) and serves five rounds, or kf = 5 and ks = 3..5
                               * on tables of >= 2^wfold5_min_log entries: the streaming fold with a grid pass's cells */
 /* ABI version of this header: bumped whenever a struct below grows or an enum is extended.  sc_abi_version()
- * returns the library's; a caller built against another major version must not pass structs.  Version 5 = round 5. */
-#define SC_ABI_VERSION 5
+ * returns the library's; a caller built against another major version must not pass structs.  Version 5 = round 5; version 6 =
+ * round 6: the option block is initialised by sc_plan_options_init (a NEW symbol: the one-argument sc_plan_options_default of
+ * version 4 and the two-argument one of version 5 are gone, so a caller built against either fails at link / load time instead
+ * of handing the library a struct of another size - ADVICE r05). */
+#define SC_ABI_VERSION 6
 int sc_abi_version(void);
 typedef struct sc_plan_options {   /* the context options the schedule depends on (sc_ctx_set_option names) */
-  uint32_t struct_size;            /* sizeof(sc_plan_options) as the CALLER compiled it: set by sc_plan_options_default from its argument;
+  uint32_t struct_size;            /* sizeof(sc_plan_options) as the CALLER compiled it: set by sc_plan_options_init from its argument;
                                     * the library reads and writes no field beyond it (fields a caller's struct lacks take their defaults) */
   int32_t vars_per_pass, first_pass_vars, grid_pass, grid_log, grid_max_vars, grid_sharded, tail_log, use_mailbox, gram_log;
   int32_t host_tail_log;           /* since version 5 */
@@ -366,7 +369,7 @@ typedef struct sc_plan_step {
   int32_t action, kf, ks, log_in, sharded;
 } sc_plan_step;
 /* struct_size = sizeof(sc_plan_options) at the call site */
-void sc_plan_options_default(sc_plan_options* o, size_t struct_size);
+void sc_plan_options_init(sc_plan_options* o, size_t struct_size);
 int sc_plan_proof(const sc_plan_options* opt, size_t num_vars, int world, int transport, sc_plan_step* out, size_t cap,
                   size_t* n_out);
 

@@ -43,9 +43,9 @@ pub struct sc_table {
     _private: [u8; 0],
 }
 /// `SC_ABI_VERSION` of the header these declarations were written against; `sc_abi_version()` is the library's.
-pub const SC_ABI_VERSION: c_int = 5;
+pub const SC_ABI_VERSION: c_int = 6;
 /// The context options the schedule depends on (`sc_plan_proof`).  `struct_size` is set by
-/// `sc_plan_options_default(&mut o, size_of::<sc_plan_options>())`; the library touches nothing beyond it.
+/// `sc_plan_options_init(&mut o, size_of::<sc_plan_options>())`; the library touches nothing beyond it.
 #[repr(C)]
 #[derive(Clone, Copy, Debug, Default)]
 pub struct sc_plan_options {
@@ -205,7 +205,7 @@ extern "C" {
     ) -> c_int;
 
     pub fn sc_abi_version() -> c_int;
-    pub fn sc_plan_options_default(o: *mut sc_plan_options, struct_size: usize);
+    pub fn sc_plan_options_init(o: *mut sc_plan_options, struct_size: usize);
     pub fn sc_plan_proof(
         opt: *const sc_plan_options,
         num_vars: usize,

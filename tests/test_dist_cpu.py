@@ -6,6 +6,7 @@ the planner prover_pass calls at every pass) says which launches and gathers a s
 consists of, the model executes them over gloo collectives, and the result is compared against
 the full-table oracle transcript (the engine itself: tests/test_gpu_sharded.py,
 tests/test_gpu_schedule.py)."""
+import ctypes
 import os
 import sys
 
@@ -232,6 +233,12 @@ def model_local_prove(o, plan_proof, p, n, world, opts, pyref):
         shards.append([o.generate_range(pyref.SEED_A, start, length), o.generate_range(pyref.SEED_B, start, length)])
     ch = [o.challenge(pyref.SEED_R, j + 1) for j in range(n)]
     steps = list(plan_proof(n, world, "local", **opts))
+    # the library's own default hand-over size (sc_plan_options_init), not a literal that ages
+    from conftest import load_package as _lp
+    _L = _lp()._lib
+    _d = _L.ScPlanOptions()
+    _lp().load().sc_plan_options_init(ctypes.byref(_d), ctypes.sizeof(_d))
+    tail_default = int(_d.host_tail_log)
     pending, cache, evals = [], None, []
     host = False
     for j in range(n):
@@ -244,11 +251,14 @@ def model_local_prove(o, plan_proof, p, n, world, opts, pyref):
             assert kf == len(pending) and step["log_in"] == int(shards[0][0].size).bit_length() - 1, (step, len(pending))
             if step["action"] == "host_tail":
                 # every shard is down to <= 2^host_tail_log entries (<= 32 with the option off): the host takes over for good
-                limit = max(opts.get("host_tail_log", 10), 5) if world > 1 else opts.get("host_tail_log", 10)
+                limit = max(opts.get("host_tail_log", tail_default), 5) if world > 1 else opts.get("host_tail_log", tail_default)
                 assert ks == n - j and not steps and (step["log_in"] <= limit or step["log_in"] == kf), (step, j)
                 host = True
             else:
-                assert step["action"] in ("pass", "grid_pass") and step["sharded"] == (world > 1)
+                # (gram_pass: four rounds from the first read; wfold_pass: the streaming fold with a grid pass's cells - to this
+                # model they are passes that fold kf challenges and serve ks rounds like any other)
+                assert step["action"] in ("pass", "grid_pass", "gram_pass", "wfold_pass") and step["sharded"] == (world > 1)
+                assert step["action"] != "gram_pass" or (kf == 0 and ks == 4)
                 S = None
                 for sh in shards:
                     if kf:
@@ -299,8 +309,15 @@ def test_local_plan_is_sufficient(world):
     g = world.bit_length() - 1
     for (p, n, opts) in [(GOLD, max(g, 1), {}), (GOLD, g + 1, {}), (GOLD, g + 4, {}), (GOLD, 10, {}), (GOLD, 14, {}), (389, 13, {}),
                          (GOLD, 12, {"grid_max_vars": 3}), (GOLD, 11, {"vars_per_pass": 1}), (GOLD, 12, {"grid_pass": 0}),
-                         (5, 9, {"grid_sharded": 0}), (GOLD, 13, {"first_pass_vars": 2, "grid_log": 6})]:
+                         (5, 9, {"grid_sharded": 0}), (GOLD, 13, {"first_pass_vars": 2, "grid_log": 6}),
+                         # the matrix-core first pass and the streaming fold behind it, asked for on small shards ...
+                         (GOLD, 15 + g, {"first_pass_vars": 4, "wfold_min_log": 12, "wfold_always": 1, "wfold5_min_log": 12}),
+                         # ... and where the DEFAULT plan takes them: 2^21-entry tables / shards, hand-over at 2^11 or 2^12 entries
+                         (GOLD, 21 + g, {})]:
         o = Oracle(p)
         evals, ch = model_local_prove(o, pkg.schedule.plan_proof, p, n, world, opts, pyref)
+        if n >= 21:
+            plan = [s["action"] for s in pkg.schedule.plan_proof(n, world, "local", **opts)]
+            assert plan[0] == "gram_pass" and "wfold_pass" in plan and plan[-1] == "host_tail", plan
         full = o.prove(o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n), np.array(ch, dtype=np.uint64))
         assert full["status"] == 0 and evals == [[int(x) for x in row] for row in full["evals"]], (world, p, n, opts)

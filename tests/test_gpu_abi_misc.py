@@ -129,3 +129,36 @@ def test_randomized_differential_run():
                          timeout=600, cwd=root)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "0 mismatches" in out.stdout
+
+
+def test_more_provers_than_tail_slots_on_one_context():
+    """a context has 32 pinned tail slots; the 33rd prover alive at the same time has none, so the plan it runs is NOT the one
+    sc_plan_proof prints for the default options (no host tail: the device serves it to the last round) - same transcript, and the
+    slot comes back when a holder is destroyed"""
+    from util import challenges, oracle
+    pkg = load_package()
+    o = oracle(GOLD)
+    ctx = pkg.Context(pkg.Field(GOLD))
+    n = 13
+    ch = challenges(o, n)
+    ref = o.prove(o.generate(pyref.SEED_A, n), o.generate(pyref.SEED_B, n), ch)
+    a = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_A, n)
+    b = pkg.DenseMultilinearExtension.generate(ctx, pyref.SEED_B, n)
+    G = pkg.matrix_multiplication.G(a, b)
+    provers = [G.native_prover() for _ in range(40)]
+    ctx.set_option("time_kernels", 1)
+    logs = {}
+    for k in (0, 31, 32, 39):
+        ctx.launch_log(reset=True)
+        assert provers[k].c1() == ref["c_1"]
+        for j in range(n):
+            assert provers[k].round_evals(int(ch[j - 1]) if j else 1, j) == [int(x) for x in ref["evals"][j]], (k, j)
+        logs[k] = [(r["kind"], r["kf"], r["ks"]) for r in ctx.launch_log(reset=True)]
+    # provers 0 and 31 hold a slot: round 0's pass ran at creation and handed over (nothing more is launched); 32 and 39 have none:
+    # the device serves their later rounds
+    assert logs[0] == [] and logs[31] == [] and len(logs[32]) >= 1 and len(logs[39]) >= 1, logs
+    ctx.set_option("time_kernels", 0)
+    del provers
+    c1, evals, _ = pkg.matrix_multiplication.prove(ctx, G, pyref.SEED_R)      # slots are back: the default plan again
+    assert c1 == ref["c_1"] and np.array_equal(evals, ref["evals"])
+    ctx.close()

@@ -265,9 +265,10 @@ def test_plan_options_struct_is_versioned():
     import ctypes
     pkg = load_package()
     lib, L = pkg._lib.load(), pkg._lib
-    assert lib.sc_abi_version() == L.ABI_VERSION == 5
+    assert lib.sc_abi_version() == L.ABI_VERSION == 6
+    assert not hasattr(lib, "sc_plan_options_default")      # the old symbol is gone: a stale caller fails at load time
     full = L.ScPlanOptions()
-    lib.sc_plan_options_default(ctypes.byref(full), ctypes.sizeof(full))
+    lib.sc_plan_options_init(ctypes.byref(full), ctypes.sizeof(full))
     assert full.struct_size == ctypes.sizeof(full) == 60 and full.host_tail_log == 12 and full.gram_log == 21
     assert (full.wfold_log, full.wfold_min_log, full.wfold_always, full.wfold5_min_log) == (40, 21, 0, 24)
 
@@ -277,7 +278,7 @@ def test_plan_options_struct_is_versioned():
             [("guard", ctypes.c_int32)]
     old = Old()
     old.guard = 0x5A5A5A5A
-    lib.sc_plan_options_default(ctypes.cast(ctypes.byref(old), ctypes.POINTER(L.ScPlanOptions)), 40)
+    lib.sc_plan_options_init(ctypes.cast(ctypes.byref(old), ctypes.POINTER(L.ScPlanOptions)), 40)
     assert old.struct_size == 40 and old.guard == 0x5A5A5A5A and old.gram_log == 21
     old.guard = 0          # (would read as host_tail_log = 0 if the library looked past struct_size)
     steps = (L.ScPlanStep * 64)()

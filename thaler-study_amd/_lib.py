@@ -27,7 +27,7 @@ class ScField(ctypes.Structure):
     _fields_ = [("p", u64), ("p_inv_neg", u64), ("r_mod_p", u64), ("r2_mod_p", u64)]
 
 
-ABI_VERSION = 5   # SC_ABI_VERSION of include/sumcheck_hip.h as this binding was written
+ABI_VERSION = 6   # SC_ABI_VERSION of include/sumcheck_hip.h as this binding was written
 
 
 class ScPlanOptions(ctypes.Structure):
@@ -97,7 +97,7 @@ SIGNATURES = {
     "sc_prod2_fold_and_sums": (ctypes.c_int, [voidp, voidp, voidp, u64p, ctypes.POINTER(voidp), ctypes.POINTER(voidp), u64p]),
     "sc_prod2_evaluate": (ctypes.c_int, [voidp, voidp, voidp, u64p, size_t, u64p]),
     "sc_abi_version": (ctypes.c_int, []),
-    "sc_plan_options_default": (None, [ctypes.POINTER(ScPlanOptions), size_t]),
+    "sc_plan_options_init": (None, [ctypes.POINTER(ScPlanOptions), size_t]),
     "sc_plan_proof": (ctypes.c_int, [ctypes.POINTER(ScPlanOptions), size_t, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ScPlanStep), size_t,
                                      ctypes.POINTER(size_t)]),
     "sc_prover_create": (ctypes.c_int, [voidp, voidp, voidp, ctypes.POINTER(voidp)]),
@@ -171,10 +171,16 @@ def load():
     except Exception:
         pass
     lib = ctypes.CDLL(LIB_PATH)
+    if not hasattr(lib, "sc_abi_version"):      # (a library older than the version check itself)
+        raise ImportError("%s exports no sc_abi_version: it predates this binding (ABI %d); rebuild (`make -C thaler-study_amd/csrc`)"
+                          % (LIB_PATH, ABI_VERSION))
     lib.sc_abi_version.restype = ctypes.c_int
     if lib.sc_abi_version() != ABI_VERSION:
         raise ImportError("%s speaks ABI version %d, this binding %d: rebuild (`make -C thaler-study_amd/csrc`)"
                           % (LIB_PATH, lib.sc_abi_version(), ABI_VERSION))
+    missing = [name for name in SIGNATURES if not hasattr(lib, name)]
+    if missing:
+        raise ImportError("%s lacks %s: rebuild (`make -C thaler-study_amd/csrc`)" % (LIB_PATH, ", ".join(missing)))
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res

@@ -12,7 +12,7 @@ def plan_proof(num_vars, world=1, transport="none", **options):
     use_mailbox, gram_log, host_tail_log); unknown names raise"""
     lib = _lib.load()
     opt = _lib.ScPlanOptions()
-    lib.sc_plan_options_default(ctypes.byref(opt), ctypes.sizeof(opt))
+    lib.sc_plan_options_init(ctypes.byref(opt), ctypes.sizeof(opt))
     for k, v in options.items():
         if k == "struct_size" or k not in dict(opt._fields_):
             raise KeyError("not a schedule option: %s" % k)
