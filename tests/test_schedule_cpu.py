@@ -287,3 +287,90 @@ def test_plan_options_struct_is_versioned():
     assert L.PLAN_ACTIONS[steps[n.value - 1].action] == "host_tail"          # the default, not the guard word
     blank = L.ScPlanOptions()
     assert lib.sc_plan_proof(ctypes.byref(blank), 28, 1, 0, steps, 64, ctypes.byref(n)) == 1      # SC_ERR_ARG: never initialised
+
+
+# ---- the rule chain against a table: a dynamic programme over the kernels that exist ----------------------
+# plan_pass decides by a chain of predicates (engine/abi_prover.inc) that has grown an exception per round.  What the chain is FOR
+# is simple to state: serve all n rounds with the launches that exist, with as few launches as possible up to the hand-over to the
+# host (a launch costs ~13 us of fixed time + ~7 us between two launches, profiles/r05_wfold_ab.txt, profiles/r06_finish_cost.txt -
+# more than anything a choice of kernel changes on the tables where there is a choice).  The table below lists, per kernel, the
+# states (kf pending challenges, ks rounds served, 2^L entries read) it accepts at DEFAULT options; a DP over (round, kf, L) finds
+# the fewest launches any chain of them needs.  The planner must never need more - for every n up to 40, whole provers and the
+# shards of 2 / 4 / 8-device handles - and, where several chains tie, must hand over at <= 2^11 entries unless 2^12 saves a launch.
+
+GRAM_LOG, GRID_LOG, WFOLD_MIN, WFOLD5_MIN, TAIL_HARD, TAIL_SMALL = 21, 20, 21, 24, 12, 5
+
+
+def _launches(j, kf, L, local):
+    """every (kind, ks) one launch can be at this state, default options"""
+    out = []
+    if j == 0 and kf == 0 and L >= GRAM_LOG:
+        out.append(("gram_pass", 4))
+    if j == 4 and kf == 4 and L >= max(12, WFOLD_MIN):
+        out.append(("wfold_pass", 5))
+    if kf == 5 and L >= 12 and (L >= WFOLD5_MIN or L - 5 > GRID_LOG):
+        out += [("wfold_pass", ks) for ks in (3, 4, 5)]
+    if 1 <= L - kf <= GRID_LOG and kf <= 5:
+        out += [("grid_pass", ks) for ks in range(1, 6)]
+    if kf == 0 and j == 0:
+        out += [("pass", ks) for ks in (1, 2, 3)]
+    elif kf <= 3:
+        out += [("pass", ks) for ks in (1, 2)]
+    elif kf == 4 and L >= 12:
+        out.append(("pass", 2))
+    return [(k, ks) for k, ks in out if ks <= L - kf]        # (the folded table keeps the variables the rounds are about)
+
+
+def _min_launches(n, g):
+    """fewest launches from the start to the hand-over (or the last round), and the smallest hand-over size that count allows"""
+    import functools
+    local = g > 0
+
+    @functools.lru_cache(maxsize=None)
+    def best(j, kf, L):
+        # -> (launches, hand-over log or 0)
+        if j >= n - g and L == kf:
+            return (0, 0)                                    # a handle's shards hold only their pending challenges: the host takes them
+        if j >= n:
+            return (0, 0)
+        res = (10**6, 0)
+        for kind, ks in _launches(j, kf, L, local):
+            out_log, j2 = L - kf, j + ks
+            if j2 > n - g and not (j2 == n - g):
+                continue
+            if j2 > n:
+                continue
+            cand = None
+            hands = kf > 0 and j2 < n and ((kind == "grid_pass" and out_log <= TAIL_HARD) or out_log <= TAIL_SMALL)
+            if hands:
+                cand = (1, out_log)
+            else:
+                sub = best(j2, ks, out_log)
+                cand = (1 + sub[0], sub[1])
+            if cand[0] < res[0] or (cand[0] == res[0] and max(cand[1], 11) < max(res[1], 11)):
+                res = cand
+        return res
+
+    return best(0, 0, n - g)
+
+
+@pytest.mark.parametrize("world", [1, 2, 8])
+def test_default_plans_are_launch_minimal(plan, world):
+    g = world.bit_length() - 1
+    transport = "none" if world == 1 else "local"
+    worse = []
+    for n in range(max(g, 1), 41):
+        steps = [s for s in plan(n, world, transport) if s["action"] != "host_tail"]
+        tail = [s for s in plan(n, world, transport) if s["action"] == "host_tail"]
+        want, hand_log = _min_launches(n, g)
+        if len(steps) > want:
+            worse.append((n, len(steps), want))
+        # every launch of the plan is a row of the table
+        j, kf, L = 0, 0, n - g
+        for s in steps:
+            assert (s["action"], s["ks"]) in _launches(j, kf, L, g > 0), (n, s)
+            j, kf, L = j + s["ks"], s["ks"], L - s["kf"]
+        # the hand-over: at <= 2^11 entries unless the table allows a shorter chain only with 2^12
+        if tail and tail[0]["log_in"] > 11 and steps:
+            assert len(steps) == want and hand_log == 12, (n, tail, want, hand_log)
+    assert not worse, "plans with more launches than the kernels need (n, planned, minimal): %r" % worse
