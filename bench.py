@@ -571,7 +571,7 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
     ms_per_step = elapsed / args.steps * 1e3
     median_ms = statistics.median(step_ms) if step_ms else None
     unsampled = [m for i, m in enumerate(step_ms) if i % timed_every]
-    # the first folding pass of a 2^28-entry proof has two speeds, box to box and context to context (DESIGN.md section 11,
+    # the first folding pass of a 2^28-entry proof has two speeds, box to box and context to context (DESIGN_HISTORY.md section 11,
     # experiments/r03_fold_pass_two_modes.md, experiments/r04_vmm_placement.md): say which one this run drew
     fold_pass_mode = None
     fp_rec = next((k for k in kernels if ((k["_key"][0] == "pass" and k["_key"][1] in (3, 4) and k["_key"][2] == 2) or

@@ -154,9 +154,12 @@ def test_more_provers_than_tail_slots_on_one_context():
         for j in range(n):
             assert provers[k].round_evals(int(ch[j - 1]) if j else 1, j) == [int(x) for x in ref["evals"][j]], (k, j)
         logs[k] = [(r["kind"], r["kf"], r["ks"]) for r in ctx.launch_log(reset=True)]
-    # provers 0 and 31 hold a slot: round 0's pass ran at creation and handed over (nothing more is launched); 32 and 39 have none:
-    # the device serves their later rounds
-    assert logs[0] == [] and logs[31] == [] and len(logs[32]) >= 1 and len(logs[39]) >= 1, logs
+    # provers 0 and 31 hold a slot: their second launch hands over and the host serves the rest; 32 and 39 have none: the device
+    # goes on (one more launch here), which is the plan of host_tail_log = 0, not the default one
+    assert logs[0] == logs[31] and logs[32] == logs[39] and len(logs[32]) > len(logs[0]), logs
+    with_tail = [(s["action"], s["kf"], s["ks"]) for s in pkg.schedule.plan_proof(n) if s["action"] != "host_tail"]
+    without = [(s["action"], s["kf"], s["ks"]) for s in pkg.schedule.plan_proof(n, host_tail_log=0) if s["action"] != "host_tail"]
+    assert logs[0] == with_tail[1:] and logs[32] == without[1:], (logs, with_tail, without)      # ([0]: round 0's pass ran at creation)
     ctx.set_option("time_kernels", 0)
     del provers
     c1, evals, _ = pkg.matrix_multiplication.prove(ctx, G, pyref.SEED_R)      # slots are back: the default plan again

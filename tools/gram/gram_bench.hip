@@ -1,4 +1,4 @@
-// Prototype of a FIVE-round first pass on the int8 matrix cores (not part of the product).
+// Prototype of a FIVE-round first pass on the int8 matrix cores (not part of the product; see DESIGN_HISTORY.md section 11).
 //
 // The round polynomials of rounds 1..5 of the product sumcheck are functions of the 32 x 32 Gram matrix
 //   M[x][x'] = sum_rows a[32 row + x] * b[32 row + x'],   x, x' in {0,1}^5 (the five lowest index bits),
