@@ -12,7 +12,7 @@
 #include <cstring>
 #include <vector>
 
-#include "../include/sumcheck_hip.h"
+#include "../../include/sumcheck_hip.h"
 
 #define CK(x)                                                                              \
   do {                                                                                     \

@@ -6,7 +6,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../thaler-study_amd/csrc/kernels.hpp"
+#include "../../thaler-study_amd/csrc/kernels.hpp"
 using namespace sc;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 

@@ -1,12 +1,12 @@
 #!/bin/bash
-# on the GPU box: TLB counters of the fold pass in fast and slow contexts of one process (tools/probe_modes_pmc.py)
+# on the GPU box: TLB counters of the fold pass in fast and slow contexts of one process (tools/archive/probe_modes_pmc.py)
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 SETS=("TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_GMI_32B_sum" "TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_STALL_sum" "TCC_EA0_RDREQ_DRAM_CREDIT_STALL_sum TCC_EA0_WRREQ_DRAM_CREDIT_STALL_sum" "TCC_READ_REQ_LATENCY_sum TCC_WRITE_REQ_LATENCY_sum" "TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_sum" "TCC_TOO_MANY_EA_WRREQS_STALL_sum TCC_EA0_RDREQ_LEVEL_sum" "TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum")
 for set in "${SETS[@]}"; do
   tag=$(echo $set | tr ' ' '+')
   rm -rf $O/prof_modes
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/prof_modes -- python3 $R/tools/probe_modes_pmc.py 8 > $O/modes_$tag.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/prof_modes -- python3 $R/tools/archive/probe_modes_pmc.py 8 > $O/modes_$tag.log 2>&1
   echo "== $set"; grep "context" $O/modes_$tag.log
   python3 - "$O/prof_modes" <<'PY'
 import csv, glob, sys, collections

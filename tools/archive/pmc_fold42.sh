@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out
 for form in "fold_dma=1 fold_oneset=0" "fold_dma=0 fold_oneset=0" "fold_dma=0 fold_oneset=1"; do
   for set in "SQ_WAIT_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES" "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM SQ_INSTS_LDS"; do
     rm -rf $O/pmcf
-    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmcf -- python3 $R/tools/probe.py 28 2 $form > $O/pmcf.log 2>&1
+    rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmcf -- python3 $R/tools/archive/probe.py 28 2 $form > $O/pmcf.log 2>&1
     f=$(find $O/pmcf -name '*counter_collection.csv' | head -1)
     python3 - "$f" "$form" >> $O/r05_fold42_sq.txt <<'PY'
 import csv, sys, collections

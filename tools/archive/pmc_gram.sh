@@ -1,5 +1,5 @@
 #!/bin/bash
-# Run ON THE GPU BOX (gpurun -- 'bash tools/pmc_gram.sh'): SQ counters of the matrix-core first pass and the fold behind it, one n = 28 proof
+# Run ON THE GPU BOX (gpurun -- 'bash tools/archive/pmc_gram.sh'): SQ counters of the matrix-core first pass and the fold behind it, one n = 28 proof
 # per counter set (rocprofv3 --pmc in its own runs, --kernel-trace only).  -> gpurun_out/r04_gram_sq_counters.txt
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out

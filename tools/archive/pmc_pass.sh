@@ -7,7 +7,7 @@ i=0
 for set in "SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES SQ_WAVE_CYCLES" "GRBM_GUI_ACTIVE SQ_WAVES SQ_INSTS_SALU SQ_INSTS_VMEM"; do
   i=$((i+1))
   rm -rf $O/pmc$i
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc$i -- python3 $R/tools/probe.py 28 2 > $O/pmc$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $O/pmc$i -- python3 $R/tools/archive/probe.py 28 2 > $O/pmc$i.log 2>&1
   f=$(find $O/pmc$i -name '*counter_collection.csv' | head -1)
   python3 - "$f" <<'PY' > $O/pmc$i.txt 2>&1
 import csv, sys, collections

@@ -1,7 +1,7 @@
 """quick timing probe (not the bench): whole-prover wall time and pass-kernel device time
 usage: probe.py n1,n2 [vpp list] [opt=val ...]"""
 import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 class pyref:  # seeds of the synthetic instance; tools never load oracle/

@@ -3,7 +3,7 @@ staging with two sets (fold_dma=0), ONE staging set at three waves per SIMD (fol
 alternating (the pass has two speeds per context: experiments/r03_fold_pass_two_modes.md; only a same-context comparison isolates
 the kernel).  HIP-event durations from the launch log.  usage: probe_fold42.py [n ...]"""
 import sys, os, statistics
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 SEED_A, SEED_B, SEED_R = 0xA5A5000000000001, 0xB6B6000000000002, 0xC7C7000000000003

@@ -3,8 +3,8 @@ transcripts compared at n = 16, 20 (first_pass_vars = 4, grid_log = 8: the fold 
 per-launch durations at n = 28."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
 from __graft_entry__ import load_package
 from util import pyref
 pkg = load_package()

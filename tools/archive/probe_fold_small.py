@@ -4,7 +4,7 @@ import statistics
 import sys
 
 import os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from __graft_entry__ import load_package
 
 pkg = load_package()

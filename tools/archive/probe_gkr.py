@@ -1,6 +1,6 @@
 """timing probe for the GKR W layer sumcheck and the triangle prover"""
 import sys, time, os, random
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 import numpy as np

@@ -1,6 +1,6 @@
 """per-launch device times (sc_ctx_launch_log) of one GKR W layer proof (k) and one triangle proof (k)"""
 import sys, os, random, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import __graft_entry__ as ge
 import numpy as np
 pkg = ge.load_package()

@@ -1,6 +1,6 @@
 """timing probe for the single-table paths (BASELINE config 2 and G::new)"""
 import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 class pyref:  # seeds of the synthetic instance; tools never load oracle/

@@ -5,7 +5,7 @@ import sys
 import time
 
 import os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 from __graft_entry__ import load_package
 
 pkg = load_package()

@@ -1,7 +1,7 @@
 """Whole-proof wall time (median of 60) at the shard sizes, default schedule against variants, one process, alternating
 contexts (so that a box's mood hits both alike).  usage: probe_tail.py [n ...]"""
 import sys, time, os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import __graft_entry__ as ge
 pkg = ge.load_package()
 SEED_A, SEED_B, SEED_R = 0xA5A5000000000001, 0xB6B6000000000002, 0xC7C7000000000003

@@ -5,7 +5,7 @@
 //   copy    read 2 GiB, write 2 GiB
 //   r8w1    read 4 GiB, write 0.5 GiB (the read/write mix of the three-variable fold pass)
 #include <hip/hip_runtime.h>
-#include "../thaler-study_amd/csrc/field.hpp"
+#include "../../thaler-study_amd/csrc/field.hpp"
 #include <cstdio>
 #include <cstdlib>
 #include <algorithm>

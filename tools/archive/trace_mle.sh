@@ -2,7 +2,7 @@
 # kernel durations of the single-table paths at n = 28 (rocprofv3 kernel trace of probe_mle.py)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/tr_m -- python3 $R/tools/probe_mle.py 28 > $R/gpurun_out/tr_m.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/tr_m -- python3 $R/tools/archive/probe_mle.py 28 > $R/gpurun_out/tr_m.log 2>&1
 f=$(find $R/gpurun_out/tr_m -name '*kernel_stats.csv' | head -1)
 python3 - "$f" <<'PY'
 import csv, sys

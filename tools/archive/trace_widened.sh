@@ -4,7 +4,7 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 rm -rf /tmp/tr_w
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_w -- python3 $R/tools/probe_log.py ${1:-13} ${2:-10} > /tmp/tr_w.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr_w -- python3 $R/tools/archive/probe_log.py ${1:-13} ${2:-10} > /tmp/tr_w.log 2>&1
 csv=$(find /tmp/tr_w -name '*kernel_trace.csv' | head -1)
-python3 $R/tools/trace_timeline.py $csv ${3:-120} > $R/gpurun_out/trace_widened.txt
+python3 $R/tools/archive/trace_timeline.py $csv ${3:-120} > $R/gpurun_out/trace_widened.txt
 tail -45 $R/gpurun_out/trace_widened.txt

@@ -20,7 +20,7 @@
 #include <string>
 #include <vector>
 
-#include "../include/sumcheck_hip.h"
+#include "../../include/sumcheck_hip.h"
 
 #define CK(x)                                                                              \
   do {                                                                                     \
