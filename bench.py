@@ -179,9 +179,22 @@ def reference_probe():
     crates = glob.glob(os.path.join(home, "registry", "src", "*", "ark-poly-*")) + glob.glob(os.path.join(ROOT, "rust", "vendor", "ark-poly*"))
     src = os.environ.get("SC_REFERENCE_DIR")
     have_src = bool(src) and os.path.isfile(os.path.join(src, "matrix-multiplication", "Cargo.toml"))
-    return {"cargo": cargo or "absent", "rustc": shutil.which("rustc") or "absent", "offline_ark_crates": bool(crates),
-            "reference_sources": src if have_src else "absent (SC_REFERENCE_DIR unset; never on the GPU box)",
-            "usable": bool(cargo) and bool(crates) and have_src}
+    out = {"cargo": cargo or "absent", "rustc": shutil.which("rustc") or "absent", "offline_ark_crates": bool(crates),
+           "reference_sources": src if have_src else "absent (SC_REFERENCE_DIR unset; never on the GPU box)",
+           "usable": bool(cargo) and bool(crates) and have_src}
+    if out["usable"] and os.environ.get("SC_BENCH_REFERENCE", "1") == "1":
+        # all three exist (never on this pool): the reference's OWN criterion bench (matrix-multiplication/benches/mm_benchmark.rs:
+        # Prover::new + rounds over G for num_vars 2..15), run from its sources where they lie, bounded; its report is recorded as it
+        # comes.  It is the reference at ITS sizes - G's tables are private, no public constructor takes two 2^28-entry tables - so the
+        # n = 28 row of cpu_baseline stays the port either way.
+        import subprocess
+        try:
+            r = subprocess.run([cargo, "bench", "--offline", "--manifest-path", os.path.join(src, "Cargo.toml"), "-p", "matrix-multiplication"],
+                               capture_output=True, text=True, timeout=float(os.environ.get("SC_BENCH_REFERENCE_TIMEOUT", "600")))
+            out["criterion"] = {"returncode": r.returncode, "report_tail": [l for l in r.stdout.splitlines() if "time:" in l or "thrpt:" in l][-28:]}
+        except Exception as e:      # a bench that does not build or does not end is a finding, not a failure of this run
+            out["criterion"] = {"error": str(e)[:300]}
+    return out
 
 
 def attach_plane(plane, pkg, ctx, rank, world, dist):
