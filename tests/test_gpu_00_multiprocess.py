@@ -215,6 +215,18 @@ def test_rccl_plane_a_rank_that_dies(nproc):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("transport,nproc", [("peer", 2), ("peer", 8), ("rccl", 4)])
+def test_headline_worker_on_one_device(transport, nproc):
+    """the worker mode tests/test_gpu_multi_device.py runs at n = 20 and n = 28 on a real node (rank 0's oracle transcript handed to
+    every rank, every rank's c_1 and round triples compared, launches == plan, cold and warm proof) - here at n = 16 and n = 22 with
+    every rank on GPU 0, so that the first run on distinct devices is not the first run of this code"""
+    out = _workers(nproc, "headline", 30650 + (os.getpid() % 40) + nproc, timeout=600, transport=transport,
+                   extra_env={"SC_WORKER_NUM_VARS": "16,22"})
+    assert out.returncode == 0, (_quiet(out.stdout, 1500), _quiet(out.stderr))
+    assert out.stdout.count("HEADLINE-OK") == nproc, out.stdout[-3000:]
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nproc", [2, 4])
 def test_rccl_plane_a_collective_that_never_completes(nproc):
     """what a dead rank looks like under the REAL library: ncclAllReduce returns ncclSuccess and what it queued never completes

@@ -43,7 +43,13 @@ def _ndev():
         return 0
 
 
-NDEV = _ndev()
+# REHEARSAL (SC_MULTI_DEVICE_REHEARSAL=1, what this pool can do): the same test bodies with every "device" = GPU 0 and the librccl
+# stand-in of tests/rccl_double - it proves nothing about distinct devices, RCCL or xGMI (the one-device suite already covers that
+# ground); it executes THIS FILE's code, so that a typo here is not what the first run on a real node finds.  Run once per round:
+#   SC_MULTI_DEVICE_REHEARSAL=1 python -m pytest tests/test_gpu_multi_device.py -m gpu
+REHEARSAL = os.environ.get("SC_MULTI_DEVICE_REHEARSAL") == "1"
+RCCL_DOUBLE = os.path.join(ROOT, "tests", "rccl_double", "librccl_double.so")
+NDEV = 8 if REHEARSAL else _ndev()
 NMAX = 1 << (min(NDEV, 8).bit_length() - 1) if NDEV >= 1 else 1          # the largest power of two of devices, up to 8
 needs_two = pytest.mark.skipif(
     NDEV < 2, reason="needs >= 2 GPUs in one box (this one shows %d): distinct devices, the real librccl with N > 1 ranks and "
@@ -56,6 +62,8 @@ def _env(transport):
     env = dict(os.environ, SC_WORKER_DISTINCT_DEVICES="1", SC_WORKER_TRANSPORT=transport, HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("SC_RCCL_LIBRARY", "SC_BENCH_SINGLE_DEVICE", "SC_RCCL_DOUBLE_ASYNC_HANG", "SC_BENCH_TRANSPORT", "WORLD_SIZE", "RANK", "LOCAL_RANK"):
         env.pop(k, None)                                                 # the REAL librccl, one device per rank
+    if REHEARSAL:
+        env.update(SC_WORKER_DISTINCT_DEVICES="0", SC_RCCL_LIBRARY=RCCL_DOUBLE, SC_BENCH_SINGLE_DEVICE="1")
     return env
 
 
@@ -121,14 +129,16 @@ def test_peer_plane_fault_injection_between_devices():
 def test_a_rank_dies_under_the_real_rccl(nproc):
     """the last rank leaves between two proofs: the survivors' collective never completes on its own (RCCL's kernel waits for the
     peer), so the library's bound ends it - ncclCommAbort, SC_ERR_RCCL within rccl_timeout_ms, a poisoned context, no hang"""
-    out = _workers(nproc, "rccl_death", "rccl", 31450 + (os.getpid() % 40) + nproc, timeout=600, extra={"SC_WORKER_RCCL_TIMEOUT_MS": "5000"})
+    out = _workers(nproc, "rccl_death", "rccl", 31450 + (os.getpid() % 40) + nproc, timeout=600,
+                   extra=({"SC_WORKER_RCCL_TIMEOUT_MS": "1500", "SC_RCCL_DOUBLE_ASYNC_HANG": "1", "SC_RCCL_DOUBLE_TIMEOUT_MS": "500"} if REHEARSAL
+                          else {"SC_WORKER_RCCL_TIMEOUT_MS": "5000"}))
     assert out.stdout.count("RCCL-DEATH-OK") == nproc - 1, _tail(out)
 
 
 # ---- (b) one process, one handle over distinct devices -------------------------------------------------------------------------
 
 def _handle(pkg, p, n_dev, **opts):
-    ctx = pkg.Context(pkg.Field(p), devices=list(range(n_dev)))
+    ctx = pkg.Context(pkg.Field(p), devices=[0] * n_dev if REHEARSAL else list(range(n_dev)))
     assert ctx.get_option("n_devices") == n_dev and ctx.get_option("transport") == 4
     for k, v in opts.items():
         ctx.set_option(k, v)
@@ -208,7 +218,7 @@ def test_the_one_device_multi_handle_suite_spreads_over_the_devices():
     """tests/test_gpu_multi.py names device d % device_count for shard d: on this box its whole suite (W, triangle, GKR end to end,
     interleaved provers, more provers than tail slots ...) already ran over distinct devices - make that visible"""
     from test_gpu_multi import device_list
-    assert len(set(device_list(NMAX))) == NMAX
+    assert REHEARSAL or len(set(device_list(NMAX))) == NMAX
 
 
 # ---- (d) the bench line of a real N > 1 run --------------------------------------------------------------------------------------
@@ -222,7 +232,7 @@ def test_bench_line_on_real_devices():
     env.pop("SC_WORKER_TRANSPORT")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(NMAX), "--master-addr", "127.0.0.1",
            "--master-port", str(31550 + (os.getpid() % 40)), os.path.join(ROOT, "bench.py"), "--gpus", str(NMAX), "--steps", "5", "--warmup", "2",
-           "--num-vars", "24", "--cpu-num-vars", "0"]
+           "--num-vars", "24", "--cpu-num-vars", "24"]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, cwd=ROOT, env=env)
     assert out.returncode == 0, _tail(out)
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -232,5 +242,6 @@ def test_bench_line_on_real_devices():
     assert d["n_gpus"] == NMAX and set(tr) == {"peer", "rccl", "inproc"}
     for plane in ("peer", "rccl", "inproc"):
         assert tr[plane]["ms_per_step"] and tr[plane]["comm_nranks"] == NMAX, (plane, tr[plane])
-    assert "double" not in str(tr["rccl"].get("library", ""))
-    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"] is not None
+    assert REHEARSAL or "double" not in str(tr["rccl"].get("library", ""))
+    assert d["roofline"]["frac"] > 0 and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] == 1
+    assert "%d-rank transcript is bit-exact vs the CPU oracle at n=24" % NMAX in d["config"]["parity_gate"]
