@@ -160,9 +160,6 @@ const char* sc_last_error(const sc_ctx* ctx);
  *                      ranks' launches of the same pass that is tolerated (default 2000); past it the pass fails
  *                      with SC_ERR_RCCL on every rank that waited.  "peer_connect_ms" (default 120000): how long
  *                      sc_ctx_comm_peer_connect waits for every peer's hello (absorbs the start-up lag of a job)
- *   "host_par_min"     multi-device handle: while the host's tables still hold >= this many entries after a round's fold (and every
- *                      device's slice a whole pair), the round's fold and sums run on the handle's launcher threads, one slice
- *                      each, and the calling thread adds the N triples (default 256; 0 = the calling thread does every round)
  *   "rccl_timeout_ms"  RCCL plane: how long the host waits for work queued behind a collective - a sharded pass's sums, a
  *                      gathered table - before it gives the communicator up (default 30000).  A collective whose peer is gone
  *                      (a rank that died or is out of step) never completes on its own; past the bound, or as soon as

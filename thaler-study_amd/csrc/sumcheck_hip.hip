@@ -218,7 +218,6 @@ struct sc_ctx {
   // on its own: its kernel spins on the device.  Generous by default (a healthy collective takes microseconds; a peer may be
   // seconds late into its first launch)
   int rccl_timeout_ms = 30000;
-  int host_par_min = 256;   // a handle's host rounds run on the launcher threads while >= this many entries are left after the fold (0: never)
   mutable bool comm_failed = false;   // the communicator was given up: every later failure of this context reports SC_ERR_RCCL
   int peer_connect_ms = 120000;   // how long sc_ctx_comm_peer_connect waits for every peer's hello
   // fault injection (tests): delay every sharded launch of this rank by dbg_delay_ms on the host; dbg_skip_tag = 1
