@@ -375,6 +375,16 @@ __device__ __forceinline__ void publish_cells(const WgOut& out, u64 total) {
 
 // What every block does with its cells (thread c < 3^KS holds cell c in `total`): two ticket levels, the last block publishes.
 // Every thread of the block calls it (blocks of 256 threads or more).
+// Ordering (ADVICE r05 asked for it in the memory model rather than in asm): a block's row leaves as agent-scope atomic stores
+// (write-through: they are in memory, not in this XCD's L2, once vmcnt has drained), EVERY storing wave drains (s_waitcnt vmcnt(0)),
+// the workgroup barrier orders the waves, and only then does thread 0 draw the ticket; the block that draws the last one issues an
+// agent-scope acquire before it loads the rows with agent-scope atomic loads.  The ticket itself is RELAXED on purpose: a RELEASE
+// fetch_add makes the compiler put a buffer_wbl2 in front of it - a write-back of everything this XCD's L2 holds dirty, the folded
+// tables included - which is what the stores' write-through and the drain already did for the only data the reader needs, and it
+// costs 1.2-1.4 us per launch (tools/wfbench.hip with -DSC_TICKET_ORDER=__ATOMIC_RELEASE in round 6: wgrid(5,5)@21 23.3 against
+// 21.8 us, wfold(4,5)@21 30.4 against 29.2; profiles/r06_wfold_lds_ab.txt).  What holds the relaxed form in place is measurement:
+// tools/stress_grid.py, tools/stress_handover.py and the 8-process tests draw ~10^5 tickets per run with alternating instances, so
+// that a stale row is a wrong transcript.
 template <class F, int KS>
 __device__ __forceinline__ void wgrid_finish(const F& f, u64 total, const WgOut& out) {
   constexpr int kPow3[6] = {1, 3, 9, 27, 81, 243};
