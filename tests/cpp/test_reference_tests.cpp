@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include <random>
 
+#include "../../thaler-study_amd/host/fiat_shamir.hpp"
 #include "../../thaler-study_amd/host/gkr_protocol.hpp"
 #include "../../thaler-study_amd/host/matrix_multiplication.hpp"
 #include "../../thaler-study_amd/host/triangle_counting.hpp"
@@ -184,7 +185,55 @@ static void gkr_tests() {
   }
 }
 
+#include "fs_fixture.inc"
+static std::string to_hex(const fiat_shamir::Bytes& b) {
+  static const char* d = "0123456789abcdef";
+  std::string s;
+  for (uint8_t x : b) { s.push_back(d[x >> 4]); s.push_back(d[x & 15]); }
+  return s;
+}
+// fiat-shamir/src/lib.rs:216-236 (`it_works`) over the GPU-backed G, and SURVEY 8f rank 3's bytes: a compiled caller of the C ABI
+// produces, message for message, the non-interactive proofs oracle/fs_ref.py committed to tests/golden/fs_transcripts.json
+static void test_fiat_shamir() {
+  using namespace fiat_shamir;
+  {  // the expander against RFC 9380 appendix K.1 (expand_message_xmd, SHA-256), 64-byte Z_pad mode
+    Field g(0xFFFFFFFF00000001ull);
+    const std::string dst = "QUUX-V01-CS02-with-expander-SHA256-128";
+    Sha256FieldHasher h(g, Bytes(dst.begin(), dst.end()), 64);
+    REQUIRE(to_hex(h.expand(Bytes(), 32)) == "68a985b87eb6b46952128911f2a4412bbc302a9d759667f87f7a21d803f07235");
+    const std::string abc = "abc";
+    REQUIRE(to_hex(h.expand(Bytes(abc.begin(), abc.end()), 32)) == "d8ccab23b5985ccea865c6c97b6e5b8350e794e603b4b97902f53a8a0d605615");
+  }
+  for (const FsCase& c : kFsCases) {
+    Field f(c.p);
+    Context ctx(f);
+    sc_table *ha = nullptr, *hb = nullptr;
+    ctx.check(sc_table_generate(ctx.raw(), c.seed_a, 0, (size_t)1 << c.n, &ha), "sc_table_generate");
+    ctx.check(sc_table_generate(ctx.raw(), c.seed_b, 0, (size_t)1 << c.n, &hb), "sc_table_generate");
+    G g(std::make_shared<sumcheck_hip::DeviceMle>(ctx, ha), std::make_shared<sumcheck_hip::DeviceMle>(ctx, hb));
+    Sha256FieldHasher hasher(f);
+    Prover prover(g.clone());
+    const FiatShamirTranscript t = generate_transcript(InteractiveProver(prover, f), hasher);
+    REQUIRE(t.g.size() == (size_t)c.n);
+    for (int j = 0; j < c.n; ++j) REQUIRE(to_hex(t.g[j]) == c.messages[j]);
+    Verifier verifier(c.n, g.clone(), f);
+    REQUIRE(verify_transcript(t, verifier, f, hasher));
+    if (c.p > 5) {   // a tampered message is caught (claim mismatch, failed final check, or codec error); over F_5 the last round's
+      FiatShamirTranscript bad = t;   // only check holds by chance one time in five
+      bad.g[c.n - 1].back() ^= 1;
+      bool ok = true;
+      try {
+        Verifier v2(c.n, g.clone(), f);
+        ok = verify_transcript(bad, v2, f, hasher);
+      } catch (const std::exception&) { ok = false; }   // (ProverClaimMismatch, a codec error, or the reference's assert_eq! at :303)
+      REQUIRE(!ok);
+    }
+  }
+  std::printf("ok fiat_shamir: %zu transcripts byte for byte\n", sizeof(kFsCases) / sizeof(kFsCases[0]));
+}
+
 int main() {
+  test_fiat_shamir();
   Field f5(5);
   Context ctx(f5);
   StdRng rng(f5, 42);
