@@ -38,6 +38,7 @@ every correctness check use oracle/ as the checker only; the measured path is li
 import argparse
 import json
 import os
+import re
 import statistics
 import sys
 import time
@@ -166,6 +167,59 @@ def traffic_source(rec):
     return ("profiles/traffic.json: `%s` on the builder's GPU box, %s, commit %s, kernel sources %s (= this tree's); FETCH_SIZE x 2 KiB + "
             "WRITE_SIZE x 1 KiB per MI355X_MICROARCH.md; not collected in this run, handed out only if this run's launch-log bytes agree "
             "within 2 %%" % (prov.get("command"), prov.get("date"), prov.get("commit") or "not recorded", prov.get("csrc_sha16")))
+
+
+def self_pmc(args, n, schedule):
+    """FIRST-HAND HBM bytes for `roofline.traffic`: after the timed region, two child runs of this very workload under
+    `rocprofv3 --kernel-trace --pmc FETCH_SIZE` and `... --pmc WRITE_SIZE` (separate passes, as MI355X_MICROARCH.md's HBM section
+    prescribes; the program itself after `--`), on THIS box - a profiler has to wrap a program from its start, so it is a child
+    process (started, not exec'ed: this process holds the GPU).  Returns (bytes per launch of one proof in schedule order, what was
+    run) or (None, why not).  Off: SC_BENCH_SELF_PMC=0; by default only for the headline shape (n = 28, one GPU)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    rocprof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not rocprof:
+        return None, "rocprofv3 not found on this box"
+    if any(k.startswith("ROCPROF") for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(SC_BENCH_SELF_PMC="0", SC_BENCH_RAMP_MS="0", SC_BENCH_SECONDARY="0", TMPDIR="/tmp")
+    child = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--cpu-num-vars", "0", "--num-vars", str(n),
+             "--vars-per-pass", str(args.vars_per_pass), "--field", args.field]
+    vals = {}
+    for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+        out = tempfile.mkdtemp(prefix="sc_pmc_", dir="/tmp")
+        try:
+            r = subprocess.run([rocprof, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child, cwd="/tmp", env=env,
+                               capture_output=True, text=True, timeout=float(os.environ.get("SC_BENCH_SELF_PMC_TIMEOUT", "240")))
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None, "the %s pass failed (rc %d): %s" % (counter, r.returncode, (r.stderr or r.stdout)[-200:])
+            rows = [x for x in csv.DictReader(open(max(files, key=os.path.getmtime))) if x["Counter_Name"] == counter and "pass_kernel<" in x["Kernel_Name"]]
+        except Exception as e:      # a profiler that does not start or does not end: the record in profiles/ is used instead
+            return None, "the %s pass: %s" % (counter, str(e)[:200])
+        finally:
+            shutil.rmtree(out, ignore_errors=True)
+        # the launches of the LAST proof of the child's trace: a proof starts with the matrix-core pass or a pass that folds nothing
+        steps, cur = [], []
+        for x in rows:
+            name = x["Kernel_Name"]
+            m = re.search(r"[^_]pass_kernel<sc::\w+, (\d), (\d)", " " + name)
+            first = "gram_pass_kernel<" in name or (m is not None and m.group(1) == "0" and "wgrid" not in name and "wfold" not in name)
+            if first and cur:
+                steps.append(cur)
+                cur = []
+            cur.append(float(x["Counter_Value"]))
+        if cur:
+            steps.append(cur)
+        if not steps or len(steps[-1]) != len(schedule):
+            return None, "the %s pass shows %d launches in its last proof, this run's schedule has %d" % (counter, len(steps[-1]) if steps else 0, len(schedule))
+        vals[counter] = steps[-1]
+    per_launch = [f * 2 * 1024 + w * 1024 for f, w in zip(vals["FETCH_SIZE"], vals["WRITE_SIZE"])]
+    return per_launch, "`rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py %s`" % " ".join(child[2:])
 
 
 def reference_probe():
@@ -617,6 +671,24 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                 if dev > 0.02:
                     traffic, traffic_step = None, None
                     sys.stderr.write("bench.py: " + traffic_check + "\n")
+        # first-hand counters where this is the headline shape (or asked for): two child runs under rocprofv3 --pmc on THIS box
+        own_traffic, own_source, traffic_record = None, None, traffic
+        want_own = os.environ.get("SC_BENCH_SELF_PMC", "1")
+        if world == 1 and dom and want_own != "0" and (want_own == "force" or (n == 28 and args.vars_per_pass == 2)):
+            own, how = self_pmc(args, n, schedule)
+            if own:
+                idx = next((i for i, sc in enumerate(schedule) if tuple(sc) == tuple(dom["_key"])), None)
+                if idx is not None and abs(sum(own) - moved) / moved <= 0.02:
+                    own_traffic, own_source = own[idx], ("this run's box, after the timed region: two child passes of " + how +
+                                                         "; FETCH_SIZE x 2 KiB + WRITE_SIZE x 1 KiB per MI355X_MICROARCH.md (gfx950 reports half of a wide read)")
+                    traffic_step = sum(own)
+                    traffic_check = "ok: launches of this run move %.5g B/step, this box's PMC %.5g (%.2f %% apart)" % (moved, sum(own), abs(sum(own) - moved) / moved * 100)
+                else:
+                    own_source = "own PMC passes disagree with the launch log (%.5g vs %.5g B/step): withheld" % (sum(own), moved)
+            else:
+                own_source = "own PMC passes not available: " + how
+            if own_traffic is not None:
+                traffic = own_traffic
         result = {
             "metric": "field mul-adds/sec in sumcheck prover, n=%d vars" % n + ("" if FIELD["name"] == "GoldilocksMont" else " (generic modulus)"),
             "value": value,
@@ -661,7 +733,9 @@ def run_prover(args, pkg, torch, dist, rank, world, local_rank):
                 "unit": "GB/s",
                 "frac": dom["GBps"] / HBM_PEAK_GBS if dom and dom["GBps"] else None,
                 "traffic": traffic,
-                "traffic_source": traffic_source(tj) if traffic else traffic_check,
+                "traffic_source": own_source if own_traffic is not None else (traffic_source(tj) if traffic else traffic_check),
+                "traffic_record": {"hbm_bytes_per_launch": traffic_record, "source": traffic_source(tj) if traffic_record else None,
+                                   "own_pmc": own_source} if own_source else None,
                 "bytes_per_launch": dom["bytes_per_launch"] if dom else None,
                 "avg_launch_us": dom["avg_us"] if dom else None,
                 "per_gpu": True,

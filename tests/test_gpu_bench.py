@@ -101,3 +101,19 @@ def test_bench_generic_field():
     assert "MontGeneric" in d["roofline"]["kernel"] and 0 < d["roofline"]["frac"] <= 1.0
     assert "bit-exact vs CPU oracle at n=16 ok" in d["config"]["parity_gate"]
     assert d["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_collects_its_own_pmc_traffic():
+    """`roofline.traffic` first-hand: asked for at a small size (SC_BENCH_SELF_PMC=force; by default only the headline shape does it),
+    bench.py starts two child runs of its own workload under `rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE` after the
+    timed region and reports the dominant launch's HBM bytes as this box measured them, next to the launch log's"""
+    env = dict(os.environ, SC_BENCH_SELF_PMC="force")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--num-vars", "24", "--steps", "6", "--warmup", "2", "--cpu-num-vars", "0"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    r = d["roofline"]
+    assert r["traffic"] is not None and "this run's box" in r["traffic_source"], (r["traffic"], r["traffic_source"], r.get("traffic_record"))
+    assert 0.9 < r["traffic"] / r["bytes_per_launch"] < 1.1, (r["traffic"], r["bytes_per_launch"])
+    assert r["step"]["traffic_check"].startswith("ok")

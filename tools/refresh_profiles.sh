@@ -9,6 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 # the profiled runs skip bench.py's clock-ramp setup phase (the summaries index the proofs of a run by position); the
 # un-profiled lines keep it (their own SC_BENCH_RAMP_MS=80)
 export SC_BENCH_RAMP_MS=0
+export SC_BENCH_SELF_PMC=0   # (the profiled runs below ARE the PMC passes; bench.py must not start its own)
 mkdir -p $O/profiles_$TAG
 run_one() {   # name, bench args, summariser, extra summariser args
   local WL=$1 EXTRA=$2 SUM=$3 SARG=$4
